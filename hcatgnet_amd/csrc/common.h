@@ -1,0 +1,56 @@
+// Internal helpers shared by the HIP translation units of libhcatgnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hcatgnet_hip.h"
+
+#define HCG_WAVE 64
+
+static inline int hcg_hip_err(hipError_t e) { return e == hipSuccess ? HCG_OK : (HCG_ERR_HIP_BASE - (int)e); }
+
+// launch + return on error (kernel launch errors are sticky-free: read with hipGetLastError)
+#define HCG_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    hipError_t _e = hipGetLastError();                      \
+    if (_e != hipSuccess) return hcg_hip_err(_e);           \
+  } while (0)
+
+#define HCG_TRY(expr)                 \
+  do {                                \
+    int _rc = (expr);                 \
+    if (_rc != HCG_OK) return _rc;    \
+  } while (0)
+
+static inline size_t hcg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int64_t hcg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// bump allocator over the caller's workspace
+struct HcgArena {
+  char* base;
+  size_t size, off;
+  HcgArena(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = hcg_align_up(count * sizeof(T), 256);
+    if (off + bytes > size) return nullptr;
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+__device__ __forceinline__ float hcg_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float hcg_leaky_grad(float y_out, float slope) { return y_out > 0.f ? 1.f : slope; }
+
+// ---- internal launchers implemented in gemm.hip -------------------------------------------
+// C[M,N] = sum_k A(m,k) B(k,n), A(m,k) at A[m*sam + k*sak], B(k,n) at B[k*sbk + n*sbn];
+// epilogue: + bias[n] (nullable), LeakyReLU when act.  splits > 1: deterministic split-K through
+// `partials` ([splits, M, N] floats).
+size_t hcg_gemm_partial_floats(int64_t M, int64_t N, int64_t K, int* splits_out);
+int hcg_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+             float* C, int64_t M, int64_t N, int64_t K, const float* bias, int act, float slope,
+             float* partials, size_t partial_floats, hipStream_t stream);
+// out[d] = sum_m src[m, d]  (deterministic two-stage); partials >= colsum_partial_floats
+size_t hcg_colsum_partial_floats(int64_t M, int64_t D);
+int hcg_colsum(const float* src, float* out, int64_t M, int64_t D, float* partials, hipStream_t stream);

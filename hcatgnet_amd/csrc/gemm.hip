@@ -1,0 +1,197 @@
+// General-shape fp32 GEMM on the f32-input matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact
+// f32, a k-ordered fmaf chain), used by the any-shape path for
+//   a4 / a10  y  = x W^T (+b, LeakyReLU)      reference: GCNConv.lin, readout nn.Linear (model/gcn.py:18-45)
+//   a11       dW = dz^T x   (split-K over the node dimension, deterministic 2-stage reduce)
+//             dx = dz W
+// The fused per-graph kernels (fused.hip) carry their own MFMA loops; this file is the fallback
+// that accepts any M, N, K and any of the three operand orientations through element strides.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDS_STRIDE = 65;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Stage a [BK x 64] operand tile into LDS as tile[k][i] (i = m for A, n for B).
+// elem(i, k) lives at base[i*si + k*sk]; the thread->element map follows the unit stride so the
+// global reads are coalesced for every orientation.
+__device__ __forceinline__ void stage_tile(const float* __restrict__ base, int64_t si, int64_t sk,
+                                           int64_t i0, int64_t imax, int64_t k0, int64_t kmax,
+                                           float (*tile)[LDS_STRIDE], int tid) {
+  if (sk == 1) {  // k contiguous: 16 consecutive threads walk one row's k-range
+    const int k = tid & (BK - 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = (tid >> 4) + it * 16;
+      const int64_t gi = i0 + i, gk = k0 + k;
+      float v = 0.f;
+      if (gi < imax && gk < kmax) v = base[gi * si + gk];
+      tile[k][i] = v;
+    }
+  } else {  // i contiguous (or generic): 64 consecutive threads walk the i-range
+    const int i = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int k = (tid >> 6) + it * 4;
+      const int64_t gi = i0 + i, gk = k0 + k;
+      float v = 0.f;
+      if (gi < imax && gk < kmax) v = base[gi * si + gk * sk];
+      tile[k][i] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                              const float* __restrict__ B, int64_t sbk, int64_t sbn,
+                                              float* __restrict__ C, int64_t M, int64_t N, int64_t K,
+                                              int64_t k_per_split, const float* __restrict__ bias, int act,
+                                              float slope, float* __restrict__ partials) {
+  __shared__ float As[BK][LDS_STRIDE];
+  __shared__ float Bs[BK][LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    stage_tile(A, sam, sak, m0, M, k0, kend, As, tid);
+    stage_tile(B, sbn, sbk, n0, N, k0, kend, Bs, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = As[kk + (lane >> 5)][wr * 32 + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wc * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int64_t n = n0 + wc * 32 + (lane & 31);
+  if (n >= N) return;
+  const bool direct = (partials == nullptr);
+  const float bv = (direct && bias) ? bias[n] : 0.f;
+  float* dst = direct ? C : partials + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < M) {
+      float v = acc[r];
+      if (direct) {
+        v += bv;
+        if (act) v = hcg_leaky(v, slope);
+      }
+      dst[m * N + n] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partials, float* __restrict__ C,
+                                                       int64_t MN, int64_t N, int splits,
+                                                       const float* __restrict__ bias, int act, float slope) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += partials[(size_t)z * MN + i];  // fixed order: deterministic
+  if (bias) s += bias[i % N];
+  if (act) s = hcg_leaky(s, slope);
+  C[i] = s;
+}
+
+constexpr int CS_ROWS = 128;
+
+// partial[b][d] = sum over rows [b*CS_ROWS, ...) of src[m][d] * (mask ? leaky'(mask[m][d]) : 1)
+__global__ __launch_bounds__(256) void k_colsum_stage1(const float* __restrict__ src, const float* __restrict__ mask,
+                                                       float slope, float* __restrict__ partial, int64_t M, int64_t D) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const int64_t mbeg = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t mend = mbeg + CS_ROWS < M ? mbeg + CS_ROWS : M;
+  float s = 0.f;
+  for (int64_t m = mbeg; m < mend; ++m) {
+    float v = src[m * D + d];
+    if (mask) v *= hcg_leaky_grad(mask[m * D + d], slope);
+    s += v;
+  }
+  partial[(size_t)blockIdx.y * D + d] = s;
+}
+
+__global__ __launch_bounds__(256) void k_colsum_stage2(const float* __restrict__ partial, float* __restrict__ out,
+                                                       int64_t nb, int64_t D) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < nb; ++b) s += partial[(size_t)b * D + d];
+  out[d] = s;
+}
+
+}  // namespace
+
+size_t hcg_gemm_partial_floats(int64_t M, int64_t N, int64_t K, int* splits_out) {
+  const int64_t tiles = hcg_cdiv(M, BM) * hcg_cdiv(N, BN);
+  int64_t splits = 1;
+  if (tiles < 256 && K >= 2048) {
+    splits = 1024 / tiles;
+    const int64_t max_splits = hcg_cdiv(K, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  if (splits_out) *splits_out = (int)splits;
+  return splits > 1 ? (size_t)splits * M * N : 0;
+}
+
+int hcg_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+             int64_t M, int64_t N, int64_t K, const float* bias, int act, float slope, float* partials,
+             size_t partial_floats, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return HCG_OK;
+  if (K <= 0) {  // empty contraction: C = act(bias)
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 256)), dim3(256), 0, stream,
+                       (const float*)nullptr, C, M * N, N, 0, bias, act, slope);
+    HCG_CHECK_LAUNCH();
+    return HCG_OK;
+  }
+  int splits = 1;
+  const size_t need = hcg_gemm_partial_floats(M, N, K, &splits);
+  if (splits > 1 && (partials == nullptr || partial_floats < need)) splits = 1;  // degrade, never fail
+  int64_t kper = hcg_cdiv(hcg_cdiv(K, splits), BK) * BK;
+  splits = (int)hcg_cdiv(K, kper);
+  dim3 grid((unsigned)hcg_cdiv(N, BN), (unsigned)hcg_cdiv(M, BM), (unsigned)splits);
+  if (grid.y > 65535u) return HCG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, stream, A, sam, sak, B, sbk, sbn, C, M, N, K, kper, bias, act,
+                     slope, splits > 1 ? partials : (float*)nullptr);
+  HCG_CHECK_LAUNCH();
+  if (splits > 1) {
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 256)), dim3(256), 0, stream,
+                       (const float*)partials, C, M * N, N, splits, bias, act, slope);
+    HCG_CHECK_LAUNCH();
+  }
+  return HCG_OK;
+}
+
+size_t hcg_colsum_partial_floats(int64_t M, int64_t D) { return (size_t)hcg_cdiv(M > 0 ? M : 1, CS_ROWS) * D; }
+
+// masked variant is reached through hcg_colsum_masked (declared below for layer.hip)
+int hcg_colsum_masked(const float* src, const float* mask, float slope, float* out, int64_t M, int64_t D,
+                      float* partials, hipStream_t stream) {
+  if (D <= 0) return HCG_OK;
+  const int64_t nb = hcg_cdiv(M > 0 ? M : 1, CS_ROWS);
+  if (nb > 65535) {
+    return HCG_ERR_UNSUPPORTED;
+  }
+  dim3 g1((unsigned)hcg_cdiv(D, 256), (unsigned)nb);
+  hipLaunchKernelGGL(k_colsum_stage1, g1, dim3(256), 0, stream, src, mask, slope, partials, M, D);
+  HCG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)hcg_cdiv(D, 256)), dim3(256), 0, stream,
+                     (const float*)partials, out, nb, D);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+int hcg_colsum(const float* src, float* out, int64_t M, int64_t D, float* partials, hipStream_t stream) {
+  return hcg_colsum_masked(src, nullptr, 0.f, out, M, D, partials, stream);
+}

@@ -1,0 +1,128 @@
+/*
+ * hcatgnet_hip.h -- C ABI of libhcatgnet_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ONE path of EdAguilarB/hcatgnet: the GCN message-passing
+ * forward+backward that `GCN.forward` (reference model/gcn.py:54-76) runs through
+ * torch_geometric.  The reference has no FFI layer of its own (pure Python on PyG); this ABI is
+ * what a Python `nn.Module` binds with ctypes in place of
+ *   - torch_geometric.nn.GCNConv            (call sites model/gcn.py:18-20, 27-29, 58, 62, 127, 131)
+ *   - torch_geometric.nn.global_max_pool /
+ *     global_mean_pool + torch.cat           (call sites model/gcn.py:65-66, 134-135)
+ *   - the readout nn.Linear/LeakyReLU stack  (model/gcn.py:36-45, 70-71)
+ *   - torch autograd through all of the above (utils/utils_model.py:65 `loss.backward()`)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - fp32 tensors are row-major contiguous; `edge_index` is int64 [2,E] contiguous
+ *     (row 0 = source, row 1 = target: flow source->target, as in the reference data/rhcaa.py:160);
+ *     `batch` is int64 [N], non-decreasing graph id; derived indices are int32;
+ *   - the caller (PyTorch) owns every buffer; the library never allocates or frees device
+ *     memory, keeps no global state, and only ENQUEUES work on the `stream` it is given
+ *     (no internal synchronisation) -- safe under hipGraph capture and one-process-per-GPU DP;
+ *   - every function returns an int: 0 = HCG_OK, negative = error (see below);
+ *     nothing throws or exits across the ABI;
+ *   - data-dependent violations that only the device can see (index out of range, unsorted
+ *     `batch`, an edge that crosses graphs in blocked mode) are reported through the 4-word
+ *     `status` array written by hcg_plan_build: the host wrapper reads it when it chooses to sync.
+ */
+#ifndef HCATGNET_HIP_H
+#define HCATGNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCG_ABI_VERSION 1
+
+#define HCG_OK 0
+#define HCG_ERR_INVALID_ARG (-1)
+#define HCG_ERR_WORKSPACE (-2)   /* caller-provided workspace too small */
+#define HCG_ERR_UNSUPPORTED (-3) /* shape not supported by this entry point */
+#define HCG_ERR_HIP_BASE (-1000) /* -1000 - hipError_t */
+
+/* hcg_plan_build flags */
+#define HCG_PLAN_GENERAL 0 /* device radix sort; any edge order, any graph size           */
+#define HCG_PLAN_BLOCKED 1 /* edges grouped by graph (PyG collate order); per-graph waves */
+
+/* bits of status[0] written by hcg_plan_build */
+#define HCG_STATUS_INDEX_RANGE 1   /* an edge_index entry outside [0,N)                  */
+#define HCG_STATUS_BATCH_UNSORTED 2 /* batch not non-decreasing                           */
+#define HCG_STATUS_BATCH_RANGE 4   /* a batch id outside [0,B)                           */
+#define HCG_STATUS_EDGE_UNGROUPED 8 /* blocked mode: edges not grouped by graph / cross   */
+#define HCG_STATUS_SHAPE_LIMIT 16  /* fused mode: a graph exceeds the tile the host chose */
+
+/* activation codes of hcg_linear_* */
+#define HCG_ACT_NONE 0
+#define HCG_ACT_LEAKY 1
+
+typedef void* hcg_stream_t; /* hipStream_t */
+
+int hcg_version(void);
+const char* hcg_error_string(int code);
+
+/* ---- batch plan: gcn_norm + CSR/CSC + graph_ptr, ONCE per batch (reference recomputes
+ *      gcn_norm every layer, every step: PyG GCNConv(cached=False)) ---------- */
+size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode);
+
+/* Outputs (all caller-allocated):
+ *   graph_ptr [B+1]  node range of each graph                    (a9's `batch`)
+ *   edge_ptr  [B+1]  edge range of each graph in CSR order (blocked mode; may be NULL in general)
+ *   rowptr [N+1], col [E], eid [E]      incoming edges of each node, stable in input order:
+ *                                       col = source id, eid = position in edge_index
+ *   rowptr_t [N+1], col_t [E], eid_t [E] outgoing edges (the transpose, for the backward)
+ *   dinv [N]         (fill + sum of incoming weights)^-1/2, 0 where the degree is 0
+ *   ew_csr, ew_csc [E]  edge weights permuted to CSR / CSC order (only when edge_weight != NULL)
+ *   status [4]       status[0] = OR of HCG_STATUS_* bits (0 = clean)
+ */
+int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, const float* edge_weight,
+                   int64_t N, int64_t E, int64_t B, float fill, int mode,
+                   int32_t* graph_ptr, int32_t* edge_ptr,
+                   int32_t* rowptr, int32_t* col, int32_t* eid,
+                   int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
+                   float* dinv, float* ew_csr, float* ew_csc, int32_t* status,
+                   void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
+/* ---- dense linear (a4, a10):  y = act(x W^T + b),  W is [D_out, D_in] like nn.Linear ------ */
+size_t hcg_linear_workspace_bytes(int64_t M, int64_t D_in, int64_t D_out);
+int hcg_linear_fwd(const float* x, const float* W, const float* b /*nullable*/, float* y,
+                   int64_t M, int64_t D_in, int64_t D_out, int act, float slope, hcg_stream_t stream);
+/* dz = dy * act'(y) is formed internally (y = saved OUTPUT); then dW = dz^T x, db = colsum dz,
+ * dx = dz W (dx nullable).  dz_ws: caller buffer [M, D_out] (may alias nothing). */
+int hcg_linear_bwd(const float* dy, const float* y, const float* x, const float* W,
+                   float* dx /*nullable*/, float* dW, float* db /*nullable*/, float* dz_ws,
+                   int64_t M, int64_t D_in, int64_t D_out, int act, float slope,
+                   void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
+/* ---- one GCNConv + bias + LeakyReLU (a4-a8), general shapes ------------------------------
+ *   h = x W^T ; out_i = leaky( dinv_i * sum_{k in row i} w_k dinv_col[k] h_col[k]
+ *                               + fill * dinv_i^2 h_i + b )
+ *   h_ws: caller buffer [N, D] (the pre-aggregation features; not needed afterwards). */
+int hcg_gcn_layer_fwd(const float* x, const float* W, const float* b,
+                      const int32_t* rowptr, const int32_t* col, const float* ew_csr /*nullable*/,
+                      const float* dinv, float fill, float slope, int apply_act,
+                      float* h_ws, float* out, int64_t N, int64_t E, int64_t F, int64_t D,
+                      hcg_stream_t stream);
+/* backward of the above.  `out` = saved output (gives the LeakyReLU mask), `x` = saved input.
+ *   dh_ws: caller buffer [N, D].  dx nullable (first layer: x has no grad). */
+size_t hcg_gcn_layer_bwd_workspace_bytes(int64_t N, int64_t F, int64_t D);
+int hcg_gcn_layer_bwd(const float* dout, const float* out, const float* x, const float* W,
+                      const int32_t* rowptr_t, const int32_t* col_t, const float* ew_csc /*nullable*/,
+                      const float* dinv, float fill, float slope, int apply_act,
+                      float* dh_ws, float* dx /*nullable*/, float* dW, float* db,
+                      int64_t N, int64_t E, int64_t F, int64_t D,
+                      void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
+/* ---- graph pooling (a9): emb[g] = [ max_i a_i , mean_i a_i ]  (max FIRST, model/gcn.py:65-66) */
+int hcg_pool_fwd(const float* a, const int32_t* graph_ptr, float* emb /*[B,2D]*/,
+                 int64_t N, int64_t B, int64_t D, hcg_stream_t stream);
+/* da_i = demb_max[g] * [a_i == max_g] / #ties  +  demb_mean[g] / n_g   (torch amax semantics) */
+int hcg_pool_bwd(const float* demb, const float* a, const float* emb, const int32_t* graph_ptr,
+                 float* da, int64_t N, int64_t B, int64_t D, hcg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCATGNET_HIP_H */
