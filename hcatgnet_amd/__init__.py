@@ -1,0 +1,18 @@
+"""hcatgnet_amd -- MI355X-native drop-in for the GCN message-passing path of EdAguilarB/hcatgnet.
+
+Public surface (mirrors the reference's names for this path):
+    make_network("GCN", opt, n_node_features)   reference call_methods.py:7-12
+    GCN, GCN_explain, BaseNetwork               reference model/gcn.py, model/networks.py
+    Data, Batch, collate, DataLoader            stand-ins for the PyG containers the loops touch
+    BatchPlan                                   per-batch CSR / gcn_norm plan (GPU)
+    DataParallelGCN                             one-process-per-GPU gradient all-reduce (RCCL)
+Compute lives in csrc/libhcatgnet_hip.so (hand-written HIP for gfx950) behind include/hcatgnet_hip.h.
+"""
+from .batch import Batch, Data, DataLoader, collate  # noqa: F401
+from .call_methods import default_options, make_network  # noqa: F401
+from .gcn import GCN, GCN_explain, GCNConv  # noqa: F401
+from .networks import BaseNetwork  # noqa: F401
+from .plan import BatchPlan  # noqa: F401
+
+__all__ = ["make_network", "default_options", "GCN", "GCN_explain", "GCNConv", "BaseNetwork", "Data", "Batch",
+           "collate", "DataLoader", "BatchPlan"]

@@ -1,0 +1,97 @@
+"""ctypes binding of libhcatgnet_hip.so (the C ABI declared in include/hcatgnet_hip.h).
+
+There is NO CPU fallback: if the library is missing, or a tensor is not on an MI355X, every
+entry point raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from this package.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhcatgnet_hip.so")
+
+HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED = 0, 1
+HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
+STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
+               4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
+               16: "a graph exceeds the fused-kernel tile"}
+STATUS_EDGE_UNGROUPED = 8
+
+P, I64, SZ, F32, INT = c_void_p, c_int64, c_size_t, c_float, c_int
+
+# name -> (restype, argtypes); must list every symbol of include/hcatgnet_hip.h
+SIGNATURES = {
+    "hcg_version": (INT, []),
+    "hcg_error_string": (c_char_p, [INT]),
+    "hcg_plan_workspace_bytes": (SZ, [I64, I64, I64, INT]),
+    "hcg_plan_build": (INT, [P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "hcg_linear_workspace_bytes": (SZ, [I64, I64, I64]),
+    "hcg_linear_fwd": (INT, [P, P, P, P, I64, I64, I64, INT, F32, P]),
+    "hcg_linear_bwd": (INT, [P, P, P, P, P, P, P, P, I64, I64, I64, INT, F32, P, SZ, P]),
+    "hcg_gcn_layer_fwd": (INT, [P, P, P, P, P, P, P, F32, F32, INT, P, P, I64, I64, I64, I64, P]),
+    "hcg_gcn_layer_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
+    "hcg_gcn_layer_bwd": (INT, [P, P, P, P, P, P, P, P, F32, F32, INT, P, P, P, P, I64, I64, I64, I64, P, SZ, P]),
+    "hcg_pool_fwd": (INT, [P, P, P, I64, I64, I64, P]),
+    "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
+}
+
+_lib = None
+
+
+class HcgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HcgError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C hcatgnet_amd/csrc`). hcatgnet_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI/header drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hcg_version() != 1:
+        raise HcgError(f"ABI version mismatch: library reports {lib.hcg_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().hcg_error_string(rc)
+        raise HcgError(f"{what} failed: {msg.decode() if msg else rc} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HcgError("hcatgnet_amd runs on MI355X (ROCm) tensors only; got a CPU tensor. "
+                           "There is no CPU fallback: move the model and the batch to the GPU.")
+    if not torch.cuda.is_available():
+        raise HcgError("no ROCm GPU visible")
+
+
+def describe_status(word: int) -> str:
+    return "; ".join(msg for bit, msg in STATUS_BITS.items() if word & bit) or "ok"

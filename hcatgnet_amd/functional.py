@@ -1,0 +1,166 @@
+"""autograd Functions over the C ABI: GCN layer, graph pooling, dense linear.
+
+These stand in for what the reference reaches through torch_geometric + torch autograd:
+`GCNConv.forward` (gcn_norm, Linear, propagate: gather / message / scatter_add, bias) followed by
+LeakyReLU (model/gcn.py:58-63), `global_max_pool` / `global_mean_pool` (model/gcn.py:65-66), the
+readout Linear(+LeakyReLU) stack (model/gcn.py:70-71) and `loss.backward()` through them
+(utils/utils_model.py:65).  All arithmetic runs in libhcatgnet_hip.so; torch only owns memory.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .plan import BatchPlan
+
+LEAKY_SLOPE = 0.01  # nn.LeakyReLU() default (reference model/gcn.py:21, :63)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.HcgError(f"hcatgnet_amd computes in float32; got {t.dtype}")
+    return t.contiguous()
+
+
+class _GCNLayerFn(torch.autograd.Function):
+    """out = leaky_relu( Ahat (x W^T) + b ), Ahat = D^-1/2 (A + fill I) D^-1/2 from the plan."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, plan: BatchPlan, use_edge_weight: bool, apply_act: bool, slope: float):
+        lib = _lib.load()
+        _lib.require_gpu(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, F = x.shape
+        D = weight.shape[0]
+        if weight.shape[1] != F or N != plan.N:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(weight.shape)}, plan N {plan.N}")
+        out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+        h_ws = torch.empty(N, D, dtype=torch.float32, device=x.device)
+        ew = plan.ew_csr if use_edge_weight else None
+        fill = plan.fill if use_edge_weight else 1.0
+        rc = lib.hcg_gcn_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.rowptr),
+                                   _lib.ptr(plan.col), _lib.ptr(ew), _lib.ptr(ctx_dinv(plan, use_edge_weight)),
+                                   fill, slope, int(apply_act), _lib.ptr(h_ws), _lib.ptr(out), N, plan.E, F, D,
+                                   _lib.stream_ptr())
+        _lib.check(rc, "hcg_gcn_layer_fwd")
+        ctx.save_for_backward(x, weight, out)
+        ctx.plan, ctx.use_ew, ctx.apply_act, ctx.slope = plan, use_edge_weight, apply_act, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight, out = ctx.saved_tensors
+        plan = ctx.plan
+        dout = _f32c(dout)
+        N, F = x.shape
+        D = weight.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(D, dtype=torch.float32, device=dev)
+        dh_ws = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+        wsb = lib.hcg_gcn_layer_bwd_workspace_bytes(N, F, D)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ew = plan.ew_csc if ctx.use_ew else None
+        fill = plan.fill if ctx.use_ew else 1.0
+        rc = lib.hcg_gcn_layer_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(x), _lib.ptr(weight),
+                                   _lib.ptr(plan.rowptr_t), _lib.ptr(plan.col_t), _lib.ptr(ew),
+                                   _lib.ptr(ctx_dinv(plan, ctx.use_ew)), fill, ctx.slope, int(ctx.apply_act),
+                                   _lib.ptr(dh_ws), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), N, plan.E, F, D,
+                                   _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_gcn_layer_bwd")
+        return dx, dW, db, None, None, None, None
+
+
+def ctx_dinv(plan: BatchPlan, use_edge_weight: bool):
+    """dinv to use for a layer.  The reference passes `edge_weight` to conv1 only
+    (model/gcn.py:58 vs :62); the other layers run unweighted with fill 1 (plan.dinv_unw)."""
+    if plan.ew_csr is not None and not use_edge_weight:
+        return plan.dinv_unw
+    return plan.dinv
+
+
+class _PoolFn(torch.autograd.Function):
+    """emb = cat[global_max_pool(a), global_mean_pool(a)]  ([B, 2D], max first)."""
+
+    @staticmethod
+    def forward(ctx, a, plan: BatchPlan):
+        lib = _lib.load()
+        _lib.require_gpu(a)
+        a = _f32c(a)
+        N, D = a.shape
+        emb = torch.zeros(plan.B, 2 * D, dtype=torch.float32, device=a.device)
+        rc = lib.hcg_pool_fwd(_lib.ptr(a), _lib.ptr(plan.graph_ptr), _lib.ptr(emb), N, plan.B, D, _lib.stream_ptr())
+        _lib.check(rc, "hcg_pool_fwd")
+        ctx.save_for_backward(a, emb)
+        ctx.plan = plan
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        lib = _lib.load()
+        a, emb = ctx.saved_tensors
+        plan = ctx.plan
+        demb = _f32c(demb)
+        N, D = a.shape
+        da = torch.zeros_like(a)
+        rc = lib.hcg_pool_bwd(_lib.ptr(demb), _lib.ptr(a), _lib.ptr(emb), _lib.ptr(plan.graph_ptr), _lib.ptr(da), N,
+                              plan.B, D, _lib.stream_ptr())
+        _lib.check(rc, "hcg_pool_bwd")
+        return da, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) with act in {identity, LeakyReLU}."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, apply_act: bool, slope: float):
+        lib = _lib.load()
+        _lib.require_gpu(x, weight, bias)
+        x, weight = _f32c(x), _f32c(weight)
+        bias = _f32c(bias) if bias is not None else None
+        M, K = x.shape
+        O = weight.shape[0]
+        if weight.shape[1] != K:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+        y = torch.empty(M, O, dtype=torch.float32, device=x.device)
+        rc = lib.hcg_linear_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), M, K, O,
+                                _lib.HCG_ACT_LEAKY if apply_act else _lib.HCG_ACT_NONE, slope, _lib.stream_ptr())
+        _lib.check(rc, "hcg_linear_fwd")
+        ctx.save_for_backward(x, weight, y)
+        ctx.has_bias, ctx.apply_act, ctx.slope = bias is not None, apply_act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, K = x.shape
+        O = weight.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dz = torch.empty(max(M, 1), O, dtype=torch.float32, device=dev)
+        wsb = lib.hcg_linear_workspace_bytes(M, K, O)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.hcg_linear_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(dx), _lib.ptr(dW),
+                                _lib.ptr(db), _lib.ptr(dz), M, K, O,
+                                _lib.HCG_ACT_LEAKY if ctx.apply_act else _lib.HCG_ACT_NONE, ctx.slope, _lib.ptr(ws), wsb,
+                                _lib.stream_ptr())
+        _lib.check(rc, "hcg_linear_bwd")
+        return dx, dW, db, None, None
+
+
+def gcn_layer(x, weight, bias, plan: BatchPlan, use_edge_weight=False, apply_act=True, slope=LEAKY_SLOPE):
+    return _GCNLayerFn.apply(x, weight, bias, plan, use_edge_weight, apply_act, slope)
+
+
+def graph_pool(a, plan: BatchPlan):
+    return _PoolFn.apply(a, plan)
+
+
+def linear(x, weight, bias=None, apply_act=False, slope=LEAKY_SLOPE):
+    return _LinearFn.apply(x, weight, bias, apply_act, slope)

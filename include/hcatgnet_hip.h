@@ -75,6 +75,8 @@ size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode);
  *   rowptr_t [N+1], col_t [E], eid_t [E] outgoing edges (the transpose, for the backward)
  *   dinv [N]         (fill + sum of incoming weights)^-1/2, 0 where the degree is 0
  *   ew_csr, ew_csc [E]  edge weights permuted to CSR / CSC order (only when edge_weight != NULL)
+ *   dinv_unw [N]     (1 + in-degree)^-1/2, only when edge_weight != NULL: the reference hands the
+ *                    weights to conv1 only (model/gcn.py:58 vs :62), later layers run unweighted
  *   status [4]       status[0] = OR of HCG_STATUS_* bits (0 = clean)
  */
 int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, const float* edge_weight,
@@ -82,7 +84,7 @@ int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, const float*
                    int32_t* graph_ptr, int32_t* edge_ptr,
                    int32_t* rowptr, int32_t* col, int32_t* eid,
                    int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
-                   float* dinv, float* ew_csr, float* ew_csc, int32_t* status,
+                   float* dinv, float* ew_csr, float* ew_csc, float* dinv_unw, int32_t* status,
                    void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
 /* ---- dense linear (a4, a10):  y = act(x W^T + b),  W is [D_out, D_in] like nn.Linear ------ */

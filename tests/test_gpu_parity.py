@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Tolerances (north_star): bit-exact on indexing; <= 1e-5 relative
+(||d||_inf / ||ref||_inf per tensor) on fp32 embeddings / outputs / gradients, <= 1e-4 on weight
+gradients that sum >1e5 terms (SURVEY 8d states this bound)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import elementwise_ok, golden_files, load_golden, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+TOL_DW = 1e-4
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hcatgnet_amd
+    from hcatgnet_amd import _lib
+    _lib.load()
+    return hcatgnet_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import gcn_oracle
+    return gcn_oracle
+
+
+def _model_from_params(H, params, device="cuda"):
+    n_conv = 1 + sum(1 for k in params if k.startswith("conv_layers.") and k.endswith("lin.weight"))
+    n_read = sum(1 for k in params if k.startswith("readout.") and k.endswith("weight"))
+    D, F = params["conv1.lin.weight"].shape
+    opt = H.default_options(n_convolutions=n_conv, readout_layers=n_read, embedding_dim=D,
+                            n_classes=params[f"readout.{n_read - 1}.weight"].shape[0])
+    m = H.make_network("GCN", opt, F)
+    m.load_state_dict(params)            # state-dict compatibility with the reference's files
+    return m.to(device)
+
+
+def _rand_params(F, D, n_conv=2, n_read=2, n_classes=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    def glorot(o, i):
+        a = (6.0 / (i + o)) ** 0.5
+        return (torch.rand(o, i, generator=g) * 2 - 1) * a
+    p["conv1.lin.weight"] = glorot(D, F); p["conv1.bias"] = torch.randn(D, generator=g) * 0.1
+    for i in range(n_conv - 1):
+        p[f"conv_layers.{i}.lin.weight"] = glorot(D, D); p[f"conv_layers.{i}.bias"] = torch.randn(D, generator=g) * 0.1
+    dim = 2 * D
+    for i in range(n_read - 1):
+        p[f"readout.{i}.0.weight"] = glorot(dim // 2, dim); p[f"readout.{i}.0.bias"] = torch.randn(dim // 2, generator=g) * 0.1
+        dim //= 2
+    p[f"readout.{n_read - 1}.weight"] = glorot(n_classes, dim); p[f"readout.{n_read - 1}.bias"] = torch.randn(n_classes, generator=g) * 0.1
+    return p
+
+
+# ---------------------------------------------------------------------------------- plan / indexing
+def _check_plan_against_input(plan, edge_index, batch, B):
+    ei = edge_index.cpu().numpy(); N = batch.numel(); E = ei.shape[1]
+    rowptr = plan.rowptr.cpu().numpy(); col = plan.col.cpu().numpy()[:E]
+    rowptr_t = plan.rowptr_t.cpu().numpy(); col_t = plan.col_t.cpu().numpy()[:E]
+    # bit-exact reconstruction of the (src, dst) multiset, and STABLE order inside every row
+    order = np.lexsort((np.arange(E), ei[1]))                       # stable by target
+    assert np.array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))]))
+    assert np.array_equal(col, ei[0][order])
+    order_t = np.lexsort((np.arange(E), ei[0]))
+    assert np.array_equal(rowptr_t, np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))]))
+    assert np.array_equal(col_t, ei[1][order_t])
+    gp = plan.graph_ptr.cpu().numpy()
+    assert np.array_equal(gp, np.searchsorted(batch.cpu().numpy(), np.arange(B + 1), side="left"))
+    deg = 1.0 + np.bincount(ei[1], minlength=N).astype(np.float32)
+    assert np.array_equal(plan.dinv.cpu().numpy()[:N], (1.0 / np.sqrt(deg)).astype(np.float32))
+
+
+@pytest.mark.parametrize("mode", ["blocked", "general"])
+def test_plan_roundtrip_bit_exact(H, mode):
+    from hcatgnet_amd import synth
+    sb = synth.make_config("C2", num_graphs=257, nodes_jitter=6)
+    ei, b = sb.edge_index.cuda(), sb.batch.cuda()
+    plan = H.BatchPlan.build(ei, b, sb.x.shape[0], num_graphs=sb.num_graphs, mode=mode)
+    _check_plan_against_input(plan, sb.edge_index, sb.batch, sb.num_graphs)
+
+
+def test_plan_general_handles_shuffled_edges_and_auto_falls_back(H):
+    from hcatgnet_amd import synth
+    sb = synth.make_config("C2", num_graphs=64)
+    perm = torch.randperm(sb.edge_index.shape[1], generator=torch.Generator().manual_seed(1))
+    ei = sb.edge_index[:, perm].contiguous()
+    plan = H.BatchPlan.build(ei.cuda(), sb.batch.cuda(), sb.x.shape[0], mode="auto")
+    assert plan.mode == "general"
+    _check_plan_against_input(plan, ei, sb.batch, sb.num_graphs)
+    with pytest.raises(ValueError):
+        H.BatchPlan.build(ei.cuda(), sb.batch.cuda(), sb.x.shape[0], mode="blocked")
+
+
+def test_plan_flags_bad_indices(H):
+    ei = torch.tensor([[0, 1, 5], [1, 0, 2]], dtype=torch.int64).cuda()
+    b = torch.zeros(3, dtype=torch.int64).cuda()
+    with pytest.raises(ValueError, match="outside"):
+        H.BatchPlan.build(ei, b, 3, mode="general")
+    with pytest.raises(ValueError, match="sorted"):
+        H.BatchPlan.build(torch.tensor([[0], [1]]).cuda(), torch.tensor([1, 0, 1]).cuda(), 3, num_graphs=2, mode="general")
+
+
+def test_plan_edge_cases(H):
+    # graph 0: isolated single node; graph 1: empty slot; graph 2: 3-node path with a duplicate bond; no edges in graph 3
+    batch = torch.tensor([0, 2, 2, 2, 3, 3], dtype=torch.int64)
+    ei = torch.tensor([[1, 2, 2, 3, 1, 2], [2, 1, 3, 2, 2, 1]], dtype=torch.int64)
+    for mode in ("blocked", "general"):
+        plan = H.BatchPlan.build(ei.cuda(), batch.cuda(), 6, num_graphs=4, mode=mode)
+        _check_plan_against_input(plan, ei, batch, 4)
+    # E == 0
+    plan = H.BatchPlan.build(torch.zeros(2, 0, dtype=torch.int64).cuda(), batch.cuda(), 6, num_graphs=4, mode="general")
+    assert plan.rowptr.cpu().tolist() == [0] * 7
+
+
+# ---------------------------------------------------------------------------------- forward parity
+GOLDEN = golden_files()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_forward_matches_reference_golden_vectors(H, oracle, path):
+    """Reference weights + reference graphs -> the reference's own embeddings.csv numbers."""
+    g = load_golden(path)
+    m = _model_from_params(H, g["params"])
+    with torch.no_grad():
+        out, emb = m(H.Batch(g["x"].cuda(), g["edge_index"].cuda(), g["batch"].cuda(), g["num_graphs"]), True)
+    assert rel_inf(emb, g["ref_emb"]) <= TOL
+    assert elementwise_ok(emb, g["ref_emb"], rtol=TOL, floor=1e-3)
+    assert (out[:, 0].cpu() - g["ref_pred"]).abs().max().item() <= 5e-5
+    # and node embeddings after every conv vs the oracle
+    o_out, o_emb, acts = oracle.gcn_forward(g["params"], g["x"], g["edge_index"], g["batch"], g["num_graphs"],
+                                            return_intermediates=True)
+    plan = H.BatchPlan.build(g["edge_index"].cuda(), g["batch"].cuda(), g["x"].shape[0], num_graphs=g["num_graphs"])
+    h = m.conv1(g["x"].cuda(), plan, apply_act=True)
+    assert rel_inf(h, acts[0]) <= TOL
+    h = m.conv_layers[0](h, plan, apply_act=True)
+    assert rel_inf(h, acts[1]) <= TOL
+
+
+def _synthetic(name, num_graphs, **kw):
+    from hcatgnet_amd import synth
+    sb = synth.make_config(name, num_graphs=num_graphs, **kw)
+    cfg = synth.CONFIGS[name]
+    return sb, cfg
+
+
+@pytest.mark.parametrize("name,ng,kw", [("C1", 1, {}), ("C2", 64, {}), ("C2", 96, {"nodes_jitter": 6}),
+                                        ("C5", 16, {})])
+def test_forward_backward_vs_oracle_synthetic(H, oracle, name, ng, kw):
+    sb, cfg = _synthetic(name, ng, **kw)
+    params = _rand_params(cfg["feat"], cfg["hidden"], seed=3)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    out, emb = m(batch, True)
+    loss = torch.sqrt(m.loss(out, torch.unsqueeze(batch.y, dim=1)))     # utils/utils_model.py:64
+    m.zero_grad()
+    loss.backward()
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out) <= TOL
+    assert abs(loss.item() - o_loss.item()) <= TOL * abs(o_loss.item())
+    got = {k: v.grad for k, v in m.named_parameters()}
+    for k, ref in o_grads.items():
+        tol = TOL_DW if k.endswith("weight") else TOL
+        assert rel_inf(got[k], ref) <= tol, k
+    # fp64 oracle as the tie-breaker for accumulated rounding
+    _, _, _, g64 = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs, dtype=torch.float64)
+    for k, ref in g64.items():
+        assert rel_inf(got[k], ref) <= TOL_DW, k
+
+
+def test_input_gradient_matches_oracle(H, oracle):
+    sb, cfg = _synthetic("C2", 8)
+    params = _rand_params(cfg["feat"], cfg["hidden"], seed=5)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    batch.x.requires_grad_(True)
+    out = m(batch)
+    torch.sqrt(m.loss(out, batch.y.unsqueeze(1))).backward()
+    *_, dx = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs, x_requires_grad=True)
+    assert rel_inf(batch.x.grad, dx) <= TOL
+
+
+def test_general_plan_gives_same_numbers_as_blocked(H):
+    sb, cfg = _synthetic("C2", 32)
+    params = _rand_params(cfg["feat"], cfg["hidden"], seed=7)
+    m = _model_from_params(H, params)
+    x, ei, b = sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda()
+    with torch.no_grad():
+        o1 = m(x, ei, None, b, plan=H.BatchPlan.build(ei, b, x.shape[0], num_graphs=32, mode="blocked"))
+        o2 = m(x, ei, None, b, plan=H.BatchPlan.build(ei, b, x.shape[0], num_graphs=32, mode="general"))
+    assert torch.equal(o1, o2)   # both plans are stable sorts -> identical summation order -> bitwise equal
+
+
+def test_max_pool_ties_split_evenly(H, oracle):
+    """Chemically equivalent atoms give bit-identical rows: the max-branch gradient must be split."""
+    from hcatgnet_amd import functional as HF
+    a = torch.tensor([[1.0, 2.0, -1.0], [1.0, 0.0, -1.0], [0.5, 2.0, -1.0], [3.0, 3.0, 3.0]])
+    batch = torch.tensor([0, 0, 0, 1])
+    plan = H.BatchPlan.build(torch.zeros(2, 0, dtype=torch.int64).cuda(), batch.cuda(), 4, num_graphs=2, mode="general")
+    ag = a.cuda().requires_grad_(True)
+    emb = HF.graph_pool(ag, plan)
+    w = torch.arange(1, 13, dtype=torch.float32).reshape(2, 6).cuda()
+    (emb * w).sum().backward()
+    ar = a.clone().requires_grad_(True)
+    ref = torch.cat([oracle.global_max_pool(ar, batch, 2), oracle.global_mean_pool(ar, batch, 2)], 1)
+    (ref * w.cpu()).sum().backward()
+    assert torch.equal(emb.detach().cpu(), ref.detach())
+    assert rel_inf(ag.grad, ar.grad) <= 1e-6
+
+
+def test_edge_cases_forward_backward(H, oracle):
+    """isolated node, single-node graph, empty graph slot, duplicate bond."""
+    batch = torch.tensor([0, 2, 2, 2, 3, 3], dtype=torch.int64)
+    ei = torch.tensor([[1, 2, 2, 3, 1, 2], [2, 1, 3, 2, 2, 1]], dtype=torch.int64)
+    x = torch.randn(6, 25, generator=torch.Generator().manual_seed(0))
+    y = torch.randn(4, generator=torch.Generator().manual_seed(1))
+    params = _rand_params(25, 64, seed=11)
+    m = _model_from_params(H, params)
+    out, emb = m(x.cuda(), ei.cuda(), None, batch.cuda(), return_graph_embedding=True,
+                 plan=H.BatchPlan.build(ei.cuda(), batch.cuda(), 6, num_graphs=4))
+    torch.sqrt(m.loss(out, y.cuda().unsqueeze(1))).backward()
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, x, ei, batch, y, 4)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out) <= TOL
+    assert torch.equal(emb[1].cpu(), torch.zeros(128))          # empty slot -> zeros
+    for k, v in m.named_parameters():
+        assert rel_inf(v.grad, o_grads[k]) <= TOL, k
+
+
+@pytest.mark.parametrize("improved", [False, True])
+def test_explain_style_edge_weight(H, oracle, improved):
+    """GCN_explain.forward(x, edge_index, batch_index, edge_weight) (reference model/gcn.py:124-140):
+    weights reach conv1 only; `improved` switches the self-loop fill to 2 when weights are explicit."""
+    from hcatgnet_amd.gcn import GCN_explain
+    sb, cfg = _synthetic("C2", 4)
+    params = _rand_params(cfg["feat"], cfg["hidden"], seed=13)
+    opt = H.default_options(improved=improved)
+    m = GCN_explain(opt, cfg["feat"]); m.load_state_dict(params); m = m.cuda()
+    ew = torch.rand(sb.edge_index.shape[1], generator=torch.Generator().manual_seed(2)) + 0.25
+    with torch.no_grad():
+        out = m(x=sb.x.cuda(), edge_index=sb.edge_index.cuda(), batch_index=sb.batch.cuda(), edge_weight=ew.cuda())
+        ref, _ = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, 4, edge_weight=ew, improved=improved)
+    assert rel_inf(out, ref) <= TOL
+
+
+def test_odd_widths_general_shapes(H, oracle):
+    """F_in = 25 (diene featurisation), D = 48, 3 convs, 3 readout layers, n_classes 2."""
+    sb, _ = _synthetic("C2", 8, feat=25)
+    params = _rand_params(25, 48, n_conv=3, n_read=3, n_classes=2, seed=17)
+    m = _model_from_params(H, params)
+    with torch.no_grad():
+        out, emb = m(sb.as_batch("cuda"), True)
+        ref, remb = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, 8)
+    assert rel_inf(emb, remb) <= TOL and rel_inf(out, ref) <= TOL
+
+
+# ---------------------------------------------------------------------------------- full-size checks
+def test_full_size_c2_vs_oracle_and_determinism(H, oracle):
+    """BASELINE configs[1]/[2] at full size: 4096 graphs.  The torch oracle still finishes in < 1 s."""
+    sb, cfg = _synthetic("C2", 4096)
+    params = _rand_params(cfg["feat"], cfg["hidden"], seed=19)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+
+    def step():
+        m.zero_grad()
+        out, emb = m(batch, True)
+        torch.sqrt(m.loss(out, batch.y.unsqueeze(1))).backward()
+        return out.detach().clone(), emb.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    out, emb, grads = step()
+    out2, emb2, grads2 = step()
+    assert torch.equal(out, out2) and torch.equal(emb, emb2)                  # no atomics: run-to-run bitwise
+    assert all(torch.equal(grads[k], grads2[k]) for k in grads)
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out) <= TOL
+    for k, ref in o_grads.items():
+        assert rel_inf(grads[k], ref) <= (TOL_DW if k.endswith("weight") else 5 * TOL), k
+    # size-independent property: graphs are independent -> any sub-batch reproduces its slice bitwise
+    sub = _synthetic("C2", 4096)[0]
+    nsub = 100
+    n_nodes = int((sub.batch < nsub).sum()); n_edges = int((sub.edge_index[0] < n_nodes).sum())
+    with torch.no_grad():
+        o_sub = m(sub.x[:n_nodes].cuda(), sub.edge_index[:, :n_edges].cuda(), None, sub.batch[:n_nodes].cuda())
+    assert torch.equal(o_sub, out[:nsub])
+
+
+def test_cpu_tensors_fail_loudly(H):
+    from hcatgnet_amd._lib import HcgError
+    sb, cfg = _synthetic("C1", 1)
+    m = H.make_network("GCN", H.default_options(), cfg["feat"])
+    with pytest.raises(HcgError):
+        m(sb.as_batch())

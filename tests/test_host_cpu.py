@@ -1,0 +1,101 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host logic
+(collation, synthetic generator, module surface / state-dict compatibility) and loud failure on CPU
+tensors.  No compute entry point is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import hcatgnet_amd as H
+from hcatgnet_amd import _lib, synth
+from tests.helpers import golden_files, load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(REPO, "include", "hcatgnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hcg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hcatgnet_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().hcg_version() == 1
+    assert _lib.load().hcg_error_string(-2) == b"workspace too small"
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    sb = synth.make_config("C1")
+    m = H.make_network("GCN", H.default_options(), 64)
+    with pytest.raises(_lib.HcgError, match="no CPU fallback|MI355X"):
+        m(sb.as_batch())
+    with pytest.raises(ValueError):
+        H.make_network("GAT", H.default_options(), 64)          # reference call_methods.py:11-12
+
+
+def test_module_surface_matches_reference_contract():
+    opt = H.default_options()
+    m = H.make_network("GCN", opt, 25)
+    assert m.name == "GCN" and isinstance(m.loss, torch.nn.MSELoss)
+    assert isinstance(m.optimizer, torch.optim.Adam) and m.optimizer.defaults["eps"] == 1e-9 and m.optimizer.defaults["lr"] == 0.01
+    assert isinstance(m.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau)
+    keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert keys == {"conv1.bias": (64,), "conv1.lin.weight": (64, 25), "conv_layers.0.bias": (64,),
+                    "conv_layers.0.lin.weight": (64, 64), "readout.0.0.weight": (64, 128), "readout.0.0.bias": (64,),
+                    "readout.1.weight": (1, 64), "readout.1.bias": (1,)}
+    assert float(m.conv1.bias.abs().max()) == 0.0                          # PyG zeros(bias)
+    a = (6.0 / (25 + 64)) ** 0.5
+    assert float(m.conv1.lin.weight.abs().max()) <= a                       # glorot bound
+    # reference state-dicts load unchanged
+    g = load_golden(golden_files()[0])
+    m.load_state_dict(g["params"])
+    # seeding at construction (model/networks.py:19)
+    m1 = H.make_network("GCN", opt, 25); m2 = H.make_network("GCN", opt, 25)
+    assert torch.equal(m1.conv1.lin.weight, m2.conv1.lin.weight)
+
+
+def test_collate_reproduces_pyg_batch_rule():
+    gs = []
+    g = torch.Generator().manual_seed(0)
+    for n, e in [(3, 4), (1, 0), (5, 8)]:
+        ei = torch.randint(0, n, (2, e), generator=g)
+        gs.append(H.Data(x=torch.randn(n, 7, generator=g), edge_index=ei, y=torch.randn(1, generator=g), idx=n))
+    b = H.collate(gs)
+    assert b.num_graphs == 3 and b.x.shape == (9, 7) and b.edge_index.shape == (2, 12)
+    assert b.batch.tolist() == [0, 0, 0, 1, 2, 2, 2, 2, 2]
+    assert torch.equal(b.edge_index[:, :4], gs[0].edge_index) and torch.equal(b.edge_index[:, 4:], gs[2].edge_index + 4)
+    assert b.ptr.tolist() == [0, 3, 4, 9] and b.edge_ptr.tolist() == [0, 4, 4, 12]
+    assert b.y.shape == (3,) and b.idx.tolist() == [3, 1, 5] and b.max_nodes == 5 and b.edges_grouped
+    dl = H.DataLoader(gs, batch_size=2, shuffle=False)
+    assert [bb.num_graphs for bb in dl] == [2, 1] and len(dl) == 2
+
+
+@pytest.mark.parametrize("name,ng", [("C1", 1), ("C2", 50), ("C5", 3)])
+def test_synthetic_graphs_follow_survey_spec(name, ng):
+    cfg = synth.CONFIGS[name]
+    sb = synth.make_config(name, num_graphs=ng)
+    N, E = sb.x.shape[0], sb.edge_index.shape[1]
+    assert N == ng * cfg["nodes"] and E == ng * 2 * (cfg["nodes"] - 1 + cfg["extra_bonds"])
+    src, dst = sb.edge_index.numpy()
+    assert np.array_equal(src[0::2], dst[1::2]) and np.array_equal(dst[0::2], src[1::2])   # [i,j],[j,i] interleaved
+    assert (src != dst).all()
+    assert (sb.batch.numpy()[src] == sb.batch.numpy()[dst]).all()
+    deg = np.bincount(dst, minlength=N)
+    assert deg.max() <= cfg["max_degree"] and deg.min() >= 1
+    pairs = set(zip(src.tolist(), dst.tolist())); assert len(pairs) == E                    # no duplicate bonds
+    assert not np.all(np.diff(dst) >= 0)                                                     # NOT target-sorted
+    sb2 = synth.make_config(name, num_graphs=ng)
+    assert torch.equal(sb.x, sb2.x) and torch.equal(sb.edge_index, sb2.edge_index)           # seeded
+    assert not torch.equal(sb.x, synth.make_config(name, num_graphs=ng, rank=1).x)
