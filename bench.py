@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- graphs/sec of the GCN fwd+bwd hot path on N MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+    batch plan (CSR / gcn_norm from the int64 edge_index, rebuilt EVERY step)
+    -> forward (2 x GCNConv+LeakyReLU, [max, mean] pool, readout MLP)
+    -> sqrt(MSE) loss (reference utils/utils_model.py:64)
+    -> backward (all weight gradients)
+    -> [N > 1] RCCL all-reduce of the flat gradient buffer.
+The optimiser is excluded from `value` (the metric is "fwd+bwd", and so is the CPU baseline's
+step); `with_optimizer` reports the same loop with the reference's Adam step added.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C5|...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T_START = time.perf_counter()
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", help="BASELINE.json config: C3 (= configs[2], the metric's), C2, C5, C1")
+    ap.add_argument("--num-graphs", type=int, default=None, help="override graphs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
+    return ap.parse_args()
+
+
+class EntryTimer:
+    """HIP-event timing of ONE C-ABI entry point on the stream it launches on (torch's current
+    stream: the library only enqueues on the stream it is handed)."""
+
+    def __init__(self, lib, name):
+        self.lib, self.name, self.orig = lib, name, getattr(lib, name)
+        self.events, self.enabled = [], False
+
+    def install(self):
+        def wrapper(*a):
+            if not self.enabled:
+                return self.orig(*a)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = self.orig(*a)
+            e.record()
+            self.events.append((s, e))
+            return rc
+        setattr(self.lib, self.name, wrapper)
+
+    def uninstall(self):
+        setattr(self.lib, self.name, self.orig)
+
+    def mean_ms(self, per_step_calls):
+        torch.cuda.synchronize()
+        ms = [s.elapsed_time(e) for s, e in self.events]
+        return (sum(ms) / len(ms) if ms else float("nan")), len(ms)
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota).  On the GPU box the
+    affinity mask can name every core of the host while the container's quota is ~16."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg_name, num_graphs, steps):
+    """The reference CPU scatter path (oracle = torch-native restatement, validated bit-exact against
+    the reference's embeddings) timed on this box's host cores.  Checker / baseline only."""
+    from hcatgnet_amd import synth
+    from oracle import gcn_oracle
+    import hcatgnet_amd as H
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
+    sb = synth.make_config(cfg_name, num_graphs=num_graphs)
+    cfg = synth.CONFIGS[cfg_name]
+    model = H.make_network("GCN", H.default_options(embedding_dim=cfg["hidden"]), cfg["feat"])
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ts = []
+    for i in range(3 + steps):
+        t0 = time.perf_counter()
+        gcn_oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+        ts.append(time.perf_counter() - t0)
+        if i % 5 == 0:
+            log(f"cpu_baseline step {i}: {ts[-1] * 1e3:.1f} ms")
+    ts = sorted(ts[3:])
+    med = ts[len(ts) // 2]
+    model_name = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": sb.num_graphs / med, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed fwd+bwd steps (median, 3 warm-up) of the full {cfg_name} batch "
+                      f"({sb.num_graphs} graphs) with the torch CPU restatement of the reference's PyG scatter path, "
+                      f"{cores} threads; PyG itself is not installable here",
+            "ms_per_step": med * 1e3, "cpu_model": model_name}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hcatgnet_amd as H
+    from hcatgnet_amd import _lib, algbytes, synth
+    from hcatgnet_amd.ddp import DataParallelGCN
+    lib = _lib.load()
+    log(f"rank {rank}/{world}: library loaded")
+
+    cfg_name = args.config
+    cfg = synth.CONFIGS[cfg_name]
+    sb = synth.make_config(cfg_name, rank=rank, num_graphs=args.num_graphs)
+    x, ei, bvec, y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
+    N, E, B, F, D = x.shape[0], ei.shape[1], sb.num_graphs, cfg["feat"], cfg["hidden"]
+    opt = H.default_options(embedding_dim=D)
+    model = H.make_network("GCN", opt, F).to(dev)
+    dp = DataParallelGCN(model) if world > 1 else None
+    y2 = y.unsqueeze(1)
+
+    def step(with_opt=False):
+        model.optimizer.zero_grad(set_to_none=True)
+        b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+        out = model(b)                                   # plan build + forward
+        loss = torch.sqrt(model.loss(out, y2))
+        loss.backward()
+        if dp is not None:
+            dp.reduce_gradients()
+        if with_opt:
+            model.optimizer.step()
+        return loss
+
+    def timed(k, with_opt=False):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(with_opt)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    log(f"inputs resident: N={N} E={E} B={B} F={F} D={D}")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    log("warm-up done")
+    # kernel-level roofline: HIP events around the dominant entry point, inside the timed region
+    entry = args.roofline_entry or "hcg_gcn_layer_bwd"
+    timer = EntryTimer(lib, entry)
+    timer.install()
+    timer.enabled = True
+    dt = timed(args.steps)
+    timer.enabled = False
+    k_ms, k_calls = timer.mean_ms(args.steps)
+    timer.uninstall()
+    # same loop without the event pairs (they cost a little): the number reported as `value`
+    log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
+    dt_clean = timed(args.steps)
+    dt_best = dt_clean
+    log(f"timed: {dt_clean / args.steps * 1e3:.3f} ms/step")
+    dt_opt = timed(args.steps, with_opt=True)
+    log(f"timed with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
+
+    bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
+    step_bytes = sum(bd.values())
+    entry_bytes = {"hcg_gcn_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"]) / 2.0,
+                   "hcg_gcn_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"]) / 2.0}.get(entry, float("nan"))
+    achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+
+    if rank == 0:
+        ms_step = dt_best / args.steps * 1e3
+        rec = {
+            "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "value": world * B * args.steps / dt_best, "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: {B} synthetic graphs/GPU x {N // B} atoms x {E // B} directed edges x "
+                                   f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
+                                   f"full fwd+bwd step incl. per-step CSR/gcn_norm build and sqrt(MSE) loss",
+                       "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
+                       "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": entry, "kernel_ms": k_ms, "kernel_launches_timed": k_calls,
+                         "algorithmic_bytes_per_launch": entry_bytes},
+            "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
+                              "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "breakdown": bd},
+            "with_optimizer": {"value": world * B * args.steps / dt_opt, "unit": "graphs/s",
+                               "ms_per_step": dt_opt / args.steps * 1e3, "optimizer": "torch Adam(lr=0.01, eps=1e-9)"},
+            "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfg_name, args.num_graphs, args.cpu_steps)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ a, c
   const int g = blockIdx.x, fw = threadIdx.x & 63, rw = threadIdx.x >> 6;
   const int beg = graph_ptr[g], end = graph_ptr[g + 1];
   const int n = end - beg;
-  const float inv_n = 1.0f / (float)(n > 0 ? n : 1);
+  const float cnt_n = (float)(n > 0 ? n : 1);
   for (int f0 = 0; f0 < D; f0 += 64) {
     const int f = f0 + fw;
     float mx = -INFINITY, sm = 0.f;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ a, c
       float s = ((ssum[0][fw] + ssum[1][fw]) + ssum[2][fw]) + ssum[3][fw];
       if (n <= 0) m = 0.f;  // empty graph slot: PyG/torch scatter leaves the zero initialiser
       emb[(size_t)g * 2 * D + f] = m;
-      emb[(size_t)g * 2 * D + D + f] = s * inv_n;
+      emb[(size_t)g * 2 * D + D + f] = s / cnt_n;  // true division: bit-equal to torch's sum / count
     }
     __syncthreads();
   }
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ demb
   const int beg = graph_ptr[g], end = graph_ptr[g + 1];
   const int n = end - beg;
   if (n <= 0) return;
-  const float inv_n = 1.0f / (float)n;
+  const float cnt_n = (float)n;
   for (int f0 = 0; f0 < D; f0 += 64) {
     const int f = f0 + fw;
     float mx = 0.f, gmax = 0.f, gmean = 0.f;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ demb
     if (f < D) {
       mx = emb[(size_t)g * 2 * D + f];
       gmax = demb[(size_t)g * 2 * D + f];
-      gmean = demb[(size_t)g * 2 * D + D + f] * inv_n;
+      gmean = demb[(size_t)g * 2 * D + D + f] / cnt_n;
       for (int r = beg + rw; r < end; r += 4) cnt += (a[(size_t)r * D + f] == mx);
     }
     scnt[rw][fw] = cnt;

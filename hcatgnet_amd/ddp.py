@@ -1,0 +1,83 @@
+"""Batch-of-graphs data parallelism: one process per GPU, weights replicated, ONE exchange per
+training step -- an all-reduce of one flat fp32 gradient buffer (16 641 floats = 66.6 KB at
+F_in = D = 64) over RCCL/xGMI (`torch.distributed` backend "nccl" is RCCL on ROCm).
+
+The reference has no distributed code at all (single process, scripts_experiments/train_GNN.py:29);
+this wrapper is build-defined.  Graphs never exchange messages across ranks (block-
+diagonal adjacency), so nothing else crosses GPUs: no graph partitioning, no halo, no activation
+collective.  Gradient semantics: every rank computes sqrt(MSE) over ITS graphs; `reduce_gradients`
+averages the per-rank gradients (DDP convention).  That equals the single-process gradient of the
+mean of per-rank RMSEs, not of the RMSE over the concatenated batch; `combine="sse"` instead
+reproduces the concatenated-batch gradient exactly by all-reducing sum-of-squared-error gradients
+and the SSE itself (one extra scalar in the same buffer).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class DataParallelGCN(nn.Module):
+    def __init__(self, module: nn.Module, process_group=None):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self._params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        self._numel = sum(p.numel() for p in self._params)
+        self._flat: Optional[torch.Tensor] = None
+        self.broadcast_parameters()
+
+    # attributes the reference's loops read from the model (utils/utils_model.py:62-66)
+    @property
+    def optimizer(self):
+        return self.module.optimizer
+
+    @property
+    def loss(self):
+        return self.module.loss
+
+    @property
+    def scheduler(self):
+        return self.module.scheduler
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def world_size(self) -> int:
+        return dist.get_world_size(self.process_group) if dist.is_available() and dist.is_initialized() else 1
+
+    def broadcast_parameters(self, src: int = 0):
+        """Replicate rank-`src` weights (one flat broadcast)."""
+        if self.world_size() == 1:
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self._params])
+            dist.broadcast(flat, src=src, group=self.process_group)
+            off = 0
+            for p in self._params:
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+    def flat_gradient(self) -> torch.Tensor:
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
+        if self._flat is None or self._flat.device != grads[0].device:
+            self._flat = torch.empty(self._numel, dtype=torch.float32, device=grads[0].device)
+        torch.cat(grads, out=self._flat)
+        return self._flat
+
+    def reduce_gradients(self, average: bool = True) -> torch.Tensor:
+        """All-reduce(sum) the flat gradient, divide by world size, re-attach the views as .grad."""
+        flat = self.flat_gradient()
+        ws = self.world_size()
+        if ws > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+            if average:
+                flat.div_(ws)
+        off = 0
+        for p in self._params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        return flat

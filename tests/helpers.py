@@ -29,12 +29,17 @@ def load_golden(path):
                 y=torch.from_numpy(z["y"]), num_graphs=len(node_ptr) - 1)
 
 
-def rel_inf(a: torch.Tensor, ref: torch.Tensor) -> float:
-    """||a - ref||_inf / ||ref||_inf  (SURVEY 8d parity metric)."""
+def rel_inf(a: torch.Tensor, ref: torch.Tensor, floor: float = 1e-30) -> float:
+    """||a - ref||_inf / max(||ref||_inf, floor)  (SURVEY 8d parity metric).
+
+    `floor` is only raised for the model OUTPUT (predictions, O(1..10) kJ/mol): a prediction is a
+    64-term dot product of O(1) terms that may cancel to ~1e-2, and with a single graph in the batch
+    ||ref||_inf is that one cancelled value; floor=1.0 turns the bound into abs <= 1e-5 there
+    (the golden test applies abs <= 5e-5 to the reference's own ddG_pred for the same reason)."""
     a = a.detach().double().cpu(); ref = ref.detach().double().cpu()
     den = ref.abs().max().item() if ref.numel() else 0.0
     num = (a - ref).abs().max().item() if ref.numel() else 0.0
-    return num / max(den, 1e-30)
+    return num / max(den, floor)
 
 
 def elementwise_ok(a: torch.Tensor, ref: torch.Tensor, rtol=1e-5, floor=1e-3) -> bool:
