@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     return ap.parse_args()
 
 
@@ -179,13 +180,47 @@ def main():
             model.optimizer.step()
         return loss
 
-    def timed(k, with_opt=False):
+    graph = None
+
+    def capture():
+        """Capture plan build + forward + loss + backward (everything the library enqueues; no host
+        sync inside) into ONE hipGraph; the RCCL all-reduce stays an eager call after each replay."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        model.optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step_body()
+        return g
+
+    def step_body():
+        model.optimizer.zero_grad(set_to_none=True)
+        b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+        out = model(b)
+        loss = torch.sqrt(model.loss(out, y2))
+        loss.backward()
+        return loss
+
+    def graphed_step(with_opt=False):
+        graph.replay()
+        if dp is not None:
+            dp.reduce_gradients()
+        if with_opt:
+            model.optimizer.step()
+
+    def timed(k, with_opt=False, use_graph=False):
+        fn = graphed_step if use_graph else step
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            step(with_opt)
+            fn(with_opt)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -202,7 +237,7 @@ def main():
     torch.cuda.synchronize()
     log("warm-up done")
     # kernel-level roofline: HIP events around the dominant entry point, inside the timed region
-    entry = args.roofline_entry or "hcg_gcn_layer_bwd"
+    entry = args.roofline_entry or "hcg_fused_layer_bwd"
     timer = EntryTimer(lib, entry)
     timer.install()
     timer.enabled = True
@@ -212,16 +247,31 @@ def main():
     timer.uninstall()
     # same loop without the event pairs (they cost a little): the number reported as `value`
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
-    dt_clean = timed(args.steps)
-    dt_best = dt_clean
-    log(f"timed: {dt_clean / args.steps * 1e3:.3f} ms/step")
+    dt_eager = timed(args.steps)
+    log(f"timed eager: {dt_eager / args.steps * 1e3:.3f} ms/step")
     dt_opt = timed(args.steps, with_opt=True)
-    log(f"timed with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
+    log(f"timed eager with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
+    launch_mode, dt_best, graph_err = "eager", dt_eager, None
+    if not args.no_graph:
+        try:
+            graph = capture()
+            for _ in range(max(3, args.warmup // 2)):
+                graphed_step()
+            dt_graph = timed(args.steps, use_graph=True)
+            log(f"timed hipGraph replay: {dt_graph / args.steps * 1e3:.3f} ms/step")
+            launch_mode, dt_best = "hipgraph", dt_graph
+        except Exception as exc:  # report, never hide: the eager number stands
+            graph_err = f"{type(exc).__name__}: {exc}"
+            log(f"graph capture failed, keeping eager timing: {graph_err}")
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(bd.values())
+    # algorithmic bytes of ONE launch of the timed entry point, averaged over its launches in a step
+    # (layer 2 backward also carries the pool backward it fuses; layer 2 forward the pool forward)
     entry_bytes = {"hcg_gcn_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"]) / 2.0,
-                   "hcg_gcn_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"]) / 2.0}.get(entry, float("nan"))
+                   "hcg_gcn_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"]) / 2.0,
+                   "hcg_fused_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
+                   "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0}.get(entry, float("nan"))
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
 
     if rank == 0:
@@ -233,7 +283,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {B} synthetic graphs/GPU x {N // B} atoms x {E // B} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
-                                   f"full fwd+bwd step incl. per-step CSR/gcn_norm build and sqrt(MSE) loss",
+                                   f"full fwd+bwd step incl. per-step CSR/gcn_norm build and sqrt(MSE) loss; "
+                                   f"launch={launch_mode}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -246,6 +297,7 @@ def main():
             "with_optimizer": {"value": world * B * args.steps / dt_opt, "unit": "graphs/s",
                                "ms_per_step": dt_opt / args.steps * 1e3, "optimizer": "torch Adam(lr=0.01, eps=1e-9)"},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
+            "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3, "graph_capture_error": graph_err,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg_name, args.num_graphs, args.cpu_steps)

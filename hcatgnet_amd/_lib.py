@@ -36,6 +36,15 @@ SIGNATURES = {
     "hcg_gcn_layer_bwd": (INT, [P, P, P, P, P, P, P, P, F32, F32, INT, P, P, P, P, I64, I64, I64, I64, P, SZ, P]),
     "hcg_pool_fwd": (INT, [P, P, P, I64, I64, I64, P]),
     "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
+    "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),
+    "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
+    "hcg_fused_layer_fwd": (INT, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
+    "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
+    "hcg_readout2_supported": (INT, [I64, I64]),
+    "hcg_readout2_workspace_bytes": (SZ, [I64]),
+    "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),
+    "hcg_readout2_bwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P, SZ, P]),
+    "hcg_fused_reduce_grads": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
 }
 
 _lib = None

@@ -154,6 +154,123 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+class _FusedLayerFn(torch.autograd.Function):
+    """One fused launch per layer for batches of small graphs (csrc/fused.hip): returns the node
+    embeddings, or -- with `pool=True`, the last conv layer -- the pooled graph embedding
+    [max, mean] directly (the node embeddings stay internal, saved for the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, plan: BatchPlan, gpt: int, apply_act: bool, slope: float, pool: bool):
+        lib = _lib.load()
+        _lib.require_gpu(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, F = x.shape
+        D = weight.shape[0]
+        if weight.shape[1] != F or N != plan.N:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(weight.shape)}, plan N {plan.N}")
+        dev = x.device
+        out = torch.empty(N, D, dtype=torch.float32, device=dev)
+        emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
+        rc = lib.hcg_fused_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.rowptr),
+                                     _lib.ptr(plan.col), _lib.ptr(plan.dinv), _lib.ptr(plan.graph_ptr),
+                                     _lib.ptr(plan.edge_ptr), N, plan.B, F, D, gpt, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
+                                     _lib.stream_ptr())
+        _lib.check(rc, "hcg_fused_layer_fwd")
+        ctx.plan, ctx.gpt, ctx.apply_act, ctx.slope, ctx.pool = plan, gpt, apply_act, slope, pool
+        if pool:
+            ctx.save_for_backward(x, weight, out, emb)
+            return emb
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        plan = ctx.plan
+        if ctx.pool:
+            x, weight, out, emb = ctx.saved_tensors
+            dout, demb = None, _f32c(grad)
+        else:
+            x, weight, out = ctx.saved_tensors
+            emb, dout, demb = None, _f32c(grad), None
+        N, F = x.shape
+        D = weight.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(D, dtype=torch.float32, device=dev)
+        wsb = lib.hcg_fused_workspace_bytes(plan.B, F, D, ctx.gpt)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.hcg_fused_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), _lib.ptr(x),
+                                     _lib.ptr(weight), _lib.ptr(plan.rowptr_t), _lib.ptr(plan.col_t), _lib.ptr(plan.dinv),
+                                     _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, ctx.gpt, ctx.slope,
+                                     int(ctx.apply_act), _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_fused_layer_bwd")
+        rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, plan.B, F, D, ctx.gpt, _lib.ptr(dW), _lib.ptr(db),
+                                        _lib.stream_ptr())
+        _lib.check(rc, "hcg_fused_reduce_grads")
+        return dx, dW, db, None, None, None, None, None
+
+
+class _Readout2Fn(torch.autograd.Function):
+    """out = (LeakyReLU(emb W0^T + b0)) W1^T + b1 in one launch (csrc/readout.hip)."""
+
+    @staticmethod
+    def forward(ctx, emb, W0, b0, W1, b1, slope: float):
+        lib = _lib.load()
+        _lib.require_gpu(emb, W0, b0, W1, b1)
+        emb, W0, b0, W1, b1 = _f32c(emb), _f32c(W0), _f32c(b0), _f32c(W1), _f32c(b1)
+        B, D, C = emb.shape[0], W0.shape[0], W1.shape[0]
+        if emb.shape[1] != 2 * D or W0.shape[1] != 2 * D or W1.shape[1] != D:
+            raise ValueError("readout shape mismatch")
+        z = torch.empty(B, D, dtype=torch.float32, device=emb.device)
+        out = torch.empty(B, C, dtype=torch.float32, device=emb.device)
+        rc = lib.hcg_readout2_fwd(_lib.ptr(emb), _lib.ptr(W0), _lib.ptr(b0), _lib.ptr(W1), _lib.ptr(b1), B, D, C, slope,
+                                  _lib.ptr(z), _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, "hcg_readout2_fwd")
+        ctx.save_for_backward(emb, z, W0, W1)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        emb, z, W0, W1 = ctx.saved_tensors
+        dout = _f32c(dout)
+        B, D, C = emb.shape[0], W0.shape[0], W1.shape[0]
+        dev = emb.device
+        demb = torch.empty_like(emb)
+        dW0, dW1 = torch.empty_like(W0), torch.empty_like(W1)
+        db0 = torch.empty(D, dtype=torch.float32, device=dev)
+        db1 = torch.empty(C, dtype=torch.float32, device=dev)
+        wsb = lib.hcg_readout2_workspace_bytes(B)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.hcg_readout2_bwd(_lib.ptr(dout), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(W0), _lib.ptr(W1), B, D, C, ctx.slope,
+                                  _lib.ptr(demb), _lib.ptr(dW0), _lib.ptr(db0), _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(ws),
+                                  wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_readout2_bwd")
+        return demb, dW0, db0, dW1, db1, None
+
+
+def readout2_supported(D: int, C: int) -> bool:
+    return bool(_lib.load().hcg_readout2_supported(D, C))
+
+
+def readout2(emb, W0, b0, W1, b1, slope=LEAKY_SLOPE):
+    return _Readout2Fn.apply(emb, W0, b0, W1, b1, slope)
+
+
+def fused_graphs_per_tile(plan: BatchPlan, F: int, D: int) -> int:
+    """> 0 when the fused small-graph kernels apply to this plan / layer shape."""
+    if plan.mode != "blocked" or plan.ew_csr is not None or plan.max_nodes is None or plan.B == 0:
+        return 0
+    return int(_lib.load().hcg_fused_graphs_per_tile(F, D, plan.max_nodes))
+
+
+def fused_gcn_layer(x, weight, bias, plan: BatchPlan, gpt: int, apply_act=True, slope=LEAKY_SLOPE, pool=False):
+    return _FusedLayerFn.apply(x, weight, bias, plan, gpt, apply_act, slope, pool)
+
+
 def gcn_layer(x, weight, bias, plan: BatchPlan, use_edge_weight=False, apply_act=True, slope=LEAKY_SLOPE):
     return _GCNLayerFn.apply(x, weight, bias, plan, use_edge_weight, apply_act, slope)
 

@@ -44,8 +44,16 @@ class GCNConv(nn.Module):
             self.lin.weight.uniform_(-a, a)
             self.bias.zero_()
 
-    def forward(self, x, plan: BatchPlan, use_edge_weight: bool = False, apply_act: bool = False):
-        return HF.gcn_layer(x, self.lin.weight, self.bias, plan, use_edge_weight, apply_act)
+    def forward(self, x, plan: BatchPlan, use_edge_weight: bool = False, apply_act: bool = False,
+                fused: bool = True, pool: bool = False):
+        """`pool=True` (last conv): returns the pooled graph embedding [B, 2*out] instead of the
+        node embeddings.  `fused=True` uses the one-launch-per-layer small-graph kernels when the
+        plan / shapes allow, else the any-shape kernels."""
+        gpt = 0 if (use_edge_weight or not fused) else HF.fused_graphs_per_tile(plan, self.in_channels, self.out_channels)
+        if gpt > 0:
+            return HF.fused_gcn_layer(x, self.lin.weight, self.bias, plan, gpt, apply_act, pool=pool)
+        h = HF.gcn_layer(x, self.lin.weight, self.bias, plan, use_edge_weight, apply_act)
+        return HF.graph_pool(h, plan) if pool else h
 
 
 class _ReadoutLinear(nn.Linear):
@@ -77,6 +85,7 @@ class GCN(BaseNetwork):
         self._make_optimizer(opt.optimizer, opt.lr)
         self._make_scheduler(scheduler=opt.scheduler, step_size=opt.step_size, gamma=opt.gamma, min_lr=opt.min_lr)
         self.plan_mode = getattr(opt, "plan_mode", "auto")
+        self.use_fused = bool(getattr(opt, "use_fused", True))
 
     # ------------------------------------------------------------------ argument handling
     def _plan_for(self, graph, x, edge_index, batch, edge_weight) -> BatchPlan:
@@ -98,14 +107,21 @@ class GCN(BaseNetwork):
         return plan
 
     def _run(self, x, plan: BatchPlan, use_edge_weight: bool, return_graph_embedding: bool):
-        h = self.conv1(x, plan, use_edge_weight=use_edge_weight, apply_act=True)      # conv1 + relu1
+        last = self.n_convolutions - 1
+        fused = self.use_fused
+        h = self.conv1(x, plan, use_edge_weight=use_edge_weight, apply_act=True, fused=fused, pool=last == 0)
         for i in range(self.n_convolutions - 1):                                       # gcn.py:61-63
-            h = self.conv_layers[i](h, plan, use_edge_weight=False, apply_act=True)
-        graph_emb = HF.graph_pool(h, plan)                                             # gcn.py:65-66
+            h = self.conv_layers[i](h, plan, use_edge_weight=False, apply_act=True, fused=fused, pool=i + 1 == last)
+        graph_emb = h                                                                  # gcn.py:65-66 (pooled in-layer)
         z = graph_emb
-        for i in range(self.readout_layers):                                           # gcn.py:70-71
-            layer = self.readout[i]
-            z = layer[0](z, apply_act=True) if isinstance(layer, nn.Sequential) else layer(z)
+        if (fused and self.readout_layers == 2 and graph_emb.is_cuda
+                and HF.readout2_supported(self.embedding_dim, self._n_classes)):
+            l0, l1 = self.readout[0][0], self.readout[1]                               # one launch for the head
+            z = HF.readout2(graph_emb, l0.weight, l0.bias, l1.weight, l1.bias)
+        else:
+            for i in range(self.readout_layers):                                       # gcn.py:70-71
+                layer = self.readout[i]
+                z = layer[0](z, apply_act=True) if isinstance(layer, nn.Sequential) else layer(z)
         if return_graph_embedding:
             return z, graph_emb
         return z

@@ -106,4 +106,6 @@ class BatchPlan:
             p.validated = True
             if word:
                 raise ValueError("hcatgnet_amd: invalid batch: " + _lib.describe_status(word))
+            if p.max_nodes is None and B > 0:   # index bookkeeping for kernel selection (we are synchronising anyway)
+                p.max_nodes = int((p.graph_ptr[1:] - p.graph_ptr[:-1]).max().item())
         return p

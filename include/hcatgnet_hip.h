@@ -124,6 +124,52 @@ int hcg_pool_fwd(const float* a, const int32_t* graph_ptr, float* emb /*[B,2D]*/
 int hcg_pool_bwd(const float* demb, const float* a, const float* emb, const int32_t* graph_ptr,
                  float* da, int64_t N, int64_t B, int64_t D, hcg_stream_t stream);
 
+/* ---- fused per-layer kernels for batches of small graphs (<= 32 nodes per tile, D = 64, F <= 64) ----
+ * One launch per layer: tile of whole graphs -> LDS, x W^T on the f32 matrix cores, fixed-order
+ * segmented sum out of LDS, bias + LeakyReLU, optional [max, mean] pooling epilogue (a4-a9).
+ * Needs a BLOCKED plan (graph_ptr + CSR of hcg_plan_build) and unweighted edges (fill = 1).
+ *   hcg_fused_graphs_per_tile: graphs packed into one 32-row tile, 0 = shape not supported
+ *   emb != NULL  : also write emb[B, 2D] = [max, mean] of `out` per graph (last conv layer)
+ *   status       : the plan's status words; HCG_STATUS_SHAPE_LIMIT is raised if a tile exceeds 32 rows
+ */
+int hcg_fused_graphs_per_tile(int64_t F, int64_t D, int64_t max_nodes_per_graph);
+size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int graphs_per_tile);
+int hcg_fused_layer_fwd(const float* x, const float* W, const float* b,
+                        const int32_t* rowptr, const int32_t* col, const float* dinv,
+                        const int32_t* graph_ptr, const int32_t* edge_ptr,
+                        int64_t N, int64_t B, int64_t F, int64_t D,
+                        int graphs_per_tile, float slope, int apply_act,
+                        float* out, float* emb /*nullable*/, int32_t* status, hcg_stream_t stream);
+/* backward, stage 1 (ONE launch).  dout == NULL selects the pooled form: the upstream gradient is
+ * demb[B, 2D] and is expanded on chip with `emb` (ties of the max split evenly).  dx nullable (first
+ * layer).  Leaves one partial slab [D*KPAD + D] per workgroup in `workspace`
+ * (hcg_fused_workspace_bytes); stage 2 = hcg_fused_reduce_grads sums them in a fixed order into
+ * dW [D, F], db [D]: bitwise reproducible. */
+int hcg_fused_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
+                        const float* out, const float* x, const float* W,
+                        const int32_t* rowptr_t, const int32_t* col_t, const float* dinv,
+                        const int32_t* graph_ptr, const int32_t* edge_ptr,
+                        int64_t N, int64_t B, int64_t F, int64_t D,
+                        int graphs_per_tile, float slope, int apply_act,
+                        float* dx /*nullable*/, int32_t* status,
+                        void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B,
+                           int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
+                           hcg_stream_t stream);
+
+/* ---- fused readout head (a10 + its backward) for the reference's default shape:
+ *      z = LeakyReLU(emb W0^T + b0) [B,2D]->[B,D];  out = z W1^T + b1 [B,D]->[B,C];  D = 64, C <= 8.
+ * forward: one launch (z is kept for the backward).  backward: one launch + fixed-order slab reduce;
+ * writes demb [B,2D], dW0 [D,2D], db0 [D], dW1 [C,D], db1 [C]. */
+int hcg_readout2_supported(int64_t D, int64_t C);
+size_t hcg_readout2_workspace_bytes(int64_t B);
+int hcg_readout2_fwd(const float* emb, const float* W0, const float* b0, const float* W1, const float* b1,
+                     int64_t B, int64_t D, int64_t C, float slope, float* z, float* out, hcg_stream_t stream);
+int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const float* W0, const float* W1,
+                     int64_t B, int64_t D, int64_t C, float slope,
+                     float* demb, float* dW0, float* db0, float* dW1, float* db1,
+                     void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

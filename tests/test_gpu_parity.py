@@ -189,6 +189,7 @@ def test_general_plan_gives_same_numbers_as_blocked(H):
     sb, cfg = _synthetic("C2", 32)
     params = _rand_params(cfg["feat"], cfg["hidden"], seed=7)
     m = _model_from_params(H, params)
+    m.use_fused = False          # same (any-shape) kernels on both plans
     x, ei, b = sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda()
     with torch.no_grad():
         o1 = m(x, ei, None, b, plan=H.BatchPlan.build(ei, b, x.shape[0], num_graphs=32, mode="blocked"))
@@ -295,3 +296,136 @@ def test_cpu_tensors_fail_loudly(H):
     m = H.make_network("GCN", H.default_options(), cfg["feat"])
     with pytest.raises(HcgError):
         m(sb.as_batch())
+
+
+# ---------------------------------------------------------------------------------- fused small-graph kernels
+def _step_grads(m, batch, y):
+    m.zero_grad()
+    out, emb = m(batch, True)
+    torch.sqrt(m.loss(out, y.unsqueeze(1))).backward()
+    return out.detach(), emb.detach(), {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+
+
+@pytest.mark.parametrize("nodes,jitter,feat,extra", [(30, 0, 64, 3), (12, 4, 64, 2), (5, 2, 25, 1), (30, 0, 32, 3),
+                                                      (20, 6, 40, 3), (2, 0, 7, 0)])
+def test_fused_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, extra):
+    """One-launch-per-layer kernels (csrc/fused.hip): every staging variant (vector / scalar,
+    K padded to 32 / 64), 1..16 graphs per 32-row tile, against the oracle and the any-shape path."""
+    from hcatgnet_amd import functional as HF, synth
+    sb = synth.make_batch(num_graphs=203, nodes=nodes, extra_bonds=extra, max_degree=4, feat=feat, nodes_jitter=jitter, seed=5)
+    params = _rand_params(feat, 64, seed=23)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    plan = H.BatchPlan.build(batch.edge_index, batch.batch, batch.x.shape[0], num_graphs=sb.num_graphs, mode="blocked",
+                             max_nodes=sb.max_nodes)
+    batch._hcg_plan = plan
+    assert HF.fused_graphs_per_tile(plan, feat, 64) == 32 // sb.max_nodes >= 1
+    m.use_fused = True
+    out_f, emb_f, g_f = _step_grads(m, batch, batch.y)
+    assert plan.check_status() == 0
+    m.use_fused = False
+    out_g, emb_g, g_g = _step_grads(m, batch, batch.y)
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+    assert rel_inf(emb_f, o_emb) <= TOL and rel_inf(out_f, o_out, floor=1.0) <= TOL
+    assert rel_inf(emb_f, emb_g) <= 2e-6 and rel_inf(out_f, out_g, floor=1.0) <= 2e-6
+    for k, ref in o_grads.items():
+        assert rel_inf(g_f[k], ref) <= (TOL_DW if k.endswith("weight") else TOL), k
+        assert rel_inf(g_f[k], g_g[k]) <= TOL, k
+    # node embeddings of the first layer (no pooling epilogue) vs oracle
+    _, _, acts = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
+    with torch.no_grad():
+        h = m.conv1(batch.x, plan, apply_act=True, fused=True)
+    assert rel_inf(h, acts[0]) <= TOL
+
+
+def test_fused_input_gradient_and_determinism(H, oracle):
+    from hcatgnet_amd import synth
+    sb = synth.make_config("C2", num_graphs=300)
+    params = _rand_params(64, 64, seed=29)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    batch.x.requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        m.zero_grad(); batch.x.grad = None
+        out = m(batch)
+        torch.sqrt(m.loss(out, batch.y.unsqueeze(1))).backward()
+        outs.append((out.detach().clone(), batch.x.grad.clone(), {k: v.grad.clone() for k, v in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(outs[0][2][k], outs[1][2][k]) for k in outs[0][2])           # bitwise reproducible
+    *_, dx = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs, x_requires_grad=True)
+    assert rel_inf(batch.x.grad, dx) <= TOL
+
+
+def test_fused_edge_cases(H, oracle):
+    """empty graph slots, single-node graphs, an isolated node, duplicate bonds, and a dense
+    multigraph whose tile exceeds the LDS neighbour cache (> 256 edges -> global index path)."""
+    xs, eis, bs, off = [], [], [], 0
+    gen = torch.Generator().manual_seed(3)
+    sizes = [1, 0, 3, 20, 1, 0, 0, 7, 2]
+    for g, n in enumerate(sizes):
+        if n == 0:
+            continue
+        xs.append(torch.randn(n, 64, generator=gen))
+        bs.append(torch.full((n,), g, dtype=torch.int64))
+        if n == 20:     # complete digraph: 380 directed edges in one tile
+            i, j = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+            mask = i != j
+            eis.append(torch.stack([i[mask], j[mask]]) + off)
+        elif n >= 2:
+            path = torch.arange(n - 1)
+            e = torch.stack([torch.cat([path, path + 1]), torch.cat([path + 1, path])])
+            if n == 7:
+                e = torch.cat([e[:, :-1], e[:, :2]], 1)   # drop one direction (asymmetric) + duplicate a bond
+            eis.append(e + off)
+        off += n
+    x, ei, b = torch.cat(xs), torch.cat(eis, 1), torch.cat(bs)
+    B = len(sizes)
+    y = torch.randn(B, generator=gen)
+    params = _rand_params(64, 64, seed=31)
+    m = _model_from_params(H, params)
+    plan = H.BatchPlan.build(ei.cuda(), b.cuda(), x.shape[0], num_graphs=B, mode="blocked", max_nodes=max(sizes))
+    from hcatgnet_amd import functional as HF
+    assert HF.fused_graphs_per_tile(plan, 64, 64) == 1
+    m.zero_grad()
+    out, emb = m(x.cuda(), ei.cuda(), None, b.cuda(), return_graph_embedding=True, plan=plan)
+    torch.sqrt(m.loss(out, y.cuda().unsqueeze(1))).backward()
+    assert plan.check_status() == 0
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, x, ei, b, y, B)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out, floor=1.0) <= TOL
+    assert torch.equal(emb[1].cpu(), torch.zeros(128))
+    for k, v in m.named_parameters():
+        assert rel_inf(v.grad, o_grads[k]) <= TOL, k
+
+
+def test_fused_refuses_oversize_tile_without_touching_memory(H):
+    """Host metadata lies (max_nodes too small): the kernel must flag SHAPE_LIMIT and skip, not fault."""
+    from hcatgnet_amd import synth
+    sb = synth.make_batch(num_graphs=16, nodes=40, extra_bonds=2, max_degree=4, feat=64)
+    params = _rand_params(64, 64, seed=37)
+    m = _model_from_params(H, params)
+    plan = H.BatchPlan.build(sb.edge_index.cuda(), sb.batch.cuda(), sb.x.shape[0], num_graphs=16, mode="blocked",
+                             max_nodes=30)     # wrong on purpose
+    with torch.no_grad():
+        m(sb.x.cuda(), sb.edge_index.cuda(), None, sb.batch.cuda(), plan=plan)
+    with pytest.raises(ValueError, match="tile"):
+        plan.check_status()
+
+
+@pytest.mark.parametrize("B,C", [(1, 1), (33, 1), (200, 3), (4096, 8)])
+def test_fused_readout_head(H, B, C):
+    """csrc/readout.hip against torch fp64 autograd of the same two-layer head (model/gcn.py:36-45)."""
+    import torch.nn.functional as F
+    from hcatgnet_amd import functional as HF
+    g = torch.Generator().manual_seed(B + C)
+    emb = torch.randn(B, 128, generator=g); W0 = torch.randn(64, 128, generator=g) * 0.1; b0 = torch.randn(64, generator=g) * 0.1
+    W1 = torch.randn(C, 64, generator=g) * 0.1; b1 = torch.randn(C, generator=g) * 0.1; go = torch.randn(B, C, generator=g)
+    dev = [t.cuda().requires_grad_(True) for t in (emb, W0, b0, W1, b1)]
+    out = HF.readout2(*dev)
+    out.backward(go.cuda())
+    ref = [t.double().requires_grad_(True) for t in (emb, W0, b0, W1, b1)]
+    r = F.linear(F.leaky_relu(F.linear(ref[0], ref[1], ref[2]), 0.01), ref[3], ref[4])
+    r.backward(go.double())
+    assert rel_inf(out, r) <= TOL
+    for a, b in zip(dev, ref):
+        assert rel_inf(a.grad, b.grad) <= TOL

@@ -99,3 +99,20 @@ def test_synthetic_graphs_follow_survey_spec(name, ng):
     sb2 = synth.make_config(name, num_graphs=ng)
     assert torch.equal(sb.x, sb2.x) and torch.equal(sb.edge_index, sb2.edge_index)           # seeded
     assert not torch.equal(sb.x, synth.make_config(name, num_graphs=ng, rank=1).x)
+
+
+def test_ctypes_signatures_match_header_arity():
+    hdr = open(os.path.join(REPO, "include", "hcatgnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for m in re.finditer(r"\b(hcg_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("void", "") else len(args.split(","))
+        assert n == len(_lib.SIGNATURES[name][1]), name
+
+
+def test_algorithmic_bytes_match_survey_numbers():
+    from hcatgnet_amd import algbytes
+    assert algbytes.structure_bytes(122880, 262144) == 2_031_620
+    assert algbytes.conv_fwd(122880, 262144, 64, 64) == 64_962_820
+    assert algbytes.forward_bytes(122880, 262144, 4096, 64, 64) == 165_643_280
+    assert algbytes.step_bytes(122880, 262144, 4096, 64, 64) == 438_242_860
