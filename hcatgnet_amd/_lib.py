@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhcatgnet_hip.so")
 
-HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED = 0, 1
+HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY = 0, 1, 2
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
@@ -38,8 +38,8 @@ SIGNATURES = {
     "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
     "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
-    "hcg_fused_layer_fwd": (INT, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
-    "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
+    "hcg_fused_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
+    "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
     "hcg_readout2_supported": (INT, [I64, I64]),
     "hcg_readout2_workspace_bytes": (SZ, [I64]),
     "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),

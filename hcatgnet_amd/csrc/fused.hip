@@ -1,24 +1,30 @@
 // Fused per-layer kernels for batches of SMALL graphs (the BASELINE workload: ~30-atom graphs, 64-d).
 //
 // One GCN layer (reference: PyG GCNConv + nn.LeakyReLU, call sites model/gcn.py:58-63; SURVEY rows
-// a4-a8, and a9 for the last layer) is ONE kernel: a tile of whole graphs (<= 32 node rows) is
-// brought on chip once, transformed on the f32 matrix cores, aggregated out of LDS with a fixed-order
-// segmented sum (no atomics), biased/activated, (pooled) and written once -- the "layer-fused
-// minimum" HBM traffic of SURVEY 8(d): read the layer input once, write its output once.
+// a3-a8, and a9 for the last layer) is ONE kernel: a tile of whole graphs (<= 32 node rows) is
+// brought on chip once, transformed AND aggregated on the f32 matrix cores, biased/activated,
+// (pooled) and written once -- the "layer-fused minimum" HBM traffic of SURVEY 8(d).
 //
 // CDNA4 mapping
 //   * wavefront-autonomous tiles: each 64-lane wave owns a stream of tiles and a private LDS region
-//     (two [32][D+4] fp32 buffers); no workgroup barrier in the steady state.  A 512-thread
-//     workgroup (8 waves = 2 per SIMD) per CU keeps the matrix pipe of every SIMD fed by one wave
-//     while its partner stages / aggregates.
-//   * v_mfma_f32_32x32x2_f32 (exact f32): the weight operand lives in 64 VGPRs for the whole
-//     kernel; the activation operand is read from LDS with ds_read_b128 -- legal because the MFMA
-//     sums over k, so the (k-step, lane-half) -> k assignment is free: lane (r, h) takes
-//     k = 8t + 4h + u for u = 0..3 of its 16-byte read.  Row stride D+4 floats makes those reads
-//     conflict-free (16 lanes x 16 B = 64 banks).
-//   * backward: dW accumulates in MFMA accumulators ACROSS all tiles of a wave (K = node rows);
-//     waves combine through LDS, workgroups through a [grid][D*KPAD+D] slab reduced in a fixed order
-//     by a second kernel -> bitwise reproducible gradients.
+//     (one [32][68] fp32 tile + a [32][33] int adjacency-count matrix); no workgroup barrier in the
+//     steady state.  512-thread workgroup (8 waves = 2 per SIMD) per CU.
+//   * gcn_norm without any index structure: the tile's raw COO edges (int64 `edge_index`, grouped by
+//     graph as PyG collation emits them) are scattered into C[dst][src] += 1 with LDS integer atomics
+//     (order-independent -> deterministic), C += I, deg = row sums, dinv = deg^-1/2.  No CSR, no
+//     sort: the fused path needs only graph_ptr / edge_ptr from the batch plan.
+//   * every contraction is v_mfma_f32_32x32x2_f32 (exact f32, a k-ordered fmaf chain):
+//       H   = X W^T                      W in 64 VGPRs; X rows from LDS by ds_read_b128 (k = 8t+4h+u)
+//       Y   = (C + I) (dinv . H)         B operand = the H ACCUMULATORS themselves: MFMA sums over k,
+//                                        so k-step i may use k = krow(i, h) = (i&3) + 8(i>>2) + 4h,
+//                                        exactly the rows accumulator register i holds on lane-half h
+//       out = LeakyReLU(dinv . Y + b)    epilogue / pooling in accumulator layout
+//     backward: dH = (C + I)^T (dinv . dY), dW += dH^T X (A operand = dH accumulators, same trick),
+//     dX = dH W (one LDS transpose).  The non-MFMA instruction stream per tile is a few hundred
+//     instructions; as a VALU/LDS segmented sum it was ~1500 and bound the kernel.
+//   * backward: dW accumulates in MFMA accumulators ACROSS all tiles of a wave; waves combine
+//     through LDS, workgroups through a [grid][D*KPAD+D] slab reduced in a fixed order by a second
+//     kernel -> bitwise reproducible gradients.
 #include "common.h"
 
 // Diagnostic builds only (tools/probe_fused.hip defines HCG_STAMP): s_memtime stamps of a few waves go to
@@ -38,7 +44,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(idx) do { } while (0)
 #endif
 // tools/probe_fused.hip -DHCG_ABLATE=<bits> (timing-only diagnostic builds; results are wrong on purpose):
-//   1 = no MFMA in the forward GEMM, 2 = no neighbour gather, 4 = no output stores, 8 = no x loads
+//   1 = no MFMA in the forward GEMM, 2 = no aggregation MFMA, 4 = no output stores, 8 = no x loads
 #ifndef HCG_ABLATE
 #define HCG_ABLATE 0
 #endif
@@ -49,41 +55,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 32;          // node rows per wave tile
 constexpr int DD = 64;          // layer width handled by this file (embedding_dim = 64)
-constexpr int HS = DD + 4;      // LDS row stride (floats) of a [TM][DD] buffer
+constexpr int HS = DD + 4;      // LDS row stride (floats) of the [TM][DD] tile buffer
+constexpr int CS = TM + 1;      // row stride of the adjacency-count matrix (conflict-free rows AND columns)
+constexpr int CNT_WORDS = 1280; // >= TM * CS, multiple of 256 (zero-filled with 5 float4 stores per lane)
 constexpr int WAVES = 8;        // waves per workgroup
-constexpr int LCOL_CAP = 128;   // edges of one tile whose neighbour row offsets are cached in LDS
 constexpr int BUF_FLOATS = TM * HS;
-constexpr unsigned ZERO_ROW_OFF = TM * HS * 4;  // byte offset of the all-zero row that follows a gather buffer
 
-// bufA is the buffer the segmented sum gathers from (forward: h', backward: dY'); it that is gathered from is followed by one
-// all-zero row so that a missing neighbour slot is an unconditional add of zeros (no select per value).
-// `lofs` holds, per edge of the tile, the BYTE offset of the neighbour's row inside that buffer.
 struct WaveLds {
-  float bufA[BUF_FLOATS];
-  float zeroA[HS];
-  float bufB[BUF_FLOATS];
-  int lrow[TM + 4];
-  float ldinv[TM];
-  int lgp[TM + 4];  // node offset of every graph of the tile (a tile holds <= TM graphs)
-  unsigned short lofs[LCOL_CAP];
+  float buf[BUF_FLOATS];   // forward: x tile.  backward: dY', then x tile, then dH (for the dX transpose)
+  int cnt[CNT_WORDS];      // C + I of the tile: cnt[dst * CS + src]
+  float ldinv[TM];         // in-degree counter while the edges are scattered, then (1 + deg)^-1/2
+  int lgp[TM + 4];         // node offset of every graph of the tile (a tile holds <= TM graphs)
 };
 
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4_max(float4 a, float4 b) {
-  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
-}
-__device__ __forceinline__ float4 f4_shfl_xor(float4 v, int m) {
-  return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
-}
+// rows of a 32x32 MFMA accumulator: register i of lane-half h holds row krow(i, h)
+__device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// tile bookkeeping shared by forward and backward.  `rp`/`ci` are the CSR (forward) or its transpose
-// (backward); `edge_ptr[g]` == rp[graph_ptr[g]] because a blocked plan keeps every graph's edges
-// contiguous, so all four tile scalars come from ONE round of (scalar) loads.
+// All four tile scalars come from ONE round of (scalar) loads of the blocked plan's graph_ptr / edge_ptr.
 // Rule for every global load in this file: never guard a load with a per-lane branch (hipcc then
 // serialises it behind its own s_waitcnt vmcnt(0)); clamp the index into range and select afterwards.
 struct TileInfo {
   int g0, g1, nbase, n, ebase, ne;
-  bool cols_in_lds;
 };
 
 __device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const int32_t* __restrict__ graph_ptr,
@@ -102,120 +94,67 @@ __device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const in
     ti.ne = 0;
     ti.g1 = ti.g0;
   }
-  ti.cols_in_lds = ti.ne <= LCOL_CAP;
   return ti;
 }
 
-// per-lane index data of a tile: loaded into registers by load(), published to the wave's LDS by
-// write() -- split so the NEXT tile's index can be in flight while the current tile computes.
-struct TileIndex {
-  int my_row, my_gp;
-  float my_dinv;
-  int my_col[LCOL_CAP / 64];
+// per-lane index data of a tile (first 64 edges + graph offsets), loaded into registers by load() and
+// turned into the LDS count matrix by build() -- split so the NEXT tile can be in flight while the
+// current one computes.
+struct TileEdges {
+  long long es, ed;
+  int my_gp;
 
   __device__ __forceinline__ void load(const TileInfo& ti, const int32_t* __restrict__ graph_ptr,
-                                       const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                       const float* __restrict__ dinv, int64_t N, int lane) {
-    const int lr = lane <= ti.n ? lane : ti.n;               // rp has N + 1 entries: nbase + n is valid
-    my_row = rp[ti.nbase + lr] - ti.ebase;
-    int64_t dn = (int64_t)ti.nbase + (lane < TM ? lane : 0);
-    if (dn > N - 1) dn = N - 1;
-    my_dinv = dinv[dn];
+                                       const int64_t* __restrict__ ei, int64_t E, int lane) {
     const int ng = ti.g1 - ti.g0;
     my_gp = graph_ptr[ti.g0 + (lane <= ng ? lane : ng)] - ti.nbase;
-    const bool want = ti.cols_in_lds && ti.ne > 0;          // wave-uniform
-#pragma unroll
-    for (int j = 0; j < LCOL_CAP / 64; ++j) {
-      const int k = lane + 64 * j;
-      my_col[j] = want ? ci[ti.ebase + (k < ti.ne ? k : ti.ne - 1)] - ti.nbase : 0;
+    es = 0;
+    ed = 0;
+    if (ti.ne > 0) {  // wave-uniform
+      const int64_t k = (int64_t)ti.ebase + (lane < ti.ne ? lane : ti.ne - 1);
+      es = ei[k];
+      ed = ei[E + k];
     }
   }
 
-  __device__ __forceinline__ void write(WaveLds& L, const TileInfo& ti, int lane, int32_t* status) const {
-    const int ng = ti.g1 - ti.g0;
-    if (ti.cols_in_lds) {
+  // C = I + sum_e [dst_e][src_e],  ldinv = (row sum)^-1/2 ; edges beyond the first 64 are read here
+  __device__ __forceinline__ void build(WaveLds& L, const TileInfo& ti, const int64_t* __restrict__ ei, int64_t E,
+                                        int lane, int32_t* status) const {
 #pragma unroll
-      for (int j = 0; j < LCOL_CAP / 64; ++j) {
-        const int k = lane + 64 * j;
-        if (k < ti.ne) {
-          int c = my_col[j];
-          if (c < 0 || c >= ti.n) { c = 0; atomicOr(status, HCG_STATUS_EDGE_UNGROUPED); }
-          L.lofs[k] = (unsigned short)(c * HS * 4);
+    for (int j = 0; j < CNT_WORDS / 256; ++j)
+      *reinterpret_cast<int4*>(&L.cnt[(lane + 64 * j) * 4]) = make_int4(0, 0, 0, 0);
+    if (lane < TM) L.ldinv[lane] = 0.f;
+    int* degc = reinterpret_cast<int*>(L.ldinv);
+    if (lane < ti.n) L.cnt[lane * CS + lane] = 1;                       // self loop, weight 1
+    const int ng = ti.g1 - ti.g0;
+    if (lane <= ng) L.lgp[lane] = my_gp;
+    for (int k0 = 0; k0 < ti.ne; k0 += 64) {
+      long long s = es, d = ed;
+      if (k0 > 0) {
+        const int64_t k = (int64_t)ti.ebase + (k0 + lane < ti.ne ? k0 + lane : ti.ne - 1);
+        s = ei[k];
+        d = ei[E + k];
+      }
+      if (k0 + lane < ti.ne) {
+        const long long sl = s - ti.nbase, dl = d - ti.nbase;
+        if (sl < 0 || sl >= ti.n || dl < 0 || dl >= ti.n) {
+          atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);                  // edge leaves its graph: ignored, flagged
+        } else {
+          atomicAdd(&L.cnt[(int)dl * CS + (int)sl], 1);                 // ds_add_u32: exact, order-independent
+          atomicAdd(&degc[(int)dl], 1);
         }
       }
     }
-    if (lane <= ti.n) L.lrow[lane] = my_row;
-    if (lane < TM) L.ldinv[lane] = lane < ti.n ? my_dinv : 0.f;
-    if (lane <= ng) L.lgp[lane] = my_gp;
+    if (lane < TM) {
+      const float deg = 1.0f + (float)degc[lane];
+      L.ldinv[lane] = lane < ti.n ? 1.0f / sqrtf(deg) : 0.f;
+    }
   }
 };
 
-constexpr int GJ = 4;  // neighbours gathered with all reads in flight; longer rows continue in a loop
-
-// res[it] = sum_{k in row i} src[c_k] + src[i]   for this lane's rows i = 4*it + r4 (it = 0..TM/4-1),
-// float4 slot q.  Neighbours first in CSR order, self loop last (the order the reference's
-// scatter_add_ over [edges ; self loops] adds them).  Written for ILP: the row offsets, then the
-// neighbour indices, then the neighbour rows are each read as one batch of independent LDS loads --
-// as a dependent per-neighbour loop this phase took 17k cycles per tile (4x the MFMA time).
-__device__ __forceinline__ void gather_tile(const WaveLds& L, const float* src, const TileInfo& ti,
-                                            const int32_t* __restrict__ ci, int q, int r4, int32_t* status,
-                                            float4 (&res)[TM / 4]) {
-  constexpr int HALF = TM / 8;  // two batches of 4 row groups: bounds the live index registers
-  const char* srcb = reinterpret_cast<const char*>(src) + 16 * q;
-#pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
-    int kb[HALF], dg[HALF];
-#pragma unroll
-    for (int u = 0; u < HALF; ++u) {
-      const int i = (hb * HALF + u) * 4 + r4;
-      const int ic = i < ti.n ? i : (ti.n > 0 ? ti.n - 1 : 0);
-      kb[u] = L.lrow[ic];
-      dg[u] = i < ti.n ? L.lrow[ic + 1] - kb[u] : 0;
-    }
-    if (ti.cols_in_lds) {
-      unsigned ofs[HALF][GJ];
-#pragma unroll
-      for (int u = 0; u < HALF; ++u)
-#pragma unroll
-        for (int j = 0; j < GJ; ++j) {
-          const int k = kb[u] + j;
-          const unsigned o = L.lofs[k < LCOL_CAP ? k : LCOL_CAP - 1];
-          ofs[u][j] = j < dg[u] ? o : ZERO_ROW_OFF;        // missing slot -> the zero row
-        }
-#pragma unroll
-      for (int u = 0; u < HALF; ++u) {
-        float4 acc = *reinterpret_cast<const float4*>(srcb + ofs[u][0]);
-#pragma unroll
-        for (int j = 1; j < GJ; ++j) acc = f4_add(acc, *reinterpret_cast<const float4*>(srcb + ofs[u][j]));
-        res[hb * HALF + u] = acc;
-      }
-#pragma unroll
-      for (int u = 0; u < HALF; ++u) {
-        if (__ballot(dg[u] > GJ) != 0ull) {                  // rare: a node with more than GJ neighbours
-          const int ke = kb[u] + dg[u];
-          for (int k = kb[u] + GJ; __ballot(k < ke) != 0ull; ++k)
-            if (k < ke) res[hb * HALF + u] = f4_add(res[hb * HALF + u], *reinterpret_cast<const float4*>(srcb + L.lofs[k]));
-        }
-      }
-    } else {                                                  // tile with > LCOL_CAP edges: indices from global
-#pragma unroll
-      for (int u = 0; u < HALF; ++u) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int ke = kb[u] + dg[u];
-        for (int k = kb[u]; __ballot(k < ke) != 0ull; ++k) {
-          if (k < ke) {
-            int c = ci[ti.ebase + k] - ti.nbase;
-            if (c < 0 || c >= ti.n) { c = 0; atomicOr(status, HCG_STATUS_EDGE_UNGROUPED); }
-            acc = f4_add(acc, *reinterpret_cast<const float4*>(srcb + c * HS * 4));
-          }
-        }
-        res[hb * HALF + u] = acc;
-      }
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < TM / 4; ++it)
-    res[it] = f4_add(res[it], *reinterpret_cast<const float4*>(srcb + (it * 4 + r4) * HS * 4));
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_shfl_xor(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
 
 // Stage n rows of a row-major [Nrows, F] global matrix into buf[row][0..KPAD), rows >= n and columns
@@ -311,27 +250,26 @@ __device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __
 template <int KPAD, bool VEC, bool POOL>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ dinv,
-    const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B,
-    int num_tiles, float slope, int apply_act, float* __restrict__ out, float* __restrict__ emb,
-    int32_t* __restrict__ status) {
+    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
+    const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
+    float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
   __shared__ WaveLds lds[WAVES];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> scalar tile loads
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveLds& L = lds[wave];
-  const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
+  const int r = lane & 31, h = lane >> 5;
   const int stride = gridDim.x * WAVES;
   int t = blockIdx.x * WAVES + wave;
   bool have = t < num_tiles;
 
   // first tile's loads go out before anything else
   TileInfo ti;
-  TileIndex tix;
+  TileEdges te;
   Stager<KPAD, VEC> sx;
   if (have) {
     ti = tile_scalars(t, gpt, B, graph_ptr, edge_ptr, lane, status);
     sx.load(x, F, N, ti.nbase, ti.n, lane);
-    tix.load(ti, graph_ptr, rowptr, col, dinv, N, lane);
+    te.load(ti, graph_ptr, ei, E, lane);
   }
 
   // weight operand: W [64][F] -> LDS (coalesced, once per workgroup) -> 64 VGPRs per lane.
@@ -339,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   // row nb*32 + r at a fixed k -> stride KPAD + 1 floats -> conflict-free.
   float wreg[2][KPAD / 2];
   {
-    float* wl = reinterpret_cast<float*>(&lds[0]);   // 64 * (KPAD + 1) floats fit in one wave region
+    float* wl = reinterpret_cast<float*>(&lds[0]);   // flat view of the workgroup's LDS (64*(KPAD+1) floats)
     stage_matrix(wl, KPAD + 1, W, DD, F, KPAD);
     __syncthreads();
 #pragma unroll
@@ -348,13 +286,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       for (int s = 0; s < KPAD / 2; ++s) wreg[nb][s] = wl[(nb * 32 + r) * (KPAD + 1) + 8 * (s >> 2) + 4 * h + (s & 3)];
     __syncthreads();
   }
-  for (int k = lane; k < HS; k += 64) L.zeroA[k] = 0.f;
-  const float4 bia = *reinterpret_cast<const float4*>(bias + 4 * q);
+  const float b0 = bias[r], b1 = bias[32 + r];
   STAMP(0);
   int stamp_it = 0;
   if (have) {
-    tix.write(L, ti, lane, status);
-    sx.write(L.bufB, F, ti.n, lane);
+    sx.write(L.buf, F, ti.n, lane);
+    te.build(L, ti, ei, E, lane, status);
   }
 
   while (have) {
@@ -363,74 +300,87 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const int tn = t + stride;
     const bool have_next = tn < num_tiles;
     TileInfo tin;
-    TileIndex tixn;
+    TileEdges ten;
     Stager<KPAD, VEC> sxn;
     if (VEC && have_next) {   // (the scalar-staging variants are short of registers: they load after the compute)
       tin = tile_scalars(tn, gpt, B, graph_ptr, edge_ptr, lane, status);
       sxn.load(x, F, N, tin.nbase, tin.n, lane);
-      tixn.load(tin, graph_ptr, rowptr, col, dinv, N, lane);
+      ten.load(tin, graph_ptr, ei, E, lane);
     }
     STAMP(2 + 8 * stamp_it);
 
+    // ---- H = X W^T
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if (!(HCG_ABLATE & 1)) tile_gemm<KPAD>(L.bufB, wreg, acc0, acc1, lane);
+    if (!(HCG_ABLATE & 1)) tile_gemm<KPAD>(L.buf, wreg, acc0, acc1, lane);
     STAMP(3 + 8 * stamp_it);
 
-    // h' = dinv (.) h  -> bufA   (C/D map: col = lane&31, row = (i&3) + 8*(i>>2) + 4*h)
+    // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H'
+    f32x16 y0, y1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      const float dv = L.ldinv[row];
-      L.bufA[row * HS + r] = dv * acc0[i];
-      L.bufA[row * HS + 32 + r] = dv * acc1[i];
+      const float dv = L.ldinv[krow(i, h)];
+      acc0[i] *= dv;
+      acc1[i] *= dv;
+      y0[i] = 0.f;
+      y1[i] = 0.f;
     }
     STAMP(4 + 8 * stamp_it);
-
-    // segmented sum + bias + LeakyReLU, 4 node rows per wave step, all LDS reads batched
-    float4 y[TM / 4];
     if (!(HCG_ABLATE & 2)) {
-      gather_tile(L, L.bufA, ti, col, q, r4, status, y);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float a = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)]; B[k][j] = acc[i]
+        y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc0[i], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[i], y1, 0, 0, 0);
+      }
     } else {
-#pragma unroll
-      for (int it = 0; it < TM / 4; ++it) y[it] = *reinterpret_cast<const float4*>(L.bufA + (it * 4 + r4) * HS + 4 * q);
+      y0 = acc0;
+      y1 = acc1;
     }
+
+    // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers
 #pragma unroll
-    for (int it = 0; it < TM / 4; ++it) {
-      const int i = it * 4 + r4;
-      const float di = L.ldinv[i];
-      float4 v = make_float4(di * y[it].x + bia.x, di * y[it].y + bia.y, di * y[it].z + bia.z, di * y[it].w + bia.w);
-      // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes), 2 ops not 3
-      if (apply_act) v = make_float4(fmaxf(v.x, slope * v.x), fmaxf(v.y, slope * v.y), fmaxf(v.z, slope * v.z), fmaxf(v.w, slope * v.w));
-      y[it] = v;
+    for (int i = 0; i < 16; ++i) {
+      const int row = krow(i, h);
+      const float dv = L.ldinv[row];
+      float v0 = fmaf(y0[i], dv, b0), v1 = fmaf(y1[i], dv, b1);
+      // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes)
+      if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
+      y0[i] = v0;
+      y1[i] = v1;
       if (!(HCG_ABLATE & 4)) {
-        if (i < ti.n) *reinterpret_cast<float4*>(out + (size_t)(ti.nbase + i) * DD + 4 * q) = v;
-      } else if (v.x == 12345.678f) {
-        out[0] = v.y;   // keeps the values live without storing them
+        if (row < ti.n) {
+          float* o = out + (size_t)(ti.nbase + row) * DD + r;
+          o[0] = v0;
+          o[32] = v1;
+        }
+      } else if (v0 == 12345.678f) {
+        out[0] = v1;
       }
     }
     if (POOL) {
       for (int g = ti.g0; g < ti.g1; ++g) {
         const int gb = L.lgp[g - ti.g0], ge = L.lgp[g - ti.g0 + 1];
-        float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float m0 = -INFINITY, m1 = -INFINITY, s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int it = 0; it < TM / 4; ++it) {
-          const int i = it * 4 + r4;
-          if (i >= gb && i < ge) { pmax = f4_max(pmax, y[it]); psum = f4_add(psum, y[it]); }
+        for (int i = 0; i < 16; ++i) {
+          const int row = krow(i, h);
+          if (row >= gb && row < ge) { m0 = fmaxf(m0, y0[i]); m1 = fmaxf(m1, y1[i]); s0 += y0[i]; s1 += y1[i]; }
         }
-        pmax = f4_max(pmax, f4_shfl_xor(pmax, 16));
-        pmax = f4_max(pmax, f4_shfl_xor(pmax, 32));
-        psum = f4_add(psum, f4_shfl_xor(psum, 16));
-        psum = f4_add(psum, f4_shfl_xor(psum, 32));
-        if (r4 == 0) {
+        m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (h == 0) {
           const int n = ge - gb;
           const float cnt = (float)(n > 0 ? n : 1);
-          if (n <= 0) pmax = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(emb + (size_t)g * 2 * DD + 4 * q) = pmax;
-          *reinterpret_cast<float4*>(emb + (size_t)g * 2 * DD + DD + 4 * q) =
-              make_float4(psum.x / cnt, psum.y / cnt, psum.z / cnt, psum.w / cnt);
+          if (n <= 0) { m0 = 0.f; m1 = 0.f; }
+          float* e = emb + (size_t)g * 2 * DD;
+          e[r] = m0;
+          e[32 + r] = m1;
+          e[DD + r] = s0 / cnt;
+          e[DD + 32 + r] = s1 / cnt;
         }
       }
     }
@@ -442,12 +392,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       if (!VEC) {
         tin = tile_scalars(tn, gpt, B, graph_ptr, edge_ptr, lane, status);
         sxn.load(x, F, N, tin.nbase, tin.n, lane);
-        tixn.load(tin, graph_ptr, rowptr, col, dinv, N, lane);
+        ten.load(tin, graph_ptr, ei, E, lane);
       }
       t = tn;
       ti = tin;
-      tixn.write(L, ti, lane, status);
-      sxn.write(L.bufB, F, ti.n, lane);
+      sxn.write(L.buf, F, ti.n, lane);
+      ten.build(L, ti, ei, E, lane, status);
     }
   }
   STAMP(63);
@@ -463,10 +413,9 @@ template <int KPAD, bool VEC, bool NEEDS_DX, bool POOLG>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb,
     const float* __restrict__ a_out, const float* __restrict__ x, int F, const float* __restrict__ W,
-    const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t, const float* __restrict__ dinv,
-    const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B,
-    int num_tiles, float slope, int apply_act, float* __restrict__ dx, float* __restrict__ partials,
-    int32_t* __restrict__ status) {
+    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
+    const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
+    float* __restrict__ dx, float* __restrict__ partials, int32_t* __restrict__ status) {
   __shared__ WaveLds lds[WAVES];
   __shared__ float wlds[NEEDS_DX ? DD * KPAD : 4];   // dx operand W [d][f], shared by the 8 waves
   const int lane = threadIdx.x & 63;
@@ -480,7 +429,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     stage_matrix(wlds, KPAD, W, DD, F, KPAD);
     __syncthreads();
   }
-  for (int k = lane; k < HS; k += 64) L.zeroA[k] = 0.f;
 
   f32x16 dw[2][NBF];  // dW[d-block][f-block], accumulated over every tile of this wave
 #pragma unroll
@@ -493,16 +441,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 
   for (int t = blockIdx.x * WAVES + wave; t < num_tiles; t += stride) {
     const TileInfo ti = tile_scalars(t, gpt, B, graph_ptr, edge_ptr, lane, status);
-    // the global reads of step 1 go in flight together: A rows, dA rows, index data
+    // the global reads of step 1 go in flight together: A rows, dA rows, edges
     Stager<DD, true> sa;
     sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
     Stager<DD, true> sd;
     if (!POOLG) sd.load(dout, DD, N, ti.nbase, ti.n, lane);
-    TileIndex tix;
-    tix.load(ti, graph_ptr, rowptr_t, col_t, dinv, N, lane);
-    tix.write(L, ti, lane, status);
+    TileEdges te;
+    te.load(ti, graph_ptr, ei, E, lane);
+    te.build(L, ti, ei, E, lane, status);
 
-    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> bufA (rows >= n zero); A / dA stay in registers
+    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> buf (rows >= n zero); A / dA stay in registers
     float4 dy[TM / 4];
     if (POOLG) {
 #pragma unroll
@@ -557,44 +505,55 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         const float di = L.ldinv[i];
         d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
       }
-      *reinterpret_cast<float4*>(L.bufA + i * HS + 4 * q) = d;
+      *reinterpret_cast<float4*>(L.buf + i * HS + 4 * q) = d;
     }
 
-    // x rows: issued now (the A / dA registers are free again), consumed after the segmented sum
+    // x rows: issued now (the A / dA registers are free again), consumed after dH
     Stager<KPAD, VEC> sx;
-    if (VEC) sx.load(x, F, N, ti.nbase, ti.n, lane);
+    constexpr bool EARLY_X = VEC && !NEEDS_DX;   // the dx variants are short of registers: they load x late
+    if (EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
 
-    // ---- 2. dH_j = dinv_j * ( sum_{k in out(j)} dY'_k + dY'_j ) -> bufB (rows >= n zero)
-    {
-      float4 res[TM / 4];
-      gather_tile(L, L.bufA, ti, col_t, q, r4, status, res);
+    // ---- 2. dH = dinv (.) ( (C + I)^T dY' ):  A[m = j][k = i] = cnt[i][j],  B[k = i][col] = dY'[i][col]
+    f32x16 dh0, dh1;
 #pragma unroll
-      for (int it = 0; it < TM / 4; ++it) {
-        const int i = it * 4 + r4;
-        const float di = i < ti.n ? L.ldinv[i] : 0.f;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < ti.n) s = make_float4(di * res[it].x, di * res[it].y, di * res[it].z, di * res[it].w);
-        *reinterpret_cast<float4*>(L.bufB + i * HS + 4 * q) = s;
-      }
-    }
-
-    // ---- 3. x tile -> bufA ; dW += dH^T x   (K = node rows: k-step s <-> node 2s + h)
-    if (!VEC) sx.load(x, F, N, ti.nbase, ti.n, lane);   // scalar-staging variants: short of registers, load late
-    sx.write(L.bufA, F, ti.n, lane);
+    for (int i = 0; i < 16; ++i) { dh0[i] = 0.f; dh1[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < TM / 2; ++s) {
-      const int node = 2 * s + h;
-      const float a0 = L.bufB[node * HS + r], a1 = L.bufB[node * HS + 32 + r];
+      const int k = 2 * s + h;
+      const float a = (float)L.cnt[k * CS + r];
+      dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + r], dh0, 0, 0, 0);
+      dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + 32 + r], dh1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float dv = L.ldinv[krow(i, h)];
+      dh0[i] *= dv;
+      dh1[i] *= dv;
+    }
+
+    // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (k-step i <-> node krow(i, h))
+    if (!EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
+    sx.write(L.buf, F, ti.n, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int node = krow(i, h);
 #pragma unroll
       for (int nb = 0; nb < NBF; ++nb) {
-        const float b = L.bufA[node * HS + nb * 32 + r];
-        dw[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, dw[0][nb], 0, 0, 0);
-        dw[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, dw[1][nb], 0, 0, 0);
+        const float b = L.buf[node * HS + nb * 32 + r];
+        dw[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(dh0[i], b, dw[0][nb], 0, 0, 0);
+        dw[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(dh1[i], b, dw[1][nb], 0, 0, 0);
       }
     }
 
-    // ---- 4. dx = dH W   (B[k = d][j = f] = W[d][f] from the workgroup's LDS copy; k-step s <-> d = 8t+4h+u)
+    // ---- 4. dx = dH W: dH -> buf as [node][d] (the contraction runs over the accumulator's LANE
+    //         dimension, so this one needs the LDS transpose), B[k = d][j = f] = W[d][f] from LDS
     if (NEEDS_DX) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int node = krow(i, h);
+        L.buf[node * HS + r] = dh0[i];
+        L.buf[node * HS + 32 + r] = dh1[i];
+      }
       f32x16 dxa[NBF];
 #pragma unroll
       for (int nb = 0; nb < NBF; ++nb)
@@ -602,7 +561,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         for (int i = 0; i < 16; ++i) dxa[nb][i] = 0.f;
 #pragma unroll
       for (int t8 = 0; t8 < DD / 8; ++t8) {
-        const float4 a = *reinterpret_cast<const float4*>(L.bufB + r * HS + 8 * t8 + 4 * h);
+        const float4 a = *reinterpret_cast<const float4*>(L.buf + r * HS + 8 * t8 + 4 * h);
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -614,7 +573,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int row = krow(i, h);
         if (row < ti.n) {
 #pragma unroll
           for (int nb = 0; nb < NBF; ++nb) {
@@ -626,28 +585,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     }
   }
 
-  // ---- combine the waves of this workgroup (fixed order) and publish one partial slab
-  __syncthreads();  // every wave is done with its tile buffers
-  float* mine = reinterpret_cast<float*>(&lds[wave]);  // >= 64*KPAD + 64 floats (two tile buffers)
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NBF; ++nb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int d = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        mine[d * KPAD + nb * 32 + r] = dw[mb][nb][i];
-      }
+  // ---- combine the waves of this workgroup (fixed order, two rounds of four waves through a flat
+  //      view of the LDS) and publish one partial slab
+  constexpr int SLABF = DD * KPAD + DD;
+  constexpr int PER_T = (SLABF + WAVES * 64 - 1) / (WAVES * 64);
+  float* flat = reinterpret_cast<float*>(&lds[0]);
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 16));
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 32));
-  if (r4 == 0) *reinterpret_cast<float4*>(mine + DD * KPAD + 4 * q) = dbacc;
-  __syncthreads();
-  float* slab = partials + (size_t)blockIdx.x * (DD * KPAD + DD);
-  for (int idx = threadIdx.x; idx < DD * KPAD + DD; idx += WAVES * 64) {
-    float s = 0.f;
+  float tot[PER_T];
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) s += reinterpret_cast<const float*>(&lds[w])[idx];
-    slab[idx] = s;
+  for (int j = 0; j < PER_T; ++j) tot[j] = 0.f;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();   // tile buffers (round 0) / the previous round's regions (round 1) are free
+    if ((wave >> 2) == round) {
+      float* mine = flat + (size_t)(wave & 3) * SLABF;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBF; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mine[(mb * 32 + krow(i, h)) * KPAD + nb * 32 + r] = dw[mb][nb][i];
+      if (r4 == 0) *reinterpret_cast<float4*>(mine + DD * KPAD + 4 * q) = dbacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER_T; ++j) {
+      const int idx = threadIdx.x + j * WAVES * 64;
+      if (idx < SLABF) tot[j] += ((flat[idx] + flat[SLABF + idx]) + flat[2 * SLABF + idx]) + flat[3 * SLABF + idx];
+    }
+  }
+  float* slab = partials + (size_t)blockIdx.x * SLABF;
+#pragma unroll
+  for (int j = 0; j < PER_T; ++j) {
+    const int idx = threadIdx.x + j * WAVES * 64;
+    if (idx < SLABF) slab[idx] = tot[j];
   }
 }
 
@@ -704,23 +676,22 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
   return (size_t)pick_grid(tiles) * (DD * kpad + DD) * sizeof(float) + 256;
 }
 
-extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* b, const int32_t* rowptr,
-                                   const int32_t* col, const float* dinv, const int32_t* graph_ptr,
-                                   const int32_t* edge_ptr, int64_t N, int64_t B,
-                                   int64_t F, int64_t D, int graphs_per_tile, float slope, int apply_act, float* out,
-                                   float* emb, int32_t* status, hcg_stream_t stream_) {
+extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
+                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* out, float* emb,
+                                   int32_t* status, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;  // LeakyReLU is evaluated as max(v, slope*v)
-  if (N < 0 || B < 0) return HCG_ERR_INVALID_ARG;
+  if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
-  if (!x || !W || !b || !rowptr || !dinv || !graph_ptr || !edge_ptr || !out || !status) return HCG_ERR_INVALID_ARG;
+  if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = pick_grid(tiles);
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
-#define LAUNCH_FWD(KP, VC, PL)                                                                                       \
-  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL>), g, blk, 0, stream, x, (int)F, W, b, rowptr, col, dinv, graph_ptr, \
+#define LAUNCH_FWD(KP, VC, PL)                                                                                        \
+  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL>), g, blk, 0, stream, x, (int)F, W, b, edge_index, E, graph_ptr,   \
                      edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, emb, status)
   if (F <= 32) {
     if (vec) { if (emb) LAUNCH_FWD(32, true, true); else LAUNCH_FWD(32, true, false); }
@@ -735,17 +706,17 @@ extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* 
 }
 
 extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
-                                   const float* x, const float* W, const int32_t* rowptr_t, const int32_t* col_t,
-                                   const float* dinv, const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N,
-                                   int64_t B, int64_t F, int64_t D,
-                                   int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
+                                   const float* x, const float* W, const int64_t* edge_index, int64_t E,
+                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
                                    void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
-  if (N < 0 || B < 0 || !W || !workspace) return HCG_ERR_INVALID_ARG;
+  if (N < 0 || B < 0 || E < 0 || !W || !workspace) return HCG_ERR_INVALID_ARG;
   const bool poolg = (dout == nullptr);
   if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
-  if (N > 0 && B > 0 && (!out || !x || !rowptr_t || !dinv || !graph_ptr || !edge_ptr || !status)) return HCG_ERR_INVALID_ARG;
+  if (N > 0 && B > 0 && (!out || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index)))
+    return HCG_ERR_INVALID_ARG;
   const int kpad = F <= 32 ? 32 : 64;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = (N > 0 && B > 0) ? pick_grid(tiles) : 0;
@@ -756,9 +727,9 @@ extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const f
     const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
     const bool ndx = dx != nullptr;
     const dim3 g(grid), blk(WAVES * 64);
-#define LAUNCH_BWD(KP, VC, DX, PG)                                                                                  \
-  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG>), g, blk, 0, stream, dout, demb, emb, out, x, (int)F, W,    \
-                     rowptr_t, col_t, dinv, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, dx,    \
+#define LAUNCH_BWD(KP, VC, DX, PG)                                                                                   \
+  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG>), g, blk, 0, stream, dout, demb, emb, out, x, (int)F, W,     \
+                     edge_index, E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, dx,     \
                      partials, status)
 #define DISPATCH_BWD(KP, VC)                                                             \
   do {                                                                                   \

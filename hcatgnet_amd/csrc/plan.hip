@@ -127,6 +127,49 @@ __global__ __launch_bounds__(256) void k_edge_ptr(const int64_t* __restrict__ ei
   for (int64_t g = prev + 1; g <= cur; ++g) edge_ptr[g] = (int32_t)e;
 }
 
+// blocked mode: graph_ptr and edge_ptr in ONE launch (threads [0, N] walk nodes, [N+1, N+E+1] edges)
+__global__ __launch_bounds__(256) void k_ptrs(const int64_t* __restrict__ ei, const int64_t* __restrict__ batch,
+                                              int64_t N, int64_t E, int64_t B, int32_t* __restrict__ graph_ptr,
+                                              int32_t* __restrict__ edge_ptr, int32_t* __restrict__ status) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int st = 0;
+  int64_t prev = -1, cur = B, pos;
+  int32_t* dst;
+  if (tid <= N) {
+    const int64_t i = tid;
+    pos = i; dst = graph_ptr;
+    if (i > 0) prev = batch[i - 1];
+    if (i < N) {
+      cur = batch[i];
+      if (cur < 0 || cur >= B) st |= HCG_STATUS_BATCH_RANGE;
+      if (i > 0 && cur < prev) st |= HCG_STATUS_BATCH_UNSORTED;
+    }
+  } else if (tid <= N + 1 + E) {
+    const int64_t e = tid - (N + 1);
+    pos = e; dst = edge_ptr;
+    if (e > 0) {
+      int64_t s = ei[e - 1];
+      if (s < 0 || s >= N) s = 0;  // range errors are flagged by the thread that owns the edge
+      prev = batch[s];
+    }
+    if (e < E) {
+      int64_t s = ei[e], d = ei[E + e];
+      if (s < 0 || s >= N || d < 0 || d >= N) { st |= HCG_STATUS_INDEX_RANGE; s = 0; d = 0; }
+      cur = batch[s];
+      if (batch[d] != cur) st |= HCG_STATUS_EDGE_UNGROUPED;
+      if (e > 0 && cur < prev) st |= HCG_STATUS_EDGE_UNGROUPED;
+    }
+  } else {
+    return;
+  }
+  if (st) atomicOr(status, st);
+  if (prev < -1) prev = -1;
+  if (prev > B) prev = B;
+  if (cur < 0) cur = 0;
+  if (cur > B) cur = B;
+  for (int64_t g = prev + 1; g <= cur; ++g) dst[g] = (int32_t)pos;
+}
+
 constexpr int GE_LDS_EDGES = 2048;  // edges of one graph staged in LDS (16 KiB); larger graphs re-read global
 
 // One wavefront per graph.  Lane i of a 64-node chunk owns node (chunk + i): it walks the graph's
@@ -219,7 +262,7 @@ int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) <= v && b < 31) ++
 
 extern "C" size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode) {
   (void)N; (void)B;
-  if (mode == HCG_PLAN_BLOCKED || E <= 0) return 256;
+  if ((mode & ~HCG_PLAN_PTRS_ONLY) == HCG_PLAN_BLOCKED || E <= 0) return 256;
   const size_t keys = hcg_align_up((size_t)E * sizeof(uint64_t), 256);
   return 3 * keys + hcg_align_up(sort_temp_bytes(E), 256) + 1024;
 }
@@ -232,22 +275,31 @@ extern "C" int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, c
   hipStream_t stream = (hipStream_t)stream_;
   if (N < 0 || E < 0 || B < 0 || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 31) || B >= ((int64_t)1 << 31))
     return HCG_ERR_INVALID_ARG;
-  if (!graph_ptr || !rowptr || !rowptr_t || !dinv || !status) return HCG_ERR_INVALID_ARG;
-  if (E > 0 && (!edge_index || !col || !col_t)) return HCG_ERR_INVALID_ARG;
+  const bool want_csr = (mode & HCG_PLAN_PTRS_ONLY) == 0;
+  if (!graph_ptr || !status) return HCG_ERR_INVALID_ARG;
+  if (want_csr && (!rowptr || !rowptr_t || !dinv)) return HCG_ERR_INVALID_ARG;
+  if (E > 0 && (!edge_index || (want_csr && (!col || !col_t)))) return HCG_ERR_INVALID_ARG;
   if (N > 0 && !batch) return HCG_ERR_INVALID_ARG;
   if (edge_weight && (!eid || !eid_t || !ew_csr || !ew_csc || !dinv_unw)) return HCG_ERR_INVALID_ARG;
+  const bool ptrs_only = (mode & HCG_PLAN_PTRS_ONLY) != 0;
+  mode &= ~HCG_PLAN_PTRS_ONLY;
   if (mode != HCG_PLAN_GENERAL && mode != HCG_PLAN_BLOCKED) return HCG_ERR_INVALID_ARG;
   if (mode == HCG_PLAN_BLOCKED && !edge_ptr) return HCG_ERR_INVALID_ARG;
+  if (ptrs_only && mode != HCG_PLAN_BLOCKED) return HCG_ERR_INVALID_ARG;
 
   HCG_TRY(hcg_hip_err(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), stream)));
-  hipLaunchKernelGGL(k_graph_ptr, dim3((unsigned)hcg_cdiv(N + 1, 256)), dim3(256), 0, stream, batch, N, B, graph_ptr,
-                     status);
-  HCG_CHECK_LAUNCH();
+  if (mode == HCG_PLAN_BLOCKED) {
+    hipLaunchKernelGGL(k_ptrs, dim3((unsigned)hcg_cdiv(N + E + 2, 256)), dim3(256), 0, stream, edge_index, batch, N, E,
+                       B, graph_ptr, edge_ptr, status);
+    HCG_CHECK_LAUNCH();
+    if (ptrs_only) return HCG_OK;   // the fused kernels rebuild gcn_norm on chip from the raw edges
+  } else {
+    hipLaunchKernelGGL(k_graph_ptr, dim3((unsigned)hcg_cdiv(N + 1, 256)), dim3(256), 0, stream, batch, N, B, graph_ptr,
+                       status);
+    HCG_CHECK_LAUNCH();
+  }
 
   if (mode == HCG_PLAN_BLOCKED) {
-    hipLaunchKernelGGL(k_edge_ptr, dim3((unsigned)hcg_cdiv(E + 1, 256)), dim3(256), 0, stream, edge_index, batch, N, E,
-                       B, edge_ptr, status);
-    HCG_CHECK_LAUNCH();
     if (B > 0) {
       hipLaunchKernelGGL(k_graph_csr, dim3((unsigned)B), dim3(64), 0, stream, edge_index, E, B,
                          (const int32_t*)graph_ptr, (const int32_t*)edge_ptr, fill, rowptr, col, eid, rowptr_t, col_t,

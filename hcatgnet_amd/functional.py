@@ -34,6 +34,7 @@ class _GCNLayerFn(torch.autograd.Function):
         D = weight.shape[0]
         if weight.shape[1] != F or N != plan.N:
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(weight.shape)}, plan N {plan.N}")
+        plan.ensure_csr()
         out = torch.empty(N, D, dtype=torch.float32, device=x.device)
         h_ws = torch.empty(N, D, dtype=torch.float32, device=x.device)
         ew = plan.ew_csr if use_edge_weight else None
@@ -171,9 +172,8 @@ class _FusedLayerFn(torch.autograd.Function):
         dev = x.device
         out = torch.empty(N, D, dtype=torch.float32, device=dev)
         emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
-        rc = lib.hcg_fused_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.rowptr),
-                                     _lib.ptr(plan.col), _lib.ptr(plan.dinv), _lib.ptr(plan.graph_ptr),
-                                     _lib.ptr(plan.edge_ptr), N, plan.B, F, D, gpt, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
+        rc = lib.hcg_fused_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
+                                     _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, gpt, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
                                      _lib.stream_ptr())
         _lib.check(rc, "hcg_fused_layer_fwd")
         ctx.plan, ctx.gpt, ctx.apply_act, ctx.slope, ctx.pool = plan, gpt, apply_act, slope, pool
@@ -202,7 +202,7 @@ class _FusedLayerFn(torch.autograd.Function):
         wsb = lib.hcg_fused_workspace_bytes(plan.B, F, D, ctx.gpt)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = lib.hcg_fused_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), _lib.ptr(x),
-                                     _lib.ptr(weight), _lib.ptr(plan.rowptr_t), _lib.ptr(plan.col_t), _lib.ptr(plan.dinv),
+                                     _lib.ptr(weight), _lib.ptr(plan.edge_index), plan.E,
                                      _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, ctx.gpt, ctx.slope,
                                      int(ctx.apply_act), _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "hcg_fused_layer_bwd")

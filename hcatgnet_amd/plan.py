@@ -2,7 +2,11 @@
 
 Replaces what PyG recomputes inside every `GCNConv.forward` (gcn_norm: self loops, degree,
 deg^-1/2; reference call sites model/gcn.py:58,62) and the `batch`-vector scatter indices of the
-pools (model/gcn.py:65-66): CSR by target node + its transpose, `dinv`, `graph_ptr`.
+pools (model/gcn.py:65-66).  Two levels:
+  * pointers  graph_ptr / edge_ptr (+ device-side validation) -- ONE launch; all the fused
+              small-graph kernels need (they rebuild gcn_norm on chip from the raw edges);
+  * CSR       rowptr/col (+ transpose) and dinv for the any-shape kernels, built lazily by
+              `ensure_csr()` the first time a layer needs them.
 """
 from __future__ import annotations
 
@@ -14,8 +18,9 @@ from . import _lib
 
 
 class BatchPlan:
-    __slots__ = ("N", "E", "B", "mode", "fill", "graph_ptr", "edge_ptr", "rowptr", "col", "eid", "rowptr_t",
-                 "col_t", "eid_t", "dinv", "ew_csr", "ew_csc", "dinv_unw", "status", "max_nodes", "max_edges", "validated")
+    __slots__ = ("N", "E", "B", "mode", "fill", "edge_index", "batch", "edge_weight", "graph_ptr", "edge_ptr",
+                 "rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t", "dinv", "ew_csr", "ew_csc", "dinv_unw",
+                 "status", "max_nodes", "max_edges", "validated", "has_csr")
 
     def check_status(self):
         """Synchronising read of the device-side status word; raises on any violation."""
@@ -25,16 +30,55 @@ class BatchPlan:
             raise ValueError("hcatgnet_amd: invalid batch: " + _lib.describe_status(word))
         return word
 
+    # ------------------------------------------------------------------ device build
+    def _run(self, which: str, csr: bool):
+        lib = _lib.load()
+        dev = self.edge_index.device
+        N, E, B = self.N, self.E, self.B
+        i32 = dict(dtype=torch.int32, device=dev)
+        if csr and self.rowptr is None:
+            self.rowptr = torch.empty(N + 1, **i32)
+            self.rowptr_t = torch.empty(N + 1, **i32)
+            self.col = torch.empty(max(E, 1), **i32)
+            self.col_t = torch.empty(max(E, 1), **i32)
+            self.dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+            if self.edge_weight is not None:
+                self.eid = torch.empty(max(E, 1), **i32)
+                self.eid_t = torch.empty(max(E, 1), **i32)
+                self.ew_csr = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+                self.ew_csc = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+                self.dinv_unw = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        m = _lib.HCG_PLAN_BLOCKED if which == "blocked" else _lib.HCG_PLAN_GENERAL
+        if not csr:
+            m |= _lib.HCG_PLAN_PTRS_ONLY
+        wsb = lib.hcg_plan_workspace_bytes(N, E, B, m)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        p = _lib.ptr
+        rc = lib.hcg_plan_build(p(self.edge_index), p(self.batch), p(self.edge_weight), N, E, B, self.fill, m,
+                                p(self.graph_ptr), p(self.edge_ptr), p(self.rowptr), p(self.col), p(self.eid),
+                                p(self.rowptr_t), p(self.col_t), p(self.eid_t), p(self.dinv), p(self.ew_csr),
+                                p(self.ew_csc), p(self.dinv_unw), p(self.status), p(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_plan_build")
+        self.mode = which
+        self.has_csr = csr
+
+    def ensure_csr(self):
+        """Build rowptr/col/dinv (and the transpose) if this plan so far only holds the pointers."""
+        if not self.has_csr:
+            self._run(self.mode, csr=True)
+        return self
+
     @staticmethod
     def build(edge_index: torch.Tensor, batch: Optional[torch.Tensor], num_nodes: int,
               num_graphs: Optional[int] = None, edge_weight: Optional[torch.Tensor] = None,
               improved: bool = False, mode: str = "auto", validate: bool = True,
-              max_nodes: Optional[int] = None, max_edges: Optional[int] = None) -> "BatchPlan":
+              max_nodes: Optional[int] = None, max_edges: Optional[int] = None, csr: Optional[bool] = None) -> "BatchPlan":
         """mode: 'blocked' (edges grouped by graph, the order PyG-style collation emits),
         'general' (any order; device radix sort) or 'auto' (blocked, re-planned as general when the
         device reports ungrouped edges -- needs `validate=True`, i.e. one 4-byte D2H sync).
-        `validate=False` + an explicit mode enqueues the build without any host sync."""
-        lib = _lib.load()
+        `validate=False` + an explicit mode enqueues the build without any host sync.
+        csr: None = lazily (blocked plans start with the pointers only), True = build it now."""
+        _lib.load()
         _lib.require_gpu(edge_index, batch, edge_weight)
         dev = edge_index.device
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -65,43 +109,25 @@ class BatchPlan:
 
         p = BatchPlan()
         p.N, p.E, p.B, p.fill = N, E, B, fill
-        p.max_nodes, p.max_edges, p.validated = max_nodes, max_edges, False
+        p.edge_index, p.batch, p.edge_weight = edge_index, batch, edge_weight
+        p.max_nodes, p.max_edges, p.validated, p.has_csr = max_nodes, max_edges, False, False
         i32 = dict(dtype=torch.int32, device=dev)
         p.graph_ptr = torch.empty(B + 1, **i32)
         p.edge_ptr = torch.empty(B + 1, **i32)
-        p.rowptr = torch.empty(N + 1, **i32)
-        p.rowptr_t = torch.empty(N + 1, **i32)
-        p.col = torch.empty(max(E, 1), **i32)
-        p.col_t = torch.empty(max(E, 1), **i32)
-        p.dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
         p.status = torch.empty(4, **i32)
-        if edge_weight is not None:
-            p.eid = torch.empty(max(E, 1), **i32)
-            p.eid_t = torch.empty(max(E, 1), **i32)
-            p.ew_csr = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-            p.ew_csc = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-            p.dinv_unw = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-        else:
-            p.eid = p.eid_t = p.ew_csr = p.ew_csc = p.dinv_unw = None
+        p.rowptr = p.col = p.eid = p.rowptr_t = p.col_t = p.eid_t = None
+        p.dinv = p.ew_csr = p.ew_csc = p.dinv_unw = None
 
-        def run(which: str):
-            m = _lib.HCG_PLAN_BLOCKED if which == "blocked" else _lib.HCG_PLAN_GENERAL
-            wsb = lib.hcg_plan_workspace_bytes(N, E, B, m)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            rc = lib.hcg_plan_build(_lib.ptr(edge_index), _lib.ptr(batch), _lib.ptr(edge_weight), N, E, B, fill, m,
-                                    _lib.ptr(p.graph_ptr), _lib.ptr(p.edge_ptr), _lib.ptr(p.rowptr), _lib.ptr(p.col),
-                                    _lib.ptr(p.eid), _lib.ptr(p.rowptr_t), _lib.ptr(p.col_t), _lib.ptr(p.eid_t),
-                                    _lib.ptr(p.dinv), _lib.ptr(p.ew_csr), _lib.ptr(p.ew_csc), _lib.ptr(p.dinv_unw),
-                                    _lib.ptr(p.status),
-                                    _lib.ptr(ws), wsb, _lib.stream_ptr())
-            _lib.check(rc, "hcg_plan_build")
-            p.mode = which
+        def want_csr(which):
+            if csr is not None:
+                return bool(csr) or which == "general"
+            return which == "general" or edge_weight is not None
 
-        run(want)
+        p._run(want, want_csr(want))
         if validate:
             word = int(p.status[0].item())
             if word & _lib.STATUS_EDGE_UNGROUPED and mode == "auto" and not (word & ~_lib.STATUS_EDGE_UNGROUPED):
-                run("general")
+                p._run("general", True)
                 word = int(p.status[0].item())
             p.validated = True
             if word:

@@ -46,6 +46,8 @@ extern "C" {
 /* hcg_plan_build flags */
 #define HCG_PLAN_GENERAL 0 /* device radix sort; any edge order, any graph size           */
 #define HCG_PLAN_BLOCKED 1 /* edges grouped by graph (PyG collate order); per-graph waves */
+#define HCG_PLAN_PTRS_ONLY 2 /* OR with BLOCKED: only graph_ptr / edge_ptr / status (one launch);
+                                all CSR outputs may be NULL -- enough for the hcg_fused_* kernels */
 
 /* bits of status[0] written by hcg_plan_build */
 #define HCG_STATUS_INDEX_RANGE 1   /* an edge_index entry outside [0,N)                  */
@@ -125,17 +127,20 @@ int hcg_pool_bwd(const float* demb, const float* a, const float* emb, const int3
                  float* da, int64_t N, int64_t B, int64_t D, hcg_stream_t stream);
 
 /* ---- fused per-layer kernels for batches of small graphs (<= 32 nodes per tile, D = 64, F <= 64) ----
- * One launch per layer: tile of whole graphs -> LDS, x W^T on the f32 matrix cores, fixed-order
- * segmented sum out of LDS, bias + LeakyReLU, optional [max, mean] pooling epilogue (a4-a9).
- * Needs a BLOCKED plan (graph_ptr + CSR of hcg_plan_build) and unweighted edges (fill = 1).
+ * One launch per layer: tile of whole graphs -> LDS, gcn_norm rebuilt on chip from the tile's raw COO
+ * edges (LDS integer atomics into a [32][32] count matrix: no CSR), x W^T AND the neighbourhood sum
+ * on the f32 matrix cores, bias + LeakyReLU, optional [max, mean] pooling epilogue (a3-a9).
+ * Needs only graph_ptr / edge_ptr of a BLOCKED plan (edges grouped by graph) and the original int64
+ * edge_index [2, E]; unweighted edges (self-loop weight 1).
  *   hcg_fused_graphs_per_tile: graphs packed into one 32-row tile, 0 = shape not supported
  *   emb != NULL  : also write emb[B, 2D] = [max, mean] of `out` per graph (last conv layer)
- *   status       : the plan's status words; HCG_STATUS_SHAPE_LIMIT is raised if a tile exceeds 32 rows
+ *   status       : the plan's status words; HCG_STATUS_SHAPE_LIMIT is raised if a tile exceeds 32 rows,
+ *                  HCG_STATUS_EDGE_UNGROUPED if an edge leaves its tile (such edges are ignored)
  */
 int hcg_fused_graphs_per_tile(int64_t F, int64_t D, int64_t max_nodes_per_graph);
 size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int graphs_per_tile);
 int hcg_fused_layer_fwd(const float* x, const float* W, const float* b,
-                        const int32_t* rowptr, const int32_t* col, const float* dinv,
+                        const int64_t* edge_index, int64_t E,
                         const int32_t* graph_ptr, const int32_t* edge_ptr,
                         int64_t N, int64_t B, int64_t F, int64_t D,
                         int graphs_per_tile, float slope, int apply_act,
@@ -147,7 +152,7 @@ int hcg_fused_layer_fwd(const float* x, const float* W, const float* b,
  * dW [D, F], db [D]: bitwise reproducible. */
 int hcg_fused_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
                         const float* out, const float* x, const float* W,
-                        const int32_t* rowptr_t, const int32_t* col_t, const float* dinv,
+                        const int64_t* edge_index, int64_t E,
                         const int32_t* graph_ptr, const int32_t* edge_ptr,
                         int64_t N, int64_t B, int64_t F, int64_t D,
                         int graphs_per_tile, float slope, int apply_act,

@@ -60,7 +60,11 @@ def _rand_params(F, D, n_conv=2, n_read=2, n_classes=1, seed=0):
 
 # ---------------------------------------------------------------------------------- plan / indexing
 def _check_plan_against_input(plan, edge_index, batch, B):
+    plan.ensure_csr()
     ei = edge_index.cpu().numpy(); N = batch.numel(); E = ei.shape[1]
+    if plan.mode == "blocked":   # blocked plans also carry the per-graph edge ranges the fused kernels use
+        gid = batch.cpu().numpy()[ei[0]] if E else np.zeros(0, np.int64)
+        assert np.array_equal(plan.edge_ptr.cpu().numpy(), np.searchsorted(gid, np.arange(B + 1), side="left"))
     rowptr = plan.rowptr.cpu().numpy(); col = plan.col.cpu().numpy()[:E]
     rowptr_t = plan.rowptr_t.cpu().numpy(); col_t = plan.col_t.cpu().numpy()[:E]
     # bit-exact reconstruction of the (src, dst) multiset, and STABLE order inside every row

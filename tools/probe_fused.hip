@@ -11,56 +11,69 @@
 int main() {
   const int B = 4096, n = 30, F = 64, D = 64, N = B * n;
   std::mt19937 rng(1);
-  std::vector<int> rowptr(N + 1), col, gp(B + 1), ep(B + 1);
-  std::vector<float> dinv(N), x((size_t)N * F), W(D * F), bias(D, 0.1f);
+  std::vector<int> gp(B + 1), ep(B + 1);
+  std::vector<long long> src, dst;
+  std::vector<float> x((size_t)N * F), W(D * F), bias(D, 0.1f);
   for (auto& v : x) v = (float)(rng() % 2000) / 1000.f - 1.f;
   for (auto& v : W) v = (float)(rng() % 2000) / 8000.f - 0.125f;
   // ring + 2 chords per graph: 32 bonds -> 64 directed edges
   for (int g = 0; g < B; ++g) {
-    gp[g] = g * n; ep[g] = (int)col.size();
-    std::vector<std::vector<int>> adj(n);
-    for (int i = 0; i < n; ++i) { adj[i].push_back((i + 1) % n); adj[(i + 1) % n].push_back(i); }
-    adj[0].push_back(15); adj[15].push_back(0); adj[7].push_back(22); adj[22].push_back(7);
-    for (int i = 0; i < n; ++i) {
-      rowptr[g * n + i] = (int)col.size();
-      for (int j : adj[i]) col.push_back(g * n + j);
-      dinv[g * n + i] = 1.f / sqrtf(1.f + adj[i].size());
-    }
+    gp[g] = g * n; ep[g] = (int)src.size();
+    auto bond = [&](int i, int j) { src.push_back(g * n + i); dst.push_back(g * n + j); src.push_back(g * n + j); dst.push_back(g * n + i); };
+    for (int i = 0; i < n; ++i) bond(i, (i + 1) % n);
+    bond(0, 15); bond(7, 22);
   }
-  gp[B] = N; ep[B] = (int)col.size(); rowptr[N] = (int)col.size();
-  const int E = (int)col.size();
+  gp[B] = N; ep[B] = (int)src.size();
+  const int E = (int)src.size();
+  std::vector<long long> ei(2 * (size_t)E);
+  for (int e = 0; e < E; ++e) { ei[e] = src[e]; ei[E + e] = dst[e]; }
   printf("N %d E %d\n", N, E);
-  float *dx, *dW, *db, *ddinv, *dout, *demb; int *drp, *dcol, *dgp, *dep, *dstatus; unsigned long long* dst;
-  CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&db, D * 4)); CK(hipMalloc(&ddinv, N * 4));
+  float *dx, *dW, *db, *dout, *demb; long long* dei; int *dgp, *dep, *dstatus; unsigned long long* dstamp;
+  CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&db, D * 4));
   CK(hipMalloc(&dout, (size_t)N * D * 4)); CK(hipMalloc(&demb, (size_t)B * 2 * D * 4));
-  CK(hipMalloc(&drp, (N + 1) * 4)); CK(hipMalloc(&dcol, E * 4)); CK(hipMalloc(&dgp, (B + 1) * 4)); CK(hipMalloc(&dep, (B + 1) * 4));
-  CK(hipMalloc(&dstatus, 16)); CK(hipMalloc(&dst, 4 * WAVES * 64 * 8));
+  CK(hipMalloc(&dei, ei.size() * 8)); CK(hipMalloc(&dgp, (B + 1) * 4)); CK(hipMalloc(&dep, (B + 1) * 4));
+  CK(hipMalloc(&dstatus, 16)); CK(hipMalloc(&dstamp, 4 * WAVES * 64 * 8));
   CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(db, bias.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ddinv, dinv.data(), N * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(drp, rowptr.data(), (N + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcol, col.data(), E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, bias.data(), D * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dei, ei.data(), ei.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(dgp, gp.data(), (B + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dep, ep.data(), (B + 1) * 4, hipMemcpyHostToDevice));
-  CK(hipMemset(dstatus, 0, 16)); CK(hipMemset(dst, 0, 4 * WAVES * 64 * 8));
+  CK(hipMemset(dstatus, 0, 16)); CK(hipMemset(dstamp, 0, 4 * WAVES * 64 * 8));
 #ifdef HCG_STAMP
-  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dst, sizeof(dst)));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dstamp, sizeof(dstamp)));
 #endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int pool = 0; pool < 2; ++pool) {
     for (int it = 0; it < 5; ++it)
-      hcg_fused_layer_fwd(dx, dW, db, drp, dcol, ddinv, dgp, dep, N, B, F, D, 1, 0.01f, 1, dout, pool ? demb : nullptr, dstatus, 0);
+      hcg_fused_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 1, dout, pool ? demb : nullptr, dstatus, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     const int iters = 50;
     for (int it = 0; it < iters; ++it)
-      hcg_fused_layer_fwd(dx, dW, db, drp, dcol, ddinv, dgp, dep, N, B, F, D, 1, 0.01f, 1, dout, pool ? demb : nullptr, dstatus, 0);
+      hcg_fused_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 1, dout, pool ? demb : nullptr, dstatus, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("fwd pool=%d: %.2f us per launch\n", pool, ms * 1000.f / iters);
+  }
+  {  // backward kernels (layer 2: pooled gradient + dx; layer 1: dout, no dx)
+    float *ddx, *dws; CK(hipMalloc(&ddx, (size_t)N * F * 4));
+    size_t wsb = hcg_fused_workspace_bytes(B, F, D, 1); CK(hipMalloc(&dws, wsb));
+    CK(hipMemset(demb, 0, (size_t)B * 2 * D * 4));
+    for (int variant = 0; variant < 2; ++variant) {
+      for (int it = 0; it < 55; ++it) {
+        if (it == 5) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
+        if (variant == 0) hcg_fused_layer_bwd(nullptr, demb, demb, dout, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 1, ddx, dstatus, dws, wsb, 0);
+        else hcg_fused_layer_bwd(dout, nullptr, nullptr, dout, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 1, nullptr, dstatus, dws, wsb, 0);
+      }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("bwd %s: %.2f us per launch\n", variant == 0 ? "layer2 (pooled grad + dx)" : "layer1 (dout, no dx)", ms * 1000.f / 50);
+    }
   }
 #ifndef HCG_STAMP
   return 0;
 #endif
   std::vector<unsigned long long> st(4 * WAVES * 64);
-  CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
   int status[4]; CK(hipMemcpy(status, dstatus, 16, hipMemcpyDeviceToHost)); printf("status %d\n", status[0]);
   const char* names[] = {"", "tile start", "loads+LDS write", "gemm", "h' write", "aggregate+store"};
   for (int w : {0, 1, 8, 9, 17}) {
