@@ -21,10 +21,11 @@ import torch.nn as nn
 
 
 class DataParallelGCN(nn.Module):
-    def __init__(self, module: nn.Module, process_group=None):
+    def __init__(self, module: nn.Module, process_group=None, force_collective: bool = False):
         super().__init__()
         self.module = module
         self.process_group = process_group
+        self.force_collective = force_collective   # run the collectives even at world size 1 (tests)
         self._params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self._numel = sum(p.numel() for p in self._params)
         self._flat: Optional[torch.Tensor] = None
@@ -51,7 +52,7 @@ class DataParallelGCN(nn.Module):
 
     def broadcast_parameters(self, src: int = 0):
         """Replicate rank-`src` weights (one flat broadcast)."""
-        if self.world_size() == 1:
+        if self.world_size() == 1 and not self.force_collective:
             return
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1) for p in self._params])
@@ -72,9 +73,9 @@ class DataParallelGCN(nn.Module):
         """All-reduce(sum) the flat gradient, divide by world size, re-attach the views as .grad."""
         flat = self.flat_gradient()
         ws = self.world_size()
-        if ws > 1:
+        if ws > 1 or self.force_collective:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
-            if average:
+            if average and ws > 1:
                 flat.div_(ws)
         off = 0
         for p in self._params:

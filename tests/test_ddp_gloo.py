@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: world_size-2 `gloo` run of the batch-of-graphs data-parallel wrapper
+(hcatgnet_amd/ddp.py).  Only the exchange logic runs here (flat gradient buffer all-reduce +
+parameter broadcast) -- no kernel is called; on the GPU box the same code runs over RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import hcatgnet_amd as H
+from hcatgnet_amd.ddp import DataParallelGCN
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = H.make_network("GCN", H.default_options(), 64)
+        if rank == 1:                                   # diverge rank 1 on purpose: the wrapper must re-sync
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        dp = DataParallelGCN(model)
+        ref = H.make_network("GCN", H.default_options(), 64)      # same seed -> rank 0's initial weights
+        same = all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))
+        # rank-dependent fake gradients: g_r = (r + 1) * (index pattern)
+        for i, p in enumerate(model.parameters()):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        flat = dp.reduce_gradients()
+        expect = torch.cat([torch.full((p.numel(),), 1.5 * (i + 1)) for i, p in enumerate(model.parameters())])
+        ok_flat = torch.allclose(flat, expect) and flat.numel() == 16641      # 4096+64+4096+64+8192+64+64+1
+        ok_views = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) and p.grad.data_ptr() != 0
+                       for i, p in enumerate(model.parameters()))
+        # the module surface the reference loops read is forwarded
+        ok_attrs = dp.optimizer is model.optimizer and dp.loss is model.loss and dp.scheduler is model.scheduler
+        # sum (not mean) mode
+        for i, p in enumerate(model.parameters()):
+            p.grad = torch.full_like(p, float(rank + 1))
+        s = dp.reduce_gradients(average=False)
+        ok_sum = torch.allclose(s, torch.full_like(s, 3.0))
+        q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_broadcast_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def test_single_process_wrapper_is_a_no_op_exchange():
+    model = H.make_network("GCN", H.default_options(), 25)
+    dp = DataParallelGCN(model)
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    flat = dp.reduce_gradients()
+    assert dp.world_size() == 1 and torch.equal(flat, torch.ones_like(flat))

@@ -433,3 +433,33 @@ def test_fused_readout_head(H, B, C):
     assert rel_inf(out, r) <= TOL
     for a, b in zip(dev, ref):
         assert rel_inf(a.grad, b.grad) <= TOL
+
+
+def test_rccl_gradient_allreduce_world1(H):
+    """The RCCL leg of the DP wrapper on the one GPU we have: backend "nccl" (= RCCL), world size 1,
+    collectives forced.  (Multi-rank RCCL only runs in the driver's multi-GPU tier; the multi-rank
+    logic is covered by tests/test_ddp_gloo.py.)"""
+    import socket
+    import torch.distributed as dist
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.ddp import DataParallelGCN
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        sb = synth.make_config("C2", num_graphs=64)
+        m = H.make_network("GCN", H.default_options(), 64).cuda()
+        dp = DataParallelGCN(m, force_collective=True)
+        batch = sb.as_batch("cuda")
+        out = dp(batch)
+        torch.sqrt(dp.loss(out, batch.y.unsqueeze(1))).backward()
+        before = [p.grad.clone() for p in m.parameters()]
+        flat = dp.reduce_gradients()
+        torch.cuda.synchronize()
+        assert flat.numel() == 16641
+        for p, g in zip(m.parameters(), before):
+            assert torch.equal(p.grad, g)
+        dp.optimizer.step()
+    finally:
+        dist.destroy_process_group()
