@@ -148,10 +148,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
     import hcatgnet_amd as H
     from hcatgnet_amd import _lib, algbytes, synth
     from hcatgnet_amd.ddp import DataParallelGCN
@@ -165,7 +161,7 @@ def main():
     N, E, B, F, D = x.shape[0], ei.shape[1], sb.num_graphs, cfg["feat"], cfg["hidden"]
     opt = H.default_options(embedding_dim=D)
     model = H.make_network("GCN", opt, F).to(dev)
-    dp = DataParallelGCN(model) if world > 1 else None
+    dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
     y2 = y.unsqueeze(1)
 
     def step(with_opt=False):
@@ -181,6 +177,7 @@ def main():
         return loss
 
     graph = None
+    static_grads = []
 
     def capture():
         """Capture plan build + forward + loss + backward (everything the library enqueues; no host
@@ -196,6 +193,8 @@ def main():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             step_body()
+        static_grads.clear()
+        static_grads.extend(p.grad for p in model.parameters())   # the tensors every replay rewrites
         return g
 
     def step_body():
@@ -209,21 +208,21 @@ def main():
     def graphed_step(with_opt=False):
         graph.replay()
         if dp is not None:
-            dp.reduce_gradients()
+            dp.reduce_gradients(grads=static_grads)
         if with_opt:
             model.optimizer.step()
 
     def timed(k, with_opt=False, use_graph=False):
         fn = graphed_step if use_graph else step
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
             fn(with_opt)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -236,7 +235,26 @@ def main():
         step()
     torch.cuda.synchronize()
     log("warm-up done")
-    # kernel-level roofline: HIP events around the dominant entry point, inside the timed region
+
+    launch_mode, graph_err = "eager", None
+    if not args.no_graph:
+        try:
+            graph = capture()
+            launch_mode = "hipgraph"
+            log("step captured into a hipGraph")
+        except Exception as exc:  # report, never hide: the eager number stands
+            graph, graph_err = None, f"{type(exc).__name__}: {exc}"
+            log(f"graph capture failed, keeping eager launches: {graph_err}")
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dp = DataParallelGCN(model)           # broadcasts rank-0 weights (in place: the graph sees them)
+        for _ in range(3):
+            step()
+        log(f"RCCL process group up: world {world}")
+
+    # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
     entry = args.roofline_entry or "hcg_fused_layer_bwd"
     timer = EntryTimer(lib, entry)
     timer.install()
@@ -245,24 +263,18 @@ def main():
     timer.enabled = False
     k_ms, k_calls = timer.mean_ms(args.steps)
     timer.uninstall()
-    # same loop without the event pairs (they cost a little): the number reported as `value`
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
     dt_eager = timed(args.steps)
     log(f"timed eager: {dt_eager / args.steps * 1e3:.3f} ms/step")
     dt_opt = timed(args.steps, with_opt=True)
     log(f"timed eager with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
-    launch_mode, dt_best, graph_err = "eager", dt_eager, None
-    if not args.no_graph:
-        try:
-            graph = capture()
-            for _ in range(max(3, args.warmup // 2)):
-                graphed_step()
-            dt_graph = timed(args.steps, use_graph=True)
-            log(f"timed hipGraph replay: {dt_graph / args.steps * 1e3:.3f} ms/step")
-            launch_mode, dt_best = "hipgraph", dt_graph
-        except Exception as exc:  # report, never hide: the eager number stands
-            graph_err = f"{type(exc).__name__}: {exc}"
-            log(f"graph capture failed, keeping eager timing: {graph_err}")
+    dt_best = dt_eager
+    if graph is not None:
+        for _ in range(max(3, args.warmup // 2)):
+            graphed_step()
+        dt_graph = timed(args.steps, use_graph=True)
+        log(f"timed hipGraph replay: {dt_graph / args.steps * 1e3:.3f} ms/step")
+        dt_best = dt_graph
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(bd.values())

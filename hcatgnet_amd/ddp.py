@@ -62,16 +62,20 @@ class DataParallelGCN(nn.Module):
                 p.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
 
-    def flat_gradient(self) -> torch.Tensor:
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
+    def flat_gradient(self, grads=None) -> torch.Tensor:
+        """`grads`: explicit gradient tensors in parameter order (e.g. the static tensors a captured
+        hipGraph writes into); default = each parameter's `.grad`."""
+        if grads is None:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
+        grads = [g.reshape(-1) for g in grads]
         if self._flat is None or self._flat.device != grads[0].device:
             self._flat = torch.empty(self._numel, dtype=torch.float32, device=grads[0].device)
         torch.cat(grads, out=self._flat)
         return self._flat
 
-    def reduce_gradients(self, average: bool = True) -> torch.Tensor:
+    def reduce_gradients(self, average: bool = True, grads=None) -> torch.Tensor:
         """All-reduce(sum) the flat gradient, divide by world size, re-attach the views as .grad."""
-        flat = self.flat_gradient()
+        flat = self.flat_gradient(grads)
         ws = self.world_size()
         if ws > 1 or self.force_collective:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
