@@ -285,6 +285,18 @@ def main():
                    "hcg_fused_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
                    "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0}.get(entry, float("nan"))
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950
+    # correction of MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only valid for the config they were taken on
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+    if cfg_name in ("C2", "C3", "C4") and args.num_graphs is None and os.path.isfile(tpath):
+        try:
+            tj = json.load(open(tpath))
+            prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd", "hcg_fused_layer_fwd": "k_fused_layer_fwd"}.get(entry)
+            vals = [v["hbm_bytes"] for k, v in tj.items() if prefix and k.startswith(prefix)]
+            traffic = sum(vals) / len(vals) if vals else None
+        except (OSError, ValueError, KeyError):
+            traffic = None
 
     if rank == 0:
         ms_step = dt_best / args.steps * 1e3
@@ -300,7 +312,7 @@ def main():
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": entry, "kernel_ms": k_ms, "kernel_launches_timed": k_calls,
                          "algorithmic_bytes_per_launch": entry_bytes},
             "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,

@@ -31,16 +31,25 @@
 // a buffer of their own; the product build compiles STAMP() to nothing and executes no stamp.
 #ifdef HCG_STAMP
 __device__ unsigned long long* g_stamp_buf = nullptr;
+// stamps are parked in LDS (no vector-memory op in the timed stream) and flushed by STAMP_FLUSH()
+#define STAMP_DECL __shared__ unsigned long long s_stamp[8][64];
 #define STAMP(idx)                                                                                          \
   do {                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     unsigned long long _t;                                                                                  \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (g_stamp_buf && (threadIdx.x & 63) == 0 && blockIdx.x < 4)                                           \
-      g_stamp_buf[((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 64 + (idx)] = _t;                     \
+    if ((threadIdx.x & 63) == 0) s_stamp[threadIdx.x >> 6][(idx)] = _t;                                      \
+  } while (0)
+#define STAMP_FLUSH()                                                                                       \
+  do {                                                                                                      \
+    if (g_stamp_buf && blockIdx.x < 4 && (threadIdx.x & 63) == 0)                                           \
+      for (int _i = 0; _i < 64; ++_i)                                                                       \
+        g_stamp_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + _i] = s_stamp[threadIdx.x >> 6][_i]; \
   } while (0)
 #else
+#define STAMP_DECL
+#define STAMP_FLUSH() do { } while (0)
 #define STAMP(idx) do { } while (0)
 #endif
 // tools/probe_fused.hip -DHCG_ABLATE=<bits> (timing-only diagnostic builds; results are wrong on purpose):
@@ -102,19 +111,19 @@ __device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const in
 // current one computes.
 struct TileEdges {
   long long es, ed;
-  int my_gp;
+  int gp_raw;
 
+  // Loads ONLY: no arithmetic on a loaded value and no branch in here -- either makes hipcc place an
+  // s_waitcnt vmcnt(0) right behind the loads, which turns the next-tile prefetch into a stall.
+  // (E >= 1 and `ei` readable are guaranteed by the host wrappers, also for edge-less batches.)
   __device__ __forceinline__ void load(const TileInfo& ti, const int32_t* __restrict__ graph_ptr,
                                        const int64_t* __restrict__ ei, int64_t E, int lane) {
     const int ng = ti.g1 - ti.g0;
-    my_gp = graph_ptr[ti.g0 + (lane <= ng ? lane : ng)] - ti.nbase;
-    es = 0;
-    ed = 0;
-    if (ti.ne > 0) {  // wave-uniform
-      const int64_t k = (int64_t)ti.ebase + (lane < ti.ne ? lane : ti.ne - 1);
-      es = ei[k];
-      ed = ei[E + k];
-    }
+    gp_raw = graph_ptr[ti.g0 + (lane <= ng ? lane : ng)];
+    int64_t k = (int64_t)ti.ebase + (lane < ti.ne ? lane : (ti.ne > 0 ? ti.ne - 1 : 0));
+    if (k > E - 1) k = E - 1;
+    es = ei[k];
+    ed = ei[E + k];
   }
 
   // C = I + sum_e [dst_e][src_e],  ldinv = (row sum)^-1/2 ; edges beyond the first 64 are read here
@@ -127,7 +136,7 @@ struct TileEdges {
     int* degc = reinterpret_cast<int*>(L.ldinv);
     if (lane < ti.n) L.cnt[lane * CS + lane] = 1;                       // self loop, weight 1
     const int ng = ti.g1 - ti.g0;
-    if (lane <= ng) L.lgp[lane] = my_gp;
+    if (lane <= ng) L.lgp[lane] = gp_raw - ti.nbase;
     for (int k0 = 0; k0 < ti.ne; k0 += 64) {
       long long s = es, d = ed;
       if (k0 > 0) {
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
     float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
   __shared__ WaveLds lds[WAVES];
+  STAMP_DECL
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveLds& L = lds[wave];
@@ -286,13 +296,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       for (int s = 0; s < KPAD / 2; ++s) wreg[nb][s] = wl[(nb * 32 + r) * (KPAD + 1) + 8 * (s >> 2) + 4 * h + (s & 3)];
     __syncthreads();
   }
-  const float b0 = bias[r], b1 = bias[32 + r];
+  float b0 = bias[r], b1 = bias[32 + r];
+  // retire the bias loads HERE: left pending, their first use (in the epilogue of the tile loop) makes
+  // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1));
   STAMP(0);
   int stamp_it = 0;
   if (have) {
     sx.write(L.buf, F, ti.n, lane);
     te.build(L, ti, ei, E, lane, status);
   }
+#ifdef HCG_STAGGER
+  // de-phase the two waves of each SIMD: the second-dispatched half starts its first MFMA phase later
+  if (wave >= WAVES / 2) {
+#pragma unroll
+    for (int z = 0; z < HCG_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   while (have) {
     STAMP(1 + 8 * stamp_it);
@@ -338,8 +358,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       y0 = acc0;
       y1 = acc1;
     }
+    STAMP(6 + 8 * stamp_it);
 
-    // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers
+    // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers.
+    //      The values go back through the (now dead) x tile so that the HBM stores are 8 row-contiguous
+    //      dwordx4 per lane instead of 64 exec-masked dword stores.
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = krow(i, h);
@@ -349,14 +372,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
       y0[i] = v0;
       y1[i] = v1;
-      if (!(HCG_ABLATE & 4)) {
-        if (row < ti.n) {
-          float* o = out + (size_t)(ti.nbase + row) * DD + r;
-          o[0] = v0;
-          o[32] = v1;
+      L.buf[row * HS + r] = v0;
+      L.buf[row * HS + 32 + r] = v1;
+    }
+    {
+      const int q = lane & 15, r4 = lane >> 4;
+#pragma unroll
+      for (int it = 0; it < TM / 4; ++it) {
+        const int row = it * 4 + r4;
+        const float4 v = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+        if (!(HCG_ABLATE & 4)) {
+          if (row < ti.n) *reinterpret_cast<float4*>(out + (size_t)(ti.nbase + row) * DD + 4 * q) = v;
+        } else if (v.x == 12345.678f) {
+          out[0] = v.y;
         }
-      } else if (v0 == 12345.678f) {
-        out[0] = v1;
       }
     }
     if (POOL) {
@@ -401,6 +430,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     }
   }
   STAMP(63);
+  STAMP_FLUSH();
 }
 
 // =====================================================================================================
@@ -571,14 +601,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
             dxa[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wlds[d * KPAD + nb * 32 + r], dxa[nb], 0, 0, 0);
         }
       }
+      if (VEC) {   // F == KPAD: rows are whole float4 groups -> transpose through LDS, dwordx4 stores
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = krow(i, h);
-        if (row < ti.n) {
+        for (int i = 0; i < 16; ++i)
 #pragma unroll
-          for (int nb = 0; nb < NBF; ++nb) {
-            const int f = nb * 32 + r;
-            if (f < F) dx[(size_t)(ti.nbase + row) * F + f] = dxa[nb][i];
+          for (int nb = 0; nb < NBF; ++nb) L.buf[krow(i, h) * HS + nb * 32 + r] = dxa[nb][i];
+#pragma unroll
+        for (int it = 0; it < TM / 4; ++it) {
+          const int row = it * 4 + r4;
+          if (4 * q < KPAD) {
+            const float4 v = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+            if (row < ti.n) *reinterpret_cast<float4*>(dx + (size_t)(ti.nbase + row) * F + 4 * q) = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = krow(i, h);
+          if (row < ti.n) {
+#pragma unroll
+            for (int nb = 0; nb < NBF; ++nb) {
+              const int f = nb * 32 + r;
+              if (f < F) dx[(size_t)(ti.nbase + row) * F + f] = dxa[nb][i];
+            }
           }
         }
       }
@@ -633,6 +678,7 @@ __global__ __launch_bounds__(256) void k_fused_reduce(const float* __restrict__ 
   const int idx = blockIdx.x * 16 + o;
   float s = 0.f;
   if (idx < slab_floats) {
+#pragma unroll 8
     for (int b = sl; b < nslabs; b += RED_SLICES) s += partials[(size_t)b * slab_floats + idx];
   }
   part[sl][o] = s;
@@ -690,6 +736,7 @@ extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* 
   const int grid = pick_grid(tiles);
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
+  if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no tile has edges
 #define LAUNCH_FWD(KP, VC, PL)                                                                                        \
   hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL>), g, blk, 0, stream, x, (int)F, W, b, edge_index, E, graph_ptr,   \
                      edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, emb, status)
@@ -727,6 +774,7 @@ extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const f
     const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
     const bool ndx = dx != nullptr;
     const dim3 g(grid), blk(WAVES * 64);
+    if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy
 #define LAUNCH_BWD(KP, VC, DX, PG)                                                                                   \
   hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG>), g, blk, 0, stream, dout, demb, emb, out, x, (int)F, W,     \
                      edge_index, E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, dx,     \

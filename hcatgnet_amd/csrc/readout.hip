@@ -24,14 +24,21 @@ struct RLds {
   float z[RT * ZS];
 };
 
-__device__ __forceinline__ void stage_emb(float* buf, const float* __restrict__ emb, int g0, int n, int lane) {
+// (loads are unconditional with a clamped row: a per-lane guard would serialise them, see fused.hip)
+__device__ __forceinline__ void stage_emb(float* buf, const float* __restrict__ emb, int g0, int n, int B, int lane) {
   const int q = lane & 31, r2 = lane >> 5;  // 32 lanes x 16 B = one 512-byte row
+  float4 v[RT / 2];
+#pragma unroll
+  for (int it = 0; it < RT / 2; ++it) {
+    int row = g0 + it * 2 + r2;
+    if (row > B - 1) row = B - 1;
+    v[it] = *reinterpret_cast<const float4*>(emb + (size_t)row * RK + 4 * q);
+  }
 #pragma unroll
   for (int it = 0; it < RT / 2; ++it) {
     const int row = it * 2 + r2;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < n) v = *reinterpret_cast<const float4*>(emb + (size_t)(g0 + row) * RK + 4 * q);
-    *reinterpret_cast<float4*>(buf + row * ES + 4 * q) = v;
+    if (row >= n) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(buf + row * ES + 4 * q) = v[it];
   }
 }
 
@@ -45,17 +52,26 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_fwd(const float* __r
   const int r = lane & 31, h = lane >> 5;
   const int tiles = (B + RT - 1) / RT;
 
-  float wreg[2][RK / 2];  // B[k][j] = W0[j][k]; k-step s = 4t+u <-> k = 8t + 4h + u
+  // W0 [64][128] -> LDS image [n][RK + 1] (coalesced, once per workgroup) -> 128 VGPRs per lane.
+  // B[k][j] = W0[j][k]; k-step s = 4t+u <-> k = 8t + 4h + u.  (As 128 strided global loads per lane this
+  // prologue was most of the kernel's 15 us.)
+  float wreg[2][RK / 2];
+  {
+    float* wl = reinterpret_cast<float*>(&lds[0]);   // 64 * 129 floats = 33 KB of the 100 KB block
+    for (int idx = threadIdx.x; idx < RD * RK; idx += RWAVES * 64) wl[(idx / RK) * (RK + 1) + (idx % RK)] = W0[idx];
+    __syncthreads();
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int s = 0; s < RK / 2; ++s) wreg[nb][s] = W0[(size_t)(nb * 32 + r) * RK + 8 * (s >> 2) + 4 * h + (s & 3)];
+      for (int s = 0; s < RK / 2; ++s) wreg[nb][s] = wl[(nb * 32 + r) * (RK + 1) + 8 * (s >> 2) + 4 * h + (s & 3)];
+    __syncthreads();
+  }
   const float bz0 = b0[r], bz1 = b0[32 + r];
 
   for (int t = blockIdx.x * RWAVES + wave; t < tiles; t += gridDim.x * RWAVES) {
     const int g0 = t * RT;
     const int n = B - g0 < RT ? B - g0 : RT;
-    stage_emb(L.e, emb, g0, n, lane);
+    stage_emb(L.e, emb, g0, n, B, lane);
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -106,11 +122,11 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_bwd(const float* __r
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   const int tiles = (B + RT - 1) / RT;
 
-  float wreg[4][RD / 2];  // demb operand: B[k = d][j] = W0[d][nb*32 + j]; k-step s <-> d = 8t + 4h + u
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int s = 0; s < RD / 2; ++s) wreg[nb][s] = W0[(size_t)(8 * (s >> 2) + 4 * h + (s & 3)) * RK + nb * 32 + r];
+  // demb operand: B[k = d][j] = W0[d][nb*32 + j] read from a workgroup-shared LDS copy of W0 (row-major,
+  // lanes read consecutive j: conflict-free); k-step s <-> d = 8t + 4h + u
+  __shared__ float w0s[RD * RK];
+  for (int idx = threadIdx.x; idx < RD * RK; idx += RWAVES * 64) w0s[idx] = W0[idx];
+  __syncthreads();
 
   f32x16 dw0[2][4];
 #pragma unroll
@@ -129,17 +145,31 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_bwd(const float* __r
     const int g0 = t * RT;
     const int n = B - g0 < RT ? B - g0 : RT;
     // 1. dz = (dout W1) * leaky'(z)  -> L.z  ; db0, dW1, db1 partial sums
+    //    (all loads first, unconditional with clamped rows; W1 rows are loop invariants)
+    float4 zr[RT / 4];
+    float gor[RT / 4][RCMAX];
+#pragma unroll
+    for (int it = 0; it < RT / 4; ++it) {
+      int row = g0 + it * 4 + r4;
+      if (row > B - 1) row = B - 1;
+      zr[it] = *reinterpret_cast<const float4*>(z + (size_t)row * RD + 4 * q);
+#pragma unroll
+      for (int c = 0; c < RCMAX; ++c) gor[it][c] = dout[(size_t)row * C + (c < C ? c : C - 1)];
+    }
+    float4 w1r[RCMAX];
+#pragma unroll
+    for (int c = 0; c < RCMAX; ++c) w1r[c] = *reinterpret_cast<const float4*>(W1 + (c < C ? c : C - 1) * RD + 4 * q);
 #pragma unroll
     for (int it = 0; it < RT / 4; ++it) {
       const int row = it * 4 + r4;
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < n) {
-        const float4 zz = *reinterpret_cast<const float4*>(z + (size_t)(g0 + row) * RD + 4 * q);
+        const float4 zz = zr[it];
 #pragma unroll
         for (int c = 0; c < RCMAX; ++c) {
           if (c < C) {
-            const float go = dout[(size_t)(g0 + row) * C + c];
-            const float4 w = *reinterpret_cast<const float4*>(W1 + c * RD + 4 * q);
+            const float go = gor[it][c];
+            const float4 w = w1r[c];
             d.x += go * w.x; d.y += go * w.y; d.z += go * w.z; d.w += go * w.w;
             dw1[c].x += go * zz.x; dw1[c].y += go * zz.y; dw1[c].z += go * zz.z; dw1[c].w += go * zz.w;
             if (q == 0) db1[c] += go;
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_bwd(const float* __r
       *reinterpret_cast<float4*>(L.z + row * ZS + 4 * q) = d;
     }
     // 2. emb tile (rows >= n zero)
-    stage_emb(L.e, emb, g0, n, lane);
+    stage_emb(L.e, emb, g0, n, B, lane);
     // 3. dW0 += dz^T emb   (K = graph rows)
 #pragma unroll
     for (int s = 0; s < RT / 2; ++s) {
@@ -174,12 +204,13 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_bwd(const float* __r
 #pragma unroll
     for (int t8 = 0; t8 < RD / 8; ++t8) {
       const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * t8 + 4 * h);
+      const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        de[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wreg[nb][4 * t8 + 0], de[nb], 0, 0, 0);
-        de[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wreg[nb][4 * t8 + 1], de[nb], 0, 0, 0);
-        de[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wreg[nb][4 * t8 + 2], de[nb], 0, 0, 0);
-        de[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wreg[nb][4 * t8 + 3], de[nb], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        const int d = 8 * t8 + 4 * h + u;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          de[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], w0s[d * RK + nb * 32 + r], de[nb], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -228,8 +259,10 @@ __global__ __launch_bounds__(256) void k_readout_reduce(const float* __restrict_
   const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + o;
   float s = 0.f;
-  if (idx < SLAB)
+  if (idx < SLAB) {
+#pragma unroll 8
     for (int b = sl; b < nslabs; b += RR_SLICES) s += slabs[(size_t)b * SLAB + idx];
+  }
   part[sl][o] = s;
   __syncthreads();
   if (sl == 0 && idx < SLAB) {

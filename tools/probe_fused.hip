@@ -75,14 +75,19 @@ int main() {
   std::vector<unsigned long long> st(4 * WAVES * 64);
   CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
   int status[4]; CK(hipMemcpy(status, dstatus, 16, hipMemcpyDeviceToHost)); printf("status %d\n", status[0]);
-  const char* names[] = {"", "tile start", "loads+LDS write", "gemm", "h' write", "aggregate+store"};
+  const char* names[] = {"", "tile start", "prefetch-issue", "gemm", "scale", "epilogue+store+nextstage", "agg-mfma"};
   for (int w : {0, 1, 8, 9, 17}) {
     unsigned long long* s = &st[(size_t)w * 64];
-    printf("wave %2d: prologue(W load) %llu cyc | ", w, s[1] - s[0]);
+    printf("wave %2d: first-stage %llu | ", w, s[1] - s[0]);
     for (int it = 0; it < 3; ++it) {
       if (!s[1 + 8 * it]) break;
       printf("tile%d:", it);
-      for (int k = 2; k <= 5; ++k) printf(" %s %llu", names[k], s[k + 8 * it] - s[k - 1 + 8 * it]);
+      printf(" %s %llu", names[2], s[2 + 8 * it] - s[1 + 8 * it]);
+      printf(" %s %llu", names[3], s[3 + 8 * it] - s[2 + 8 * it]);
+      printf(" %s %llu", names[4], s[4 + 8 * it] - s[3 + 8 * it]);
+      printf(" %s %llu", names[6], s[6 + 8 * it] - s[4 + 8 * it]);
+      printf(" epilogue+stores %llu", s[5 + 8 * it] - s[6 + 8 * it]);
+      if (s[1 + 8 * (it + 1)]) printf(" stage-next %llu", s[1 + 8 * (it + 1)] - s[5 + 8 * it]);
       printf(" | ");
     }
     printf("total %llu cyc\n", s[63] - s[0]);
