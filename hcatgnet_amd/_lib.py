@@ -40,6 +40,8 @@ SIGNATURES = {
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
     "hcg_fused_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
     "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
+    "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
+    "hcg_mse_bwd": (INT, [P, P, P, I64, P, P, P]),
     "hcg_readout2_supported": (INT, [I64, I64]),
     "hcg_readout2_workspace_bytes": (SZ, [I64]),
     "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),

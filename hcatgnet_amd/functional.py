@@ -252,6 +252,39 @@ class _Readout2Fn(torch.autograd.Function):
         return demb, dW0, db0, dW1, db1, None
 
 
+class _MSEFn(torch.autograd.Function):
+    """mean((input - target)^2) in one launch each way (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, inp, target):
+        lib = _lib.load()
+        _lib.require_gpu(inp, target)
+        if inp.shape != target.shape:
+            raise ValueError(f"MSELoss: input {tuple(inp.shape)} and target {tuple(target.shape)} must have the same shape")
+        a, b = _f32c(inp), _f32c(target)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        _lib.check(lib.hcg_mse_fwd(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(loss), _lib.stream_ptr()), "hcg_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        g = _f32c(g)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is None and db is None:
+            return None, None
+        _lib.check(lib.hcg_mse_bwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(g), a.numel(), _lib.ptr(da), _lib.ptr(db),
+                                   _lib.stream_ptr()), "hcg_mse_bwd")
+        return da, db
+
+
+def mse_loss(inp, target):
+    return _MSEFn.apply(inp, target)
+
+
 def readout2_supported(D: int, C: int) -> bool:
     return bool(_lib.load().hcg_readout2_supported(D, C))
 

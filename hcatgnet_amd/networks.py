@@ -12,6 +12,16 @@ import torch
 import torch.nn as nn
 
 
+class MSELoss(nn.Module):
+    """`nn.MSELoss()` (mean reduction) with the reference's call contract `loss(out, y.unsqueeze(1))`
+    (utils/utils_model.py:64); on MI355X tensors it is one HIP launch each way (csrc/loss.hip) instead
+    of torch's elementwise + reduction chain.  Same-shape float32 inputs only."""
+
+    def forward(self, inp, target):
+        from . import functional as HF
+        return HF.mse_loss(inp, target)
+
+
 class BaseNetwork(nn.Module):
     def __init__(self, opt: argparse.Namespace, n_node_features: int):
         super().__init__()
@@ -35,7 +45,7 @@ class BaseNetwork(nn.Module):
         if problem_type == "classification":
             self.loss = nn.CrossEntropyLoss()
         elif problem_type == "regression" and mae is None:
-            self.loss = nn.MSELoss()
+            self.loss = MSELoss()
         else:
             raise ValueError(f"Problem type {problem_type} not supported")
 

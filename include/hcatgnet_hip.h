@@ -175,6 +175,12 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
                      float* demb, float* dW0, float* db0, float* dW1, float* db1,
                      void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
+/* ---- MSE loss (a12 / f2): loss[0] = mean((a - b)^2) over n elements, fixed-order reduction;
+ *      backward: da = grad_loss[0] * 2 (a - b) / n, db = -da (either may be NULL). */
+int hcg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, hcg_stream_t stream);
+int hcg_mse_bwd(const float* a, const float* b, const float* grad_loss, int64_t n,
+                float* da /*nullable*/, float* db /*nullable*/, hcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

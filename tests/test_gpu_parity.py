@@ -463,3 +463,20 @@ def test_rccl_gradient_allreduce_world1(H):
         dp.optimizer.step()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_fused_mse_loss(H, n):
+    """hcatgnet_amd.networks.MSELoss == nn.MSELoss() (mean), value and both gradients."""
+    from hcatgnet_amd.networks import MSELoss
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n, 1, generator=g); b = torch.randn(n, 1, generator=g) * 3
+    ad, bd = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    loss = torch.sqrt(MSELoss()(ad, bd))
+    loss.backward()
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.sqrt(torch.nn.MSELoss()(ar, br))
+    ref.backward()
+    assert rel_inf(loss, ref) <= TOL and rel_inf(ad.grad, ar.grad) <= TOL and rel_inf(bd.grad, br.grad) <= TOL
+    with pytest.raises(ValueError):
+        MSELoss()(ad, bd.reshape(-1))

@@ -48,7 +48,7 @@ def test_cpu_tensors_fail_loudly_no_fallback():
 def test_module_surface_matches_reference_contract():
     opt = H.default_options()
     m = H.make_network("GCN", opt, 25)
-    assert m.name == "GCN" and isinstance(m.loss, torch.nn.MSELoss)
+    assert m.name == "GCN" and type(m.loss).__name__ == "MSELoss"
     assert isinstance(m.optimizer, torch.optim.Adam) and m.optimizer.defaults["eps"] == 1e-9 and m.optimizer.defaults["lr"] == 0.01
     assert isinstance(m.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau)
     keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
