@@ -87,16 +87,32 @@ struct TileInfo {
   int g0, g1, nbase, n, ebase, ne;
 };
 
-__device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const int32_t* __restrict__ graph_ptr,
-                                                 const int32_t* __restrict__ edge_ptr, int lane, int32_t* status) {
+struct TileRaw { int g0, g1, p0, p1, e0, e1; };   // the four loaded words, before any arithmetic
+
+// loads only (scalar: `t` is wave-uniform) -- kept apart from tile_finish() so that the scalars of the tile
+// AFTER the next one can be in flight for a whole tile: as a load-then-use sequence in front of the
+// prefetch they cost ~4.5k cycles per tile (scalar-cache misses while every wave of the chip asks at once)
+__device__ __forceinline__ TileRaw tile_raw(int t, int num_tiles, int gpt, int B, const int32_t* __restrict__ graph_ptr,
+                                            const int32_t* __restrict__ edge_ptr) {
+  TileRaw w;
+  t = __builtin_amdgcn_readfirstlane(t < num_tiles ? t : num_tiles - 1);
+  w.g0 = t * gpt;
+  w.g1 = w.g0 + gpt < B ? w.g0 + gpt : B;
+  w.p0 = graph_ptr[w.g0];
+  w.p1 = graph_ptr[w.g1];
+  w.e0 = edge_ptr[w.g0];
+  w.e1 = edge_ptr[w.g1];
+  return w;
+}
+
+__device__ __forceinline__ TileInfo tile_finish(const TileRaw& w, int gpt, int lane, int32_t* status) {
   TileInfo ti;
-  t = __builtin_amdgcn_readfirstlane(t);   // wave-uniform by construction: lets the four loads be scalar (s_load)
-  ti.g0 = t * gpt;
-  ti.g1 = ti.g0 + gpt < B ? ti.g0 + gpt : B;
-  ti.nbase = graph_ptr[ti.g0];
-  ti.n = graph_ptr[ti.g1] - ti.nbase;
-  ti.ebase = edge_ptr[ti.g0];
-  ti.ne = edge_ptr[ti.g1] - ti.ebase;
+  ti.g0 = w.g0;
+  ti.g1 = w.g1;
+  ti.nbase = w.p0;
+  ti.n = w.p1 - w.p0;
+  ti.ebase = w.e0;
+  ti.ne = w.e1 - w.e0;
   if (ti.n > TM || ti.n < 0 || ti.ne < 0 || gpt > TM) {  // host metadata was wrong: refuse the tile
     if (lane == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
     ti.n = 0;
@@ -104,6 +120,11 @@ __device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const in
     ti.g1 = ti.g0;
   }
   return ti;
+}
+
+__device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const int32_t* __restrict__ graph_ptr,
+                                                 const int32_t* __restrict__ edge_ptr, int lane, int32_t* status) {
+  return tile_finish(tile_raw(t, t + 1, gpt, B, graph_ptr, edge_ptr), gpt, lane, status);
 }
 
 // per-lane index data of a tile (first 64 edges + graph offsets), loaded into registers by load() and
@@ -139,19 +160,22 @@ struct TileEdges {
     if (lane <= ng) L.lgp[lane] = gp_raw - ti.nbase;
     for (int k0 = 0; k0 < ti.ne; k0 += 64) {
       long long s = es, d = ed;
-      if (k0 > 0) {
-        const int64_t k = (int64_t)ti.ebase + (k0 + lane < ti.ne ? k0 + lane : ti.ne - 1);
+      if (k0 > 0) {   // wave-uniform: only tiles with more than 64 edges come here
+        int64_t k = (int64_t)ti.ebase + (k0 + lane < ti.ne ? k0 + lane : ti.ne - 1);
+        if (k > E - 1) k = E - 1;
         s = ei[k];
         d = ei[E + k];
       }
-      if (k0 + lane < ti.ne) {
-        const long long sl = s - ti.nbase, dl = d - ti.nbase;
-        if (sl < 0 || sl >= ti.n || dl < 0 || dl >= ti.n) {
-          atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);                  // edge leaves its graph: ignored, flagged
-        } else {
-          atomicAdd(&L.cnt[(int)dl * CS + (int)sl], 1);                 // ds_add_u32: exact, order-independent
-          atomicAdd(&degc[(int)dl], 1);
-        }
+      // local ids in 32 bits; one unsigned compare each covers "< 0" and ">= n" (ids are < 2^31)
+      const unsigned sl = (unsigned)((int)s - ti.nbase), dl = (unsigned)((int)d - ti.nbase);
+      const bool live = k0 + lane < ti.ne;
+      const bool ok = sl < (unsigned)ti.n && dl < (unsigned)ti.n && (s >> 31) == 0 && (d >> 31) == 0;
+      if (live && ok) {
+        atomicAdd(&L.cnt[dl * CS + sl], 1);                             // ds_add_u32: exact, order-independent
+        atomicAdd(&degc[dl], 1);
+      }
+      if (__ballot(live && !ok) != 0ull) {                              // edge leaves its graph: ignored, flagged
+        if (lane == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);
       }
     }
     if (lane < TM) {
@@ -276,8 +300,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   TileInfo ti;
   TileEdges te;
   Stager<KPAD, VEC> sx;
+  TileRaw raw_next;   // scalars of the tile after the current one, always one tile ahead
   if (have) {
-    ti = tile_scalars(t, gpt, B, graph_ptr, edge_ptr, lane, status);
+    const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    ti = tile_finish(raw0, gpt, lane, status);
     sx.load(x, F, N, ti.nbase, ti.n, lane);
     te.load(ti, graph_ptr, ei, E, lane);
   }
@@ -306,13 +333,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     sx.write(L.buf, F, ti.n, lane);
     te.build(L, ti, ei, E, lane, status);
   }
-#ifdef HCG_STAGGER
-  // de-phase the two waves of each SIMD: the second-dispatched half starts its first MFMA phase later
-  if (wave >= WAVES / 2) {
-#pragma unroll
-    for (int z = 0; z < HCG_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
-  }
+#ifndef HCG_PRIO
+#define HCG_PRIO 0
 #endif
+  // experiment knob (tools/probe_fused.hip): static issue priority for one of the two waves of each SIMD
+  if (HCG_PRIO == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+  if (HCG_PRIO == 2 && wave < WAVES / 2) __builtin_amdgcn_s_setprio(1);
+  if (HCG_PRIO == 3 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(3);
 
   while (have) {
     STAMP(1 + 8 * stamp_it);
@@ -322,8 +349,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     TileInfo tin;
     TileEdges ten;
     Stager<KPAD, VEC> sxn;
+    const TileRaw raw_cur = raw_next;                                    // loaded one tile ago
+    raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // consumed one tile from now
     if (VEC && have_next) {   // (the scalar-staging variants are short of registers: they load after the compute)
-      tin = tile_scalars(tn, gpt, B, graph_ptr, edge_ptr, lane, status);
+      tin = tile_finish(raw_cur, gpt, lane, status);
       sxn.load(x, F, N, tin.nbase, tin.n, lane);
       ten.load(tin, graph_ptr, ei, E, lane);
     }
@@ -337,22 +366,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     STAMP(3 + 8 * stamp_it);
 
     // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H'
+    // dinv of this lane's 16 accumulator rows: read ONCE into registers (re-reading them in the
+    // epilogue cost 16 serialized LDS round trips: the compiler cannot prove the tile stores don't alias)
+    float dvr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
     f32x16 y0, y1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float dv = L.ldinv[krow(i, h)];
-      acc0[i] *= dv;
-      acc1[i] *= dv;
+      acc0[i] *= dvr[i];
+      acc1[i] *= dvr[i];
       y0[i] = 0.f;
       y1[i] = 0.f;
     }
     STAMP(4 + 8 * stamp_it);
     if (!(HCG_ABLATE & 2)) {
+      float av[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float a = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)]; B[k][j] = acc[i]
-        y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc0[i], y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[i], y1, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) av[i] = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)]
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                                            // B[k][j] = acc[i]
+        y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc0[i], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc1[i], y1, 0, 0, 0);
       }
     } else {
       y0 = acc0;
@@ -366,8 +401,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = krow(i, h);
-      const float dv = L.ldinv[row];
-      float v0 = fmaf(y0[i], dv, b0), v1 = fmaf(y1[i], dv, b1);
+      float v0 = fmaf(y0[i], dvr[i], b0), v1 = fmaf(y1[i], dvr[i], b1);
       // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes)
       if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
       y0[i] = v0;
@@ -375,16 +409,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       L.buf[row * HS + r] = v0;
       L.buf[row * HS + 32 + r] = v1;
     }
-    {
+    STAMP(7 + 8 * stamp_it);
+    if (ti.n > 0) {   // wave-uniform
+      // rows >= n are redirected to row n-1 (read AND write): duplicate identical stores instead of a
+      // per-lane branch around every store -> all 8 LDS reads and 8 stores stay in one basic block
       const int q = lane & 15, r4 = lane >> 4;
+      float4 ov[TM / 4];
 #pragma unroll
       for (int it = 0; it < TM / 4; ++it) {
-        const int row = it * 4 + r4;
-        const float4 v = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+        const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
+        ov[it] = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+      }
+#pragma unroll
+      for (int it = 0; it < TM / 4; ++it) {
+        const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
         if (!(HCG_ABLATE & 4)) {
-          if (row < ti.n) *reinterpret_cast<float4*>(out + (size_t)(ti.nbase + row) * DD + 4 * q) = v;
-        } else if (v.x == 12345.678f) {
-          out[0] = v.y;
+          *reinterpret_cast<float4*>(out + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
+        } else if (ov[it].x == 12345.678f) {
+          out[0] = ov[it].y;
         }
       }
     }
@@ -419,14 +461,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     have = have_next;
     if (have_next) {
       if (!VEC) {
-        tin = tile_scalars(tn, gpt, B, graph_ptr, edge_ptr, lane, status);
+        tin = tile_finish(raw_cur, gpt, lane, status);
         sxn.load(x, F, N, tin.nbase, tin.n, lane);
         ten.load(tin, graph_ptr, ei, E, lane);
       }
       t = tn;
       ti = tin;
+      STAMP(56);
       sxn.write(L.buf, F, ti.n, lane);
+      STAMP(57);
       ten.build(L, ti, ei, E, lane, status);
+      STAMP(58);
     }
   }
   STAMP(63);
@@ -469,8 +514,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int i = 0; i < 16; ++i) dw[mb][nb][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  TileRaw raw_next = tile_raw(blockIdx.x * WAVES + wave, num_tiles, gpt, B, graph_ptr, edge_ptr);
   for (int t = blockIdx.x * WAVES + wave; t < num_tiles; t += stride) {
-    const TileInfo ti = tile_scalars(t, gpt, B, graph_ptr, edge_ptr, lane, status);
+    const TileInfo ti = tile_finish(raw_next, gpt, lane, status);
+    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // scalars one tile ahead
     // the global reads of step 1 go in flight together: A rows, dA rows, edges
     Stager<DD, true> sa;
     sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
@@ -554,11 +601,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + r], dh0, 0, 0, 0);
       dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + 32 + r], dh1, 0, 0, 0);
     }
+    {
+      float dvr[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float dv = L.ldinv[krow(i, h)];
-      dh0[i] *= dv;
-      dh1[i] *= dv;
+      for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dh0[i] *= dvr[i]; dh1[i] *= dvr[i]; }
     }
 
     // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (k-step i <-> node krow(i, h))
@@ -606,12 +654,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         for (int i = 0; i < 16; ++i)
 #pragma unroll
           for (int nb = 0; nb < NBF; ++nb) L.buf[krow(i, h) * HS + nb * 32 + r] = dxa[nb][i];
+        if (ti.n > 0) {   // rows >= n redirected to row n-1 (duplicate identical stores, no per-lane branch)
+          const int qc = 4 * q < KPAD ? q : 0;
+          float4 ov[TM / 4];
 #pragma unroll
-        for (int it = 0; it < TM / 4; ++it) {
-          const int row = it * 4 + r4;
-          if (4 * q < KPAD) {
-            const float4 v = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
-            if (row < ti.n) *reinterpret_cast<float4*>(dx + (size_t)(ti.nbase + row) * F + 4 * q) = v;
+          for (int it = 0; it < TM / 4; ++it) {
+            const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
+            ov[it] = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * qc);
+          }
+#pragma unroll
+          for (int it = 0; it < TM / 4; ++it) {
+            const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
+            *reinterpret_cast<float4*>(dx + (size_t)(ti.nbase + row) * F + 4 * qc) = ov[it];
           }
         }
       } else {

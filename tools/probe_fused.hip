@@ -86,11 +86,11 @@ int main() {
       printf(" %s %llu", names[3], s[3 + 8 * it] - s[2 + 8 * it]);
       printf(" %s %llu", names[4], s[4 + 8 * it] - s[3 + 8 * it]);
       printf(" %s %llu", names[6], s[6 + 8 * it] - s[4 + 8 * it]);
-      printf(" epilogue+stores %llu", s[5 + 8 * it] - s[6 + 8 * it]);
+      printf(" epi-LDSwrite %llu readback+stores %llu", s[7 + 8 * it] - s[6 + 8 * it], s[5 + 8 * it] - s[7 + 8 * it]);
       if (s[1 + 8 * (it + 1)]) printf(" stage-next %llu", s[1 + 8 * (it + 1)] - s[5 + 8 * it]);
       printf(" | ");
     }
-    printf("total %llu cyc\n", s[63] - s[0]);
+    printf("total %llu cyc | last stage-next: wait+xwrite %llu build %llu (of it: before %llu)\n", s[63] - s[0], s[57] - s[56], s[58] - s[57], s[56] - s[5]);
   }
   return 0;
 }
