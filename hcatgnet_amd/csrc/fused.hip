@@ -333,14 +333,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     sx.write(L.buf, F, ti.n, lane);
     te.build(L, ti, ei, E, lane, status);
   }
-#ifndef HCG_PRIO
-#define HCG_PRIO 0
-#endif
-  // experiment knob (tools/probe_fused.hip): static issue priority for one of the two waves of each SIMD
-  if (HCG_PRIO == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
-  if (HCG_PRIO == 2 && wave < WAVES / 2) __builtin_amdgcn_s_setprio(1);
-  if (HCG_PRIO == 3 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(3);
-
   while (have) {
     STAMP(1 + 8 * stamp_it);
     // prefetch the next tile of this wave (registers only) while this one computes

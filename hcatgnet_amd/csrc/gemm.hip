@@ -91,34 +91,51 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int64
   }
 }
 
+// C[i] = sum_z partials[z][i]: 64 outputs x 4 split-lanes per block, lanes combined in a fixed order
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partials, float* __restrict__ C,
                                                        int64_t MN, int64_t N, int splits,
                                                        const float* __restrict__ bias, int act, float slope) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= MN) return;
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += partials[(size_t)z * MN + i];  // fixed order: deterministic
-  if (bias) s += bias[i % N];
-  if (act) s = hcg_leaky(s, slope);
-  C[i] = s;
+  if (i < MN) {
+#pragma unroll 4
+    for (int z = sl; z < splits; z += 4) s += partials[(size_t)z * MN + i];
+  }
+  part[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && i < MN) {
+    float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    if (bias) t += bias[i % N];
+    if (act) t = hcg_leaky(t, slope);
+    C[i] = t;
+  }
 }
 
-constexpr int CS_ROWS = 128;
+constexpr int CS_MAX_PARTS = 128;   // partial rows after stage 1
 
-// partial[b][d] = sum over rows [b*CS_ROWS, ...) of src[m][d] * (mask ? leaky'(mask[m][d]) : 1)
+// partial[b][d] = sum over the row chunk of block b of src[m][d] * (mask ? leaky'(mask[m][d]) : 1);
+// 64 feature lanes x 4 row lanes per block, the 4 row lanes combined in a fixed order
 __global__ __launch_bounds__(256) void k_colsum_stage1(const float* __restrict__ src, const float* __restrict__ mask,
-                                                       float slope, float* __restrict__ partial, int64_t M, int64_t D) {
-  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  const int64_t mbeg = (int64_t)blockIdx.y * CS_ROWS;
-  const int64_t mend = mbeg + CS_ROWS < M ? mbeg + CS_ROWS : M;
+                                                       float slope, float* __restrict__ partial, int64_t M, int64_t D,
+                                                       int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t d = (int64_t)blockIdx.x * 64 + fl;
+  const int64_t mbeg = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   float s = 0.f;
-  for (int64_t m = mbeg; m < mend; ++m) {
-    float v = src[m * D + d];
-    if (mask) v *= hcg_leaky_grad(mask[m * D + d], slope);
-    s += v;
+  if (d < D) {
+    for (int64_t m = mbeg + rl; m < mend; m += 4) {
+      float v = src[m * D + d];
+      if (mask) v *= hcg_leaky_grad(mask[m * D + d], slope);
+      s += v;
+    }
   }
-  partial[(size_t)blockIdx.y * D + d] = s;
+  part[rl][fl] = s;
+  __syncthreads();
+  if (rl == 0 && d < D) partial[(size_t)blockIdx.y * D + d] = ((part[0][fl] + part[1][fl]) + part[2][fl]) + part[3][fl];
 }
 
 __global__ __launch_bounds__(256) void k_colsum_stage2(const float* __restrict__ partial, float* __restrict__ out,
@@ -136,8 +153,8 @@ size_t hcg_gemm_partial_floats(int64_t M, int64_t N, int64_t K, int* splits_out)
   const int64_t tiles = hcg_cdiv(M, BM) * hcg_cdiv(N, BN);
   int64_t splits = 1;
   if (tiles < 256 && K >= 2048) {
-    splits = 1024 / tiles;
-    const int64_t max_splits = hcg_cdiv(K, 256);
+    splits = 512 / tiles;   // ~2 workgroups per CU; more splits only lengthen the reduction
+    const int64_t max_splits = hcg_cdiv(K, 512);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
@@ -150,7 +167,7 @@ int hcg_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
              size_t partial_floats, hipStream_t stream) {
   if (M <= 0 || N <= 0) return HCG_OK;
   if (K <= 0) {  // empty contraction: C = act(bias)
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 64)), dim3(256), 0, stream,
                        (const float*)nullptr, C, M * N, N, 0, bias, act, slope);
     HCG_CHECK_LAUNCH();
     return HCG_OK;
@@ -166,25 +183,28 @@ int hcg_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
                      slope, splits > 1 ? partials : (float*)nullptr);
   HCG_CHECK_LAUNCH();
   if (splits > 1) {
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)hcg_cdiv(M * N, 64)), dim3(256), 0, stream,
                        (const float*)partials, C, M * N, N, splits, bias, act, slope);
     HCG_CHECK_LAUNCH();
   }
   return HCG_OK;
 }
 
-size_t hcg_colsum_partial_floats(int64_t M, int64_t D) { return (size_t)hcg_cdiv(M > 0 ? M : 1, CS_ROWS) * D; }
+static int64_t colsum_parts(int64_t M) {
+  int64_t nb = hcg_cdiv(M > 0 ? M : 1, 256);
+  return nb > CS_MAX_PARTS ? CS_MAX_PARTS : nb;
+}
 
-// masked variant is reached through hcg_colsum_masked (declared below for layer.hip)
+size_t hcg_colsum_partial_floats(int64_t M, int64_t D) { return (size_t)colsum_parts(M) * D; }
+
+// masked variant is reached through hcg_colsum_masked (declared in layer.hip)
 int hcg_colsum_masked(const float* src, const float* mask, float slope, float* out, int64_t M, int64_t D,
                       float* partials, hipStream_t stream) {
   if (D <= 0) return HCG_OK;
-  const int64_t nb = hcg_cdiv(M > 0 ? M : 1, CS_ROWS);
-  if (nb > 65535) {
-    return HCG_ERR_UNSUPPORTED;
-  }
-  dim3 g1((unsigned)hcg_cdiv(D, 256), (unsigned)nb);
-  hipLaunchKernelGGL(k_colsum_stage1, g1, dim3(256), 0, stream, src, mask, slope, partials, M, D);
+  const int64_t nb = colsum_parts(M);
+  const int64_t rows_per_block = hcg_cdiv(M > 0 ? M : 1, nb);
+  dim3 g1((unsigned)hcg_cdiv(D, 64), (unsigned)nb);
+  hipLaunchKernelGGL(k_colsum_stage1, g1, dim3(256), 0, stream, src, mask, slope, partials, M, D, rows_per_block);
   HCG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_colsum_stage2, dim3((unsigned)hcg_cdiv(D, 256)), dim3(256), 0, stream,
                      (const float*)partials, out, nb, D);
