@@ -293,6 +293,101 @@ def readout2(emb, W0, b0, W1, b1, slope=LEAKY_SLOPE):
     return _Readout2Fn.apply(emb, W0, b0, W1, b1, slope)
 
 
+class _FusedModelFn(torch.autograd.Function):
+    """The whole small-graph model -- every fused conv layer (the last one with its pooling
+    epilogue) and the fused readout head -- as ONE autograd node.  Same kernels as the per-layer
+    Functions; what it removes is host time: one `apply`, one backward callback and one set of
+    allocations instead of four (the eager step is host-bound: ~0.1 ms of autograd/ctypes per node)."""
+
+    @staticmethod
+    def forward(ctx, plan: BatchPlan, gpts, slope: float, x, *params):
+        lib = _lib.load()
+        _lib.require_gpu(x, *params)
+        x = _f32c(x)
+        params = [_f32c(p) for p in params]
+        n_conv = len(gpts)
+        convs, (R0w, R0b, R1w, R1b) = params[:2 * n_conv], params[2 * n_conv:]
+        N, dev, stream = x.shape[0], x.device, _lib.stream_ptr()
+        if N != plan.N:
+            raise ValueError(f"x has {N} rows, plan was built for {plan.N}")
+        D = convs[0].shape[0]
+        acts, h = [], x
+        emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev)
+        for l in range(n_conv):
+            W, b = convs[2 * l], convs[2 * l + 1]
+            out = torch.empty(N, D, dtype=torch.float32, device=dev)
+            rc = lib.hcg_fused_layer_fwd(_lib.ptr(h), _lib.ptr(W), _lib.ptr(b), _lib.ptr(plan.edge_index), plan.E,
+                                         _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, h.shape[1], D,
+                                         gpts[l], slope, 1, _lib.ptr(out), _lib.ptr(emb) if l == n_conv - 1 else None,
+                                         _lib.ptr(plan.status), stream)
+            _lib.check(rc, "hcg_fused_layer_fwd")
+            acts.append(out)
+            h = out
+        C = R1w.shape[0]
+        z = torch.empty(plan.B, D, dtype=torch.float32, device=dev)
+        y = torch.empty(plan.B, C, dtype=torch.float32, device=dev)
+        rc = lib.hcg_readout2_fwd(_lib.ptr(emb), _lib.ptr(R0w), _lib.ptr(R0b), _lib.ptr(R1w), _lib.ptr(R1b), plan.B, D, C,
+                                  slope, _lib.ptr(z), _lib.ptr(y), stream)
+        _lib.check(rc, "hcg_readout2_fwd")
+        ctx.save_for_backward(x, emb, z, *acts, *params)
+        ctx.plan, ctx.gpts, ctx.slope, ctx.n_conv = plan, list(gpts), slope, n_conv
+        return y, emb
+
+    @staticmethod
+    def backward(ctx, dy, demb_ext):
+        lib = _lib.load()
+        plan, gpts, slope, n_conv = ctx.plan, ctx.gpts, ctx.slope, ctx.n_conv
+        saved = ctx.saved_tensors
+        x, emb, z = saved[0], saved[1], saved[2]
+        acts, params = saved[3:3 + n_conv], saved[3 + n_conv:]
+        convs, (R0w, R0b, R1w, R1b) = params[:2 * n_conv], params[2 * n_conv:]
+        N, dev, stream = x.shape[0], x.device, _lib.stream_ptr()
+        D, C, B = convs[0].shape[0], R1w.shape[0], plan.B
+        f32 = dict(dtype=torch.float32, device=dev)
+        # readout head
+        dy = _f32c(dy) if dy is not None else torch.zeros(B, C, **f32)
+        demb = torch.empty_like(emb)
+        dR0w, dR1w = torch.empty_like(R0w), torch.empty_like(R1w)
+        dR0b, dR1b = torch.empty(D, **f32), torch.empty(C, **f32)
+        wsb = lib.hcg_readout2_workspace_bytes(B)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.hcg_readout2_bwd(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C, slope,
+                                  _lib.ptr(demb), _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w), _lib.ptr(dR1b), _lib.ptr(ws),
+                                  wsb, stream)
+        _lib.check(rc, "hcg_readout2_bwd")
+        if demb_ext is not None:          # the caller also used graph_emb downstream
+            demb = demb + _f32c(demb_ext)
+        # conv stack, last layer first
+        grads = [None] * (2 * n_conv)
+        dh = None
+        for l in reversed(range(n_conv)):
+            W = convs[2 * l]
+            inp = x if l == 0 else acts[l - 1]
+            F = inp.shape[1]
+            need_dx = l > 0 or ctx.needs_input_grad[3]
+            dx = torch.empty_like(inp) if need_dx else None
+            dW, db = torch.empty_like(W), torch.empty(D, **f32)
+            wsb = lib.hcg_fused_workspace_bytes(B, F, D, gpts[l])
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            last = l == n_conv - 1
+            rc = lib.hcg_fused_layer_bwd(None if last else _lib.ptr(dh), _lib.ptr(demb) if last else None,
+                                         _lib.ptr(emb) if last else None, _lib.ptr(acts[l]), _lib.ptr(inp), _lib.ptr(W),
+                                         _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr),
+                                         N, B, F, D, gpts[l], slope, 1, _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb,
+                                         stream)
+            _lib.check(rc, "hcg_fused_layer_bwd")
+            rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db), stream)
+            _lib.check(rc, "hcg_fused_reduce_grads")
+            grads[2 * l], grads[2 * l + 1] = dW, db
+            dh = dx
+        return (None, None, None, dh if ctx.needs_input_grad[3] else None, *grads, dR0w, dR0b, dR1w, dR1b)
+
+
+def fused_model(plan: BatchPlan, gpts, x, conv_params, readout_params, slope=LEAKY_SLOPE):
+    """-> (out [B, C], graph_emb [B, 2D]).  conv_params = [W1, b1, W2, b2, ...], readout_params = [W0, b0, W1, b1]."""
+    return _FusedModelFn.apply(plan, tuple(gpts), slope, x, *conv_params, *readout_params)
+
+
 def fused_graphs_per_tile(plan: BatchPlan, F: int, D: int) -> int:
     """> 0 when the fused small-graph kernels apply to this plan / layer shape."""
     if plan.mode != "blocked" or plan.ew_csr is not None or plan.max_nodes is None or plan.B == 0:

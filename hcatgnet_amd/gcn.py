@@ -86,6 +86,7 @@ class GCN(BaseNetwork):
         self._make_scheduler(scheduler=opt.scheduler, step_size=opt.step_size, gamma=opt.gamma, min_lr=opt.min_lr)
         self.plan_mode = getattr(opt, "plan_mode", "auto")
         self.use_fused = bool(getattr(opt, "use_fused", True))
+        self.single_node = bool(getattr(opt, "single_autograd_node", True))   # whole fused model as one Function
 
     # ------------------------------------------------------------------ argument handling
     def _plan_for(self, graph, x, edge_index, batch, edge_weight) -> BatchPlan:
@@ -109,6 +110,16 @@ class GCN(BaseNetwork):
     def _run(self, x, plan: BatchPlan, use_edge_weight: bool, return_graph_embedding: bool):
         last = self.n_convolutions - 1
         fused = self.use_fused
+        if fused and not use_edge_weight and self.single_node:
+            # whole model as one autograd node when every piece has a fused kernel (small graphs, D = 64)
+            convs = [self.conv1] + list(self.conv_layers)
+            gpts = [HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) for c in convs]
+            if (all(g > 0 for g in gpts) and self.readout_layers == 2 and x.is_cuda
+                    and HF.readout2_supported(self.embedding_dim, self._n_classes)):
+                cp = [t for c in convs for t in (c.lin.weight, c.bias)]
+                l0, l1 = self.readout[0][0], self.readout[1]
+                z, graph_emb = HF.fused_model(plan, gpts, x, cp, [l0.weight, l0.bias, l1.weight, l1.bias])
+                return (z, graph_emb) if return_graph_embedding else z
         h = self.conv1(x, plan, use_edge_weight=use_edge_weight, apply_act=True, fused=fused, pool=last == 0)
         for i in range(self.n_convolutions - 1):                                       # gcn.py:61-63
             h = self.conv_layers[i](h, plan, use_edge_weight=False, apply_act=True, fused=fused, pool=i + 1 == last)

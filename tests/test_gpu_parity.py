@@ -480,3 +480,30 @@ def test_fused_mse_loss(H, n):
     assert rel_inf(loss, ref) <= TOL and rel_inf(ad.grad, ar.grad) <= TOL and rel_inf(bd.grad, br.grad) <= TOL
     with pytest.raises(ValueError):
         MSELoss()(ad, bd.reshape(-1))
+
+
+def test_single_node_model_equals_per_layer_functions(H, oracle):
+    """The one-autograd-node form of the fused model launches the same kernels as the per-layer
+    Functions: outputs and every gradient must be bitwise equal; graph_emb may carry its own gradient."""
+    from hcatgnet_amd import synth
+    sb = synth.make_config("C2", num_graphs=130)
+    params = _rand_params(64, 64, seed=41)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    batch.x.requires_grad_(True)
+    res = []
+    for single in (True, False):
+        m.single_node = single
+        m.zero_grad(); batch.x.grad = None
+        out, emb = m(batch, True)
+        (torch.sqrt(m.loss(out, batch.y.unsqueeze(1))) + 0.1 * emb.square().mean()).backward()
+        res.append((out.detach().clone(), emb.detach().clone(), batch.x.grad.clone(),
+                    {k: v.grad.clone() for k, v in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert all(torch.equal(res[0][3][k], res[1][3][k]) for k in res[0][3])
+    # and against the oracle with the same composite loss
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o_out, o_emb = oracle.gcn_forward(p, sb.x, sb.edge_index, sb.batch, sb.num_graphs)
+    (oracle.rmse_loss(o_out, sb.y) + 0.1 * o_emb.square().mean()).backward()
+    for k, v in p.items():
+        assert rel_inf(res[0][3][k], v.grad) <= (TOL_DW if k.endswith("weight") else TOL), k
