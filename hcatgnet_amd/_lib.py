@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhcatgnet_hip.so")
 
-HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY = 0, 1, 2
+HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0, 1, 2, 4
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
@@ -40,6 +40,11 @@ SIGNATURES = {
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
     "hcg_fused_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
     "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
+    "hcg_reduce_job_bytes": (SZ, []),
+    "hcg_fused_reduce_job": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
+    "hcg_readout2_bwd_partial": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, SZ, P]),
+    "hcg_readout2_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
+    "hcg_reduce_slabs": (INT, [P, INT, P]),
     "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
     "hcg_mse_bwd": (INT, [P, P, P, I64, P, P, P]),
     "hcg_readout2_supported": (INT, [I64, I64]),

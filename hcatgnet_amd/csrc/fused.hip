@@ -53,7 +53,8 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(idx) do { } while (0)
 #endif
 // tools/probe_fused.hip -DHCG_ABLATE=<bits> (timing-only diagnostic builds; results are wrong on purpose):
-//   1 = no MFMA in the forward GEMM, 2 = no aggregation MFMA, 4 = no output stores, 8 = no x loads
+//   1 = no MFMA in the forward GEMM, 2 = no aggregation MFMA, 4 = no output stores, 8 = no x loads,
+//   16 = no zero-fill of the count matrix, 32 = no x -> LDS write for prefetched tiles
 #ifndef HCG_ABLATE
 #define HCG_ABLATE 0
 #endif
@@ -150,9 +151,11 @@ struct TileEdges {
   // C = I + sum_e [dst_e][src_e],  ldinv = (row sum)^-1/2 ; edges beyond the first 64 are read here
   __device__ __forceinline__ void build(WaveLds& L, const TileInfo& ti, const int64_t* __restrict__ ei, int64_t E,
                                         int lane, int32_t* status) const {
+    if (!(HCG_ABLATE & 16)) {
 #pragma unroll
-    for (int j = 0; j < CNT_WORDS / 256; ++j)
-      *reinterpret_cast<int4*>(&L.cnt[(lane + 64 * j) * 4]) = make_int4(0, 0, 0, 0);
+      for (int j = 0; j < CNT_WORDS / 256; ++j)
+        *reinterpret_cast<int4*>(&L.cnt[(lane + 64 * j) * 4]) = make_int4(0, 0, 0, 0);
+    }
     if (lane < TM) L.ldinv[lane] = 0.f;
     int* degc = reinterpret_cast<int*>(L.ldinv);
     if (lane < ti.n) L.cnt[lane * CS + lane] = 1;                       // self loop, weight 1
@@ -460,7 +463,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       t = tn;
       ti = tin;
       STAMP(56);
-      sxn.write(L.buf, F, ti.n, lane);
+      if (!(HCG_ABLATE & 32)) sxn.write(L.buf, F, ti.n, lane);
+      else if (sxn.v4[0].x == 12345.678f) L.buf[lane] = sxn.v4[1].y + sxn.v4[2].x + sxn.v4[3].x + sxn.v4[4].x + sxn.v4[5].x + sxn.v4[6].x + sxn.v4[7].x;
       STAMP(57);
       ten.build(L, ti, ei, E, lane, status);
       STAMP(58);
@@ -853,5 +857,24 @@ extern "C" int hcg_fused_reduce_grads(const void* workspace, size_t workspace_by
   hipLaunchKernelGGL(k_fused_reduce, dim3((slab_floats + 15) / 16), dim3(256), 0, stream, (const float*)workspace, grid,
                      kpad, (int)F, dW, db);
   HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+// host-side description of this layer's slab set for hcg_reduce_slabs (no launch)
+extern "C" int hcg_fused_reduce_job(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
+                                    int graphs_per_tile, float* dW, float* db, hcg_reduce_job* job) {
+  if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1 || !dW || !db || !job || !workspace) return HCG_ERR_INVALID_ARG;
+  const int kpad = F <= 32 ? 32 : 64;
+  const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
+  const int grid = (N > 0 && B > 0) ? pick_grid(tiles) : 0;
+  const int slab_floats = DD * kpad + DD;
+  if (workspace_bytes < (size_t)grid * slab_floats * sizeof(float)) return HCG_ERR_WORKSPACE;
+  job->slabs = (const float*)workspace;
+  job->nslabs = grid;
+  job->slab_floats = slab_floats;
+  job->nseg = 2;
+  job->reserved = 0;
+  job->seg[0] = hcg_reduce_seg{0, DD * kpad, kpad, (int32_t)F, dW};
+  job->seg[1] = hcg_reduce_seg{DD * kpad, DD, 1, 1, db};
   return HCG_OK;
 }

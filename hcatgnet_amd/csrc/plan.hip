@@ -98,35 +98,6 @@ __global__ __launch_bounds__(256) void k_dinv(const int32_t* __restrict__ rowptr
 }
 
 // ------------------------------------------------------------------ BLOCKED mode
-// edge_ptr[g] = first edge whose SOURCE lies in a graph >= g; flags edges that leave their graph
-// or a source-graph sequence that is not non-decreasing.
-__global__ __launch_bounds__(256) void k_edge_ptr(const int64_t* __restrict__ ei, const int64_t* __restrict__ batch,
-                                                  int64_t N, int64_t E, int64_t B, int32_t* __restrict__ edge_ptr,
-                                                  int32_t* __restrict__ status) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e > E) return;
-  int st = 0;
-  int64_t prev = -1, cur = B;
-  if (e > 0) {
-    int64_t s = ei[e - 1];
-    if (s < 0 || s >= N) s = 0;  // range errors are flagged by the thread that owns the edge
-    prev = batch[s];
-  }
-  if (e < E) {
-    int64_t s = ei[e], d = ei[E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) { st |= HCG_STATUS_INDEX_RANGE; s = 0; d = 0; }
-    cur = batch[s];
-    if (batch[d] != cur) st |= HCG_STATUS_EDGE_UNGROUPED;
-    if (e > 0 && cur < prev) st |= HCG_STATUS_EDGE_UNGROUPED;
-  }
-  if (st) atomicOr(status, st);
-  if (prev < -1) prev = -1;
-  if (prev > B) prev = B;
-  if (cur < 0) cur = 0;
-  if (cur > B) cur = B;
-  for (int64_t g = prev + 1; g <= cur; ++g) edge_ptr[g] = (int32_t)e;
-}
-
 // blocked mode: graph_ptr and edge_ptr in ONE launch (threads [0, N] walk nodes, [N+1, N+E+1] edges)
 __global__ __launch_bounds__(256) void k_ptrs(const int64_t* __restrict__ ei, const int64_t* __restrict__ batch,
                                               int64_t N, int64_t E, int64_t B, int32_t* __restrict__ graph_ptr,
@@ -262,7 +233,7 @@ int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) <= v && b < 31) ++
 
 extern "C" size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode) {
   (void)N; (void)B;
-  if ((mode & ~HCG_PLAN_PTRS_ONLY) == HCG_PLAN_BLOCKED || E <= 0) return 256;
+  if ((mode & ~(HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS)) == HCG_PLAN_BLOCKED || E <= 0) return 256;
   const size_t keys = hcg_align_up((size_t)E * sizeof(uint64_t), 256);
   return 3 * keys + hcg_align_up(sort_temp_bytes(E), 256) + 1024;
 }
@@ -282,12 +253,13 @@ extern "C" int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, c
   if (N > 0 && !batch) return HCG_ERR_INVALID_ARG;
   if (edge_weight && (!eid || !eid_t || !ew_csr || !ew_csc || !dinv_unw)) return HCG_ERR_INVALID_ARG;
   const bool ptrs_only = (mode & HCG_PLAN_PTRS_ONLY) != 0;
-  mode &= ~HCG_PLAN_PTRS_ONLY;
+  const bool keep_status = (mode & HCG_PLAN_KEEP_STATUS) != 0;
+  mode &= ~(HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS);
   if (mode != HCG_PLAN_GENERAL && mode != HCG_PLAN_BLOCKED) return HCG_ERR_INVALID_ARG;
   if (mode == HCG_PLAN_BLOCKED && !edge_ptr) return HCG_ERR_INVALID_ARG;
   if (ptrs_only && mode != HCG_PLAN_BLOCKED) return HCG_ERR_INVALID_ARG;
 
-  HCG_TRY(hcg_hip_err(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), stream)));
+  if (!keep_status) HCG_TRY(hcg_hip_err(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), stream)));
   if (mode == HCG_PLAN_BLOCKED) {
     hipLaunchKernelGGL(k_ptrs, dim3((unsigned)hcg_cdiv(N + E + 2, 256)), dim3(256), 0, stream, edge_index, batch, N, E,
                        B, graph_ptr, edge_ptr, status);

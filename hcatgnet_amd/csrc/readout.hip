@@ -327,3 +327,35 @@ extern "C" int hcg_readout2_bwd(const float* dout, const float* emb, const float
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
+
+// backward without the slab reduction (pair with hcg_readout2_reduce_job + hcg_reduce_slabs)
+extern "C" int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z, const float* W0,
+                                        const float* W1, int64_t B, int64_t D, int64_t C, float slope, float* demb,
+                                        void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!hcg_readout2_supported(D, C)) return HCG_ERR_UNSUPPORTED;
+  if (B <= 0 || !W0 || !W1 || !dout || !emb || !z || !demb || !workspace) return HCG_ERR_INVALID_ARG;
+  const int grid = readout_grid(B);
+  if (workspace_bytes < (size_t)grid * SLAB * sizeof(float)) return HCG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_readout_bwd, dim3(grid), dim3(RWAVES * 64), 0, stream, dout, emb, z, W0, W1, (int)B, (int)C, slope,
+                     demb, (float*)workspace);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+extern "C" int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, float* dW0,
+                                       float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
+  if (B <= 0 || C < 1 || C > RCMAX || !dW0 || !db0 || !dW1 || !db1 || !job || !workspace) return HCG_ERR_INVALID_ARG;
+  const int grid = readout_grid(B);
+  if (workspace_bytes < (size_t)grid * SLAB * sizeof(float)) return HCG_ERR_WORKSPACE;
+  job->slabs = (const float*)workspace;
+  job->nslabs = grid;
+  job->slab_floats = SLAB;
+  job->nseg = 4;
+  job->reserved = 0;
+  job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
+  job->seg[1] = hcg_reduce_seg{RD * RK, RD, 1, 1, db0};
+  job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};
+  job->seg[3] = hcg_reduce_seg{RD * RK + RD + RCMAX * RD, (int32_t)C, 1, 1, db1};
+  return HCG_OK;
+}

@@ -344,6 +344,13 @@ class _FusedModelFn(torch.autograd.Function):
         N, dev, stream = x.shape[0], x.device, _lib.stream_ptr()
         D, C, B = convs[0].shape[0], R1w.shape[0], plan.B
         f32 = dict(dtype=torch.float32, device=dev)
+        # every backward kernel leaves per-workgroup slabs; ONE batched launch reduces them all at the end
+        import ctypes
+        jb = lib.hcg_reduce_job_bytes()
+        batched = n_conv + 1 <= 4
+        jobs = ctypes.create_string_buffer(jb * 4) if batched else None
+        jaddr = ctypes.addressof(jobs) if batched else 0
+        keep = []                                   # workspaces must outlive the batched reduction's enqueue
         # readout head
         dy = _f32c(dy) if dy is not None else torch.zeros(B, C, **f32)
         demb = torch.empty_like(emb)
@@ -351,15 +358,24 @@ class _FusedModelFn(torch.autograd.Function):
         dR0b, dR1b = torch.empty(D, **f32), torch.empty(C, **f32)
         wsb = lib.hcg_readout2_workspace_bytes(B)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        rc = lib.hcg_readout2_bwd(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C, slope,
-                                  _lib.ptr(demb), _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w), _lib.ptr(dR1b), _lib.ptr(ws),
-                                  wsb, stream)
-        _lib.check(rc, "hcg_readout2_bwd")
+        keep.append(ws)
+        if batched:
+            rc = lib.hcg_readout2_bwd_partial(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C,
+                                              slope, _lib.ptr(demb), _lib.ptr(ws), wsb, stream)
+            _lib.check(rc, "hcg_readout2_bwd_partial")
+            _lib.check(lib.hcg_readout2_reduce_job(_lib.ptr(ws), wsb, B, C, _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w),
+                                                   _lib.ptr(dR1b), jaddr), "hcg_readout2_reduce_job")
+        else:
+            rc = lib.hcg_readout2_bwd(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C, slope,
+                                      _lib.ptr(demb), _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w), _lib.ptr(dR1b),
+                                      _lib.ptr(ws), wsb, stream)
+            _lib.check(rc, "hcg_readout2_bwd")
         if demb_ext is not None:          # the caller also used graph_emb downstream
             demb = demb + _f32c(demb_ext)
         # conv stack, last layer first
         grads = [None] * (2 * n_conv)
         dh = None
+        njobs = 1
         for l in reversed(range(n_conv)):
             W = convs[2 * l]
             inp = x if l == 0 else acts[l - 1]
@@ -369,6 +385,7 @@ class _FusedModelFn(torch.autograd.Function):
             dW, db = torch.empty_like(W), torch.empty(D, **f32)
             wsb = lib.hcg_fused_workspace_bytes(B, F, D, gpts[l])
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            keep.append(ws)
             last = l == n_conv - 1
             rc = lib.hcg_fused_layer_bwd(None if last else _lib.ptr(dh), _lib.ptr(demb) if last else None,
                                          _lib.ptr(emb) if last else None, _lib.ptr(acts[l]), _lib.ptr(inp), _lib.ptr(W),
@@ -376,10 +393,17 @@ class _FusedModelFn(torch.autograd.Function):
                                          N, B, F, D, gpts[l], slope, 1, _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb,
                                          stream)
             _lib.check(rc, "hcg_fused_layer_bwd")
-            rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db), stream)
-            _lib.check(rc, "hcg_fused_reduce_grads")
+            if batched:
+                _lib.check(lib.hcg_fused_reduce_job(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db),
+                                                    jaddr + njobs * jb), "hcg_fused_reduce_job")
+                njobs += 1
+            else:
+                rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db), stream)
+                _lib.check(rc, "hcg_fused_reduce_grads")
             grads[2 * l], grads[2 * l + 1] = dW, db
             dh = dx
+        if batched:
+            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
         return (None, None, None, dh if ctx.needs_input_grad[3] else None, *grads, dR0w, dR0b, dR1w, dR1b)
 
 

@@ -17,14 +17,32 @@ import torch
 from . import _lib
 
 
+_SHARED_STATUS = {}
+
+
+def _shared_status(dev: torch.device) -> torch.Tensor:
+    """One once-zeroed status buffer per device, shared by the plans that are built WITHOUT validation
+    (trusted batches): their builds skip the per-step memset; flags from any of them accumulate until
+    `check_status()` reads and clears the buffer."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _SHARED_STATUS.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=dev)
+        _SHARED_STATUS[key] = t
+    return t
+
+
 class BatchPlan:
     __slots__ = ("N", "E", "B", "mode", "fill", "edge_index", "batch", "edge_weight", "graph_ptr", "edge_ptr",
                  "rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t", "dinv", "ew_csr", "ew_csc", "dinv_unw",
-                 "status", "max_nodes", "max_edges", "validated", "has_csr")
+                 "status", "max_nodes", "max_edges", "validated", "has_csr", "shared_status")
 
     def check_status(self):
-        """Synchronising read of the device-side status word; raises on any violation."""
+        """Synchronising read of the device-side status word; raises on any violation.  (For plans built
+        without validation the word is shared per device and cleared by this call.)"""
         word = int(self.status[0].item())
+        if self.shared_status and word:
+            self.status.zero_()
         self.validated = True
         if word:
             raise ValueError("hcatgnet_amd: invalid batch: " + _lib.describe_status(word))
@@ -51,6 +69,8 @@ class BatchPlan:
         m = _lib.HCG_PLAN_BLOCKED if which == "blocked" else _lib.HCG_PLAN_GENERAL
         if not csr:
             m |= _lib.HCG_PLAN_PTRS_ONLY
+        if self.shared_status:
+            m |= _lib.HCG_PLAN_KEEP_STATUS
         wsb = lib.hcg_plan_workspace_bytes(N, E, B, m)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         p = _lib.ptr
@@ -114,7 +134,8 @@ class BatchPlan:
         i32 = dict(dtype=torch.int32, device=dev)
         p.graph_ptr = torch.empty(B + 1, **i32)
         p.edge_ptr = torch.empty(B + 1, **i32)
-        p.status = torch.empty(4, **i32)
+        p.shared_status = not validate
+        p.status = _shared_status(dev) if p.shared_status else torch.empty(4, **i32)
         p.rowptr = p.col = p.eid = p.rowptr_t = p.col_t = p.eid_t = None
         p.dinv = p.ew_csr = p.ew_csc = p.dinv_unw = None
 

@@ -46,6 +46,8 @@ extern "C" {
 /* hcg_plan_build flags */
 #define HCG_PLAN_GENERAL 0 /* device radix sort; any edge order, any graph size           */
 #define HCG_PLAN_BLOCKED 1 /* edges grouped by graph (PyG collate order); per-graph waves */
+#define HCG_PLAN_KEEP_STATUS 4 /* OR: do not zero `status` first (flags accumulate in a caller-owned,
+                                  once-zeroed buffer until the caller reads and clears it) */
 #define HCG_PLAN_PTRS_ONLY 2 /* OR with BLOCKED: only graph_ptr / edge_ptr / status (one launch);
                                 all CSR outputs may be NULL -- enough for the hcg_fused_* kernels */
 
@@ -180,6 +182,32 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
 int hcg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, hcg_stream_t stream);
 int hcg_mse_bwd(const float* a, const float* b, const float* grad_loss, int64_t n,
                 float* da /*nullable*/, float* db /*nullable*/, hcg_stream_t stream);
+
+/* ---- batched slab reduction: ONE launch for all pending gradient reductions of a backward pass.
+ * hcg_fused_layer_bwd and hcg_readout2_bwd_partial leave per-workgroup slabs in their workspaces;
+ * hcg_fused_reduce_job / hcg_readout2_reduce_job describe them (host-side, no launch), hcg_reduce_slabs
+ * sums up to HCG_REDUCE_MAX_JOBS of them in a fixed order. */
+#define HCG_REDUCE_MAX_JOBS 4
+#define HCG_REDUCE_MAX_SEGS 4
+typedef struct hcg_reduce_seg {
+  int32_t begin, count;      /* element range of the slab */
+  int32_t row_in, row_out;   /* rows of row_in elements are written as rows of row_out (<= row_in) elements */
+  float* dst;
+} hcg_reduce_seg;
+typedef struct hcg_reduce_job {
+  const float* slabs;        /* [nslabs][slab_floats] */
+  int32_t nslabs, slab_floats, nseg, reserved;
+  hcg_reduce_seg seg[HCG_REDUCE_MAX_SEGS];
+} hcg_reduce_job;
+size_t hcg_reduce_job_bytes(void);
+int hcg_fused_reduce_job(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F,
+                         int64_t D, int graphs_per_tile, float* dW, float* db, hcg_reduce_job* job_host);
+int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z, const float* W0,
+                             const float* W1, int64_t B, int64_t D, int64_t C, float slope, float* demb,
+                             void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+                            float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
 
 #ifdef __cplusplus
 }
