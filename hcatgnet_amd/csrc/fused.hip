@@ -269,6 +269,25 @@ __device__ __forceinline__ void tile_gemm(const float* buf, const float (&wreg)[
   }
 }
 
+// same contraction with the weight operand read from a workgroup-shared LDS image [64][KPAD + 1]
+// (used for the second layer of the stacked forward: its 64 weight registers would not fit)
+template <int KPAD>
+__device__ __forceinline__ void tile_gemm_ldsw(const float* buf, const float* wl, f32x16& acc0, f32x16& acc1, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* w0 = wl + r * (KPAD + 1) + 4 * h;
+  const float* w1 = wl + (32 + r) * (KPAD + 1) + 4 * h;
+#pragma unroll
+  for (int t = 0; t < KPAD / 8; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(buf + r * HS + 8 * t + 4 * h);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], w0[8 * t + u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], w1[8 * t + u], acc1, 0, 0, 0);
+    }
+  }
+}
+
 // Block-cooperative staging of a [rows x cols] row-major global matrix into LDS as dst[r * ld + c]
 // (zero padded to cols_pad); every thread of the 512-thread workgroup takes part.
 __device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __restrict__ g, int rows, int cols,
@@ -283,13 +302,20 @@ __device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __
 // =====================================================================================================
 // forward:  out = LeakyReLU( Ahat (x W^T) + b ),  optional pooled epilogue emb[g] = [max, mean]
 // =====================================================================================================
-template <int KPAD, bool VEC, bool POOL>
+// STACK2: TWO conv layers per launch -- the first layer's output tile is already in LDS in exactly the
+// layout the next GEMM reads (the epilogue puts it there for the wide stores), the adjacency counts and
+// dinv are shared, and the second launch's prologue / tile staging / count build disappear.  The second
+// layer (64 -> 64) takes its weights from a workgroup-shared LDS image; POOL then refers to layer 2.
+template <int KPAD, bool VEC, bool POOL, bool STACK2>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ W2, const float* __restrict__ bias2,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
-    float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
+    float* __restrict__ out, float* __restrict__ out2, float* __restrict__ emb, int32_t* __restrict__ status) {
   __shared__ WaveLds lds[WAVES];
+  __shared__ float w2l[STACK2 ? DD * (DD + 1) : 4];
+  __shared__ float w1l[STACK2 ? DD * (KPAD + 1) : 4];   // stacked: layer-1 weights stay in LDS too (frees 64 VGPRs)
   STAMP_DECL
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -315,8 +341,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   // weight operand: W [64][F] -> LDS (coalesced, once per workgroup) -> 64 VGPRs per lane.
   // B[k][j] = W[j][k]; k-step s = 4t+u <-> k = 8t + 4h + u.  LDS image [n][KPAD + 1]: lane r reads
   // row nb*32 + r at a fixed k -> stride KPAD + 1 floats -> conflict-free.
-  float wreg[2][KPAD / 2];
-  {
+  float wreg[STACK2 ? 1 : 2][STACK2 ? 1 : KPAD / 2];
+  if (STACK2) {
+    stage_matrix(w1l, KPAD + 1, W, DD, F, KPAD);
+    stage_matrix(w2l, DD + 1, W2, DD, DD, DD);
+    __syncthreads();
+  } else {
     float* wl = reinterpret_cast<float*>(&lds[0]);   // flat view of the workgroup's LDS (64*(KPAD+1) floats)
     stage_matrix(wl, KPAD + 1, W, DD, F, KPAD);
     __syncthreads();
@@ -327,9 +357,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     __syncthreads();
   }
   float b0 = bias[r], b1 = bias[32 + r];
+  float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
   // retire the bias loads HERE: left pending, their first use (in the epilogue of the tile loop) makes
   // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1));
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
   STAMP(0);
   int stamp_it = 0;
   if (have) {
@@ -353,75 +384,89 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     }
     STAMP(2 + 8 * stamp_it);
 
-    // ---- H = X W^T
-    f32x16 acc0, acc1;
+    // dinv of this lane's 16 accumulator rows and the adjacency operand: read ONCE per tile into registers
+    // (re-reading them per use cost serialized LDS round trips: the compiler cannot prove the tile stores
+    // don't alias); shared by both layers of a stacked launch
+    float dvr[16], av[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if (!(HCG_ABLATE & 1)) tile_gemm<KPAD>(L.buf, wreg, acc0, acc1, lane);
-    STAMP(3 + 8 * stamp_it);
-
-    // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H'
-    // dinv of this lane's 16 accumulator rows: read ONCE into registers (re-reading them in the
-    // epilogue cost 16 serialized LDS round trips: the compiler cannot prove the tile stores don't alias)
-    float dvr[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
+    for (int i = 0; i < 16; ++i) {
+      dvr[i] = L.ldinv[krow(i, h)];
+      av[i] = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)] of the aggregation
+    }
     f32x16 y0, y1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      acc0[i] *= dvr[i];
-      acc1[i] *= dvr[i];
-      y0[i] = 0.f;
-      y1[i] = 0.f;
-    }
-    STAMP(4 + 8 * stamp_it);
-    if (!(HCG_ABLATE & 2)) {
-      float av[16];
+    for (int layer = 0; layer < (STACK2 ? 2 : 1); ++layer) {
+      // ---- H = X W^T
+      f32x16 acc0, acc1;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) av[i] = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)]
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {                                            // B[k][j] = acc[i]
-        y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc0[i], y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc1[i], y1, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      if (!(HCG_ABLATE & 1)) {
+        if constexpr (STACK2) {
+          if (layer == 0) tile_gemm_ldsw<KPAD>(L.buf, w1l, acc0, acc1, lane);
+          else tile_gemm_ldsw<DD>(L.buf, w2l, acc0, acc1, lane);
+        } else {
+          tile_gemm<KPAD>(L.buf, wreg, acc0, acc1, lane);
+        }
       }
-    } else {
-      y0 = acc0;
-      y1 = acc1;
-    }
-    STAMP(6 + 8 * stamp_it);
+      if (layer == 0) STAMP(3 + 8 * stamp_it);
 
-    // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers.
-    //      The values go back through the (now dead) x tile so that the HBM stores are 8 row-contiguous
-    //      dwordx4 per lane instead of 64 exec-masked dword stores.
+      // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H'
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = krow(i, h);
-      float v0 = fmaf(y0[i], dvr[i], b0), v1 = fmaf(y1[i], dvr[i], b1);
-      // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes)
-      if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
-      y0[i] = v0;
-      y1[i] = v1;
-      L.buf[row * HS + r] = v0;
-      L.buf[row * HS + 32 + r] = v1;
-    }
-    STAMP(7 + 8 * stamp_it);
-    if (ti.n > 0) {   // wave-uniform
-      // rows >= n are redirected to row n-1 (read AND write): duplicate identical stores instead of a
-      // per-lane branch around every store -> all 8 LDS reads and 8 stores stay in one basic block
-      const int q = lane & 15, r4 = lane >> 4;
-      float4 ov[TM / 4];
-#pragma unroll
-      for (int it = 0; it < TM / 4; ++it) {
-        const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
-        ov[it] = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+      for (int i = 0; i < 16; ++i) {
+        acc0[i] *= dvr[i];
+        acc1[i] *= dvr[i];
+        y0[i] = 0.f;
+        y1[i] = 0.f;
       }
+      if (layer == 0) STAMP(4 + 8 * stamp_it);
+      if (!(HCG_ABLATE & 2)) {
 #pragma unroll
-      for (int it = 0; it < TM / 4; ++it) {
-        const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
-        if (!(HCG_ABLATE & 4)) {
-          *reinterpret_cast<float4*>(out + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
-        } else if (ov[it].x == 12345.678f) {
-          out[0] = ov[it].y;
+        for (int i = 0; i < 16; ++i) {                                            // B[k][j] = acc[i]
+          y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc0[i], y0, 0, 0, 0);
+          y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc1[i], y1, 0, 0, 0);
+        }
+      } else {
+        y0 = acc0;
+        y1 = acc1;
+      }
+      if (layer == 0) STAMP(6 + 8 * stamp_it);
+
+      // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers.
+      //      The values go back through the (now dead) input tile so that the HBM stores are 8 row-contiguous
+      //      dwordx4 per lane instead of 64 exec-masked dword stores -- and, stacked, so that they ARE the
+      //      next layer's input tile.
+      const float bb0 = layer == 0 ? b0 : c0, bb1 = layer == 0 ? b1 : c1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = krow(i, h);
+        float v0 = fmaf(y0[i], dvr[i], bb0), v1 = fmaf(y1[i], dvr[i], bb1);
+        // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes)
+        if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
+        y0[i] = v0;
+        y1[i] = v1;
+        L.buf[row * HS + r] = v0;
+        L.buf[row * HS + 32 + r] = v1;
+      }
+      if (layer == 0) STAMP(7 + 8 * stamp_it);
+      if (ti.n > 0) {   // wave-uniform
+        // rows >= n are redirected to row n-1 (read AND write): duplicate identical stores instead of a
+        // per-lane branch around every store -> all 8 LDS reads and 8 stores stay in one basic block
+        const int q = lane & 15, r4 = lane >> 4;
+        float* dst = layer == 0 ? out : out2;
+        float4 ov[TM / 4];
+#pragma unroll
+        for (int it = 0; it < TM / 4; ++it) {
+          const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
+          ov[it] = *reinterpret_cast<const float4*>(L.buf + row * HS + 4 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < TM / 4; ++it) {
+          const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
+          if (!(HCG_ABLATE & 4)) {
+            *reinterpret_cast<float4*>(dst + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
+          } else if (ov[it].x == 12345.678f) {
+            dst[0] = ov[it].y;
+          }
         }
       }
     }
@@ -772,34 +817,56 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
   return (size_t)pick_grid(tiles) * (DD * kpad + DD) * sizeof(float) + 256;
 }
 
-extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
-                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
-                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* out, float* emb,
-                                   int32_t* status, hcg_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int launch_fused_fwd(const float* x, const float* W, const float* b, const float* W2, const float* b2,
+                            const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                            int64_t N, int64_t B, int64_t F, int64_t D, int graphs_per_tile, float slope, int apply_act,
+                            float* out, float* out2, float* emb, int32_t* status, hipStream_t stream) {
+  const bool stack2 = W2 != nullptr;
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;  // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
   if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (stack2 && (!b2 || !out2)) return HCG_ERR_INVALID_ARG;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = pick_grid(tiles);
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no tile has edges
-#define LAUNCH_FWD(KP, VC, PL)                                                                                        \
-  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL>), g, blk, 0, stream, x, (int)F, W, b, edge_index, E, graph_ptr,   \
-                     edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, emb, status)
-  if (F <= 32) {
-    if (vec) { if (emb) LAUNCH_FWD(32, true, true); else LAUNCH_FWD(32, true, false); }
-    else     { if (emb) LAUNCH_FWD(32, false, true); else LAUNCH_FWD(32, false, false); }
-  } else {
-    if (vec) { if (emb) LAUNCH_FWD(64, true, true); else LAUNCH_FWD(64, true, false); }
-    else     { if (emb) LAUNCH_FWD(64, false, true); else LAUNCH_FWD(64, false, false); }
-  }
+#define LAUNCH_FWD(KP, VC, PL, ST)                                                                                    \
+  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, E,  \
+                     graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, out2, emb, status)
+#define DISPATCH_FWD(KP, VC)                                                                       \
+  do {                                                                                             \
+    if (stack2) { if (emb) LAUNCH_FWD(KP, VC, true, true); else LAUNCH_FWD(KP, VC, false, true); }  \
+    else        { if (emb) LAUNCH_FWD(KP, VC, true, false); else LAUNCH_FWD(KP, VC, false, false); } \
+  } while (0)
+  if (F <= 32) { if (vec) DISPATCH_FWD(32, true); else DISPATCH_FWD(32, false); }
+  else         { if (vec) DISPATCH_FWD(64, true); else DISPATCH_FWD(64, false); }
+#undef DISPATCH_FWD
 #undef LAUNCH_FWD
   HCG_CHECK_LAUNCH();
   return HCG_OK;
+}
+
+extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
+                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* out, float* emb,
+                                   int32_t* status, hcg_stream_t stream) {
+  return launch_fused_fwd(x, W, b, nullptr, nullptr, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
+                          apply_act, out, nullptr, emb, status, (hipStream_t)stream);
+}
+
+// two stacked conv layers (F -> 64 -> 64) in ONE launch: out1 = layer-1 node embeddings, out2 = layer-2
+// node embeddings (both are needed by the backward), emb (nullable) = [max, mean] pooling of out2
+extern "C" int hcg_fused_stack2_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                                    const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
+                                    const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
+                                    int graphs_per_tile, float slope, int apply_act, float* out1, float* out2, float* emb,
+                                    int32_t* status, hcg_stream_t stream) {
+  if (!W2 || !b2 || !out2) return HCG_ERR_INVALID_ARG;
+  return launch_fused_fwd(x, W1, b1, W2, b2, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
+                          apply_act, out1, out2, emb, status, (hipStream_t)stream);
 }
 
 extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,

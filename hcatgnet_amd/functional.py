@@ -313,16 +313,27 @@ class _FusedModelFn(torch.autograd.Function):
         D = convs[0].shape[0]
         acts, h = [], x
         emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev)
-        for l in range(n_conv):
-            W, b = convs[2 * l], convs[2 * l + 1]
-            out = torch.empty(N, D, dtype=torch.float32, device=dev)
-            rc = lib.hcg_fused_layer_fwd(_lib.ptr(h), _lib.ptr(W), _lib.ptr(b), _lib.ptr(plan.edge_index), plan.E,
-                                         _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, h.shape[1], D,
-                                         gpts[l], slope, 1, _lib.ptr(out), _lib.ptr(emb) if l == n_conv - 1 else None,
-                                         _lib.ptr(plan.status), stream)
-            _lib.check(rc, "hcg_fused_layer_fwd")
-            acts.append(out)
-            h = out
+        if n_conv == 2 and gpts[0] == gpts[1]:
+            # the reference's default depth: both conv layers in ONE launch (csrc/fused.hip, STACK2)
+            a1 = torch.empty(N, D, dtype=torch.float32, device=dev)
+            a2 = torch.empty(N, D, dtype=torch.float32, device=dev)
+            rc = lib.hcg_fused_stack2_fwd(_lib.ptr(x), _lib.ptr(convs[0]), _lib.ptr(convs[1]), _lib.ptr(convs[2]),
+                                          _lib.ptr(convs[3]), _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr),
+                                          _lib.ptr(plan.edge_ptr), N, plan.B, x.shape[1], D, gpts[0], slope, 1, _lib.ptr(a1),
+                                          _lib.ptr(a2), _lib.ptr(emb), _lib.ptr(plan.status), stream)
+            _lib.check(rc, "hcg_fused_stack2_fwd")
+            acts = [a1, a2]
+        else:
+            for l in range(n_conv):
+                W, b = convs[2 * l], convs[2 * l + 1]
+                out = torch.empty(N, D, dtype=torch.float32, device=dev)
+                rc = lib.hcg_fused_layer_fwd(_lib.ptr(h), _lib.ptr(W), _lib.ptr(b), _lib.ptr(plan.edge_index), plan.E,
+                                             _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, h.shape[1], D,
+                                             gpts[l], slope, 1, _lib.ptr(out), _lib.ptr(emb) if l == n_conv - 1 else None,
+                                             _lib.ptr(plan.status), stream)
+                _lib.check(rc, "hcg_fused_layer_fwd")
+                acts.append(out)
+                h = out
         C = R1w.shape[0]
         z = torch.empty(plan.B, D, dtype=torch.float32, device=dev)
         y = torch.empty(plan.B, C, dtype=torch.float32, device=dev)
@@ -331,6 +342,7 @@ class _FusedModelFn(torch.autograd.Function):
         _lib.check(rc, "hcg_readout2_fwd")
         ctx.save_for_backward(x, emb, z, *acts, *params)
         ctx.plan, ctx.gpts, ctx.slope, ctx.n_conv = plan, list(gpts), slope, n_conv
+        ctx.set_materialize_grads(False)   # an unused graph_emb must arrive as None, not as a zero tensor + an add
         return y, emb
 
     @staticmethod

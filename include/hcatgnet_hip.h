@@ -147,6 +147,15 @@ int hcg_fused_layer_fwd(const float* x, const float* W, const float* b,
                         int64_t N, int64_t B, int64_t F, int64_t D,
                         int graphs_per_tile, float slope, int apply_act,
                         float* out, float* emb /*nullable*/, int32_t* status, hcg_stream_t stream);
+/* Two stacked conv layers F -> D -> D in ONE launch (the reference's default n_convolutions = 2): the
+ * first layer's output tile never leaves the chip before it is consumed; out1 / out2 are still written
+ * once each (the backward needs them), emb (nullable) pools out2. */
+int hcg_fused_stack2_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                         const int64_t* edge_index, int64_t E,
+                         const int32_t* graph_ptr, const int32_t* edge_ptr,
+                         int64_t N, int64_t B, int64_t F, int64_t D,
+                         int graphs_per_tile, float slope, int apply_act,
+                         float* out1, float* out2, float* emb /*nullable*/, int32_t* status, hcg_stream_t stream);
 /* backward, stage 1 (ONE launch).  dout == NULL selects the pooled form: the upstream gradient is
  * demb[B, 2D] and is expanded on chip with `emb` (ties of the max split evenly).  dx nullable (first
  * layer).  Leaves one partial slab [D*KPAD + D] per workgroup in `workspace`
