@@ -541,6 +541,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   constexpr int NBF = KPAD / 32;  // column blocks of dW (input-feature dimension)
   const int stride = gridDim.x * WAVES;
 
+  // first tile's loads go out before anything else
+  int t = blockIdx.x * WAVES + wave;
+  bool have = t < num_tiles;
+  TileInfo ti;
+  TileRaw raw_next;
+  Stager<DD, true> sa, sd;
+  TileEdges te;
+  if (have) {
+    const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    ti = tile_finish(raw0, gpt, lane, status);
+    sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
+    if (!POOLG) sd.load(dout, DD, N, ti.nbase, ti.n, lane);
+    te.load(ti, graph_ptr, ei, E, lane);
+  }
+
   if (NEEDS_DX) {
     stage_matrix(wlds, KPAD, W, DD, F, KPAD);
     __syncthreads();
@@ -555,17 +571,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int i = 0; i < 16; ++i) dw[mb][nb][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  TileRaw raw_next = tile_raw(blockIdx.x * WAVES + wave, num_tiles, gpt, B, graph_ptr, edge_ptr);
-  for (int t = blockIdx.x * WAVES + wave; t < num_tiles; t += stride) {
-    const TileInfo ti = tile_finish(raw_next, gpt, lane, status);
-    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // scalars one tile ahead
-    // the global reads of step 1 go in flight together: A rows, dA rows, edges
-    Stager<DD, true> sa;
-    sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
-    Stager<DD, true> sd;
-    if (!POOLG) sd.load(dout, DD, N, ti.nbase, ti.n, lane);
-    TileEdges te;
-    te.load(ti, graph_ptr, ei, E, lane);
+  while (have) {
     te.build(L, ti, ei, E, lane, status);
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> buf (rows >= n zero); A / dA stay in registers
@@ -626,9 +632,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       *reinterpret_cast<float4*>(L.buf + i * HS + 4 * q) = d;
     }
 
+    // next tile of this wave: its A / dA rows, edges and (one tile further) scalars go in flight now --
+    // the registers that held this tile's A / dA are free again -- and land while steps 2-4 compute
+    const int tn = t + stride;
+    const bool have_next = tn < num_tiles;
+    const TileRaw raw_cur = raw_next;
+    raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    TileInfo tin;
+    Stager<DD, true> san, sdn;
+    TileEdges ten;
+    // (measured: with the prefetch on, the dx / pooled variants spill 24-89 VGPRs and run 20-30 % SLOWER;
+    //  it stays off until the accumulators leave room -- tools/probe_fused.hip -DHCG_BWD_PREFETCH=1)
+#ifndef HCG_BWD_PREFETCH
+#define HCG_BWD_PREFETCH 0
+#endif
+    if (HCG_BWD_PREFETCH && have_next) {
+      tin = tile_finish(raw_cur, gpt, lane, status);
+      san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+      if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
+      ten.load(tin, graph_ptr, ei, E, lane);
+    }
+
     // x rows: issued now (the A / dA registers are free again), consumed after dH
     Stager<KPAD, VEC> sx;
-    constexpr bool EARLY_X = VEC && !NEEDS_DX;   // the dx variants are short of registers: they load x late
+    constexpr bool EARLY_X = false;   // registers go to the next-tile prefetch instead: x is loaded right before its use
     if (EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
 
     // ---- 2. dH = dinv (.) ( (C + I)^T dY' ):  A[m = j][k = i] = cnt[i][j],  B[k = i][col] = dY'[i][col]
@@ -722,6 +749,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
           }
         }
       }
+    }
+
+    have = have_next;
+    if (have_next) {
+      if (!HCG_BWD_PREFETCH) {
+        tin = tile_finish(raw_cur, gpt, lane, status);
+        san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+        if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
+        ten.load(tin, graph_ptr, ei, E, lane);
+      }
+      t = tn;
+      ti = tin;
+      sa = san;
+      if (!POOLG) sd = sdn;
+      te = ten;
     }
   }
 
