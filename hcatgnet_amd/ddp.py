@@ -28,7 +28,11 @@ class DataParallelGCN(nn.Module):
         self.force_collective = force_collective   # run the collectives even at world size 1 (tests)
         self._params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self._numel = sum(p.numel() for p in self._params)
-        self._flat: Optional[torch.Tensor] = None
+        self._flat: Optional[torch.Tensor] = None       # the buffer of the last reduction (own copy or in-place view)
+        self._own_flat: Optional[torch.Tensor] = None   # copy-path buffer (never aliases a gradient)
+        self._inplace = False
+        # ReduceOp.AVG exists for the NCCL/RCCL backend only (gloo: SUM + divide)
+        self._avg_ok = dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.broadcast_parameters()
 
     # attributes the reference's loops read from the model (utils/utils_model.py:62-66)
@@ -67,10 +71,28 @@ class DataParallelGCN(nn.Module):
         hipGraph writes into); default = each parameter's `.grad`."""
         if grads is None:
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
+        # fast path: the fused backward already wrote every gradient into one flat buffer in parameter order
+        g0 = grads[0]
+        if g0.is_contiguous() and g0.dtype == torch.float32:
+            base, off, ok = g0.data_ptr(), 0, True
+            for g in grads:
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+                off += g.numel()
+            if ok and off == self._numel:
+                try:
+                    flat = torch.as_strided(g0, (self._numel,), (1,))      # same storage, no copy
+                    self._flat, self._inplace = flat, True
+                    return flat
+                except RuntimeError:
+                    pass                                                    # storage smaller than expected: copy path
         grads = [g.reshape(-1) for g in grads]
-        if self._flat is None or self._flat.device != grads[0].device:
-            self._flat = torch.empty(self._numel, dtype=torch.float32, device=grads[0].device)
-        torch.cat(grads, out=self._flat)
+        self._inplace = False
+        if self._own_flat is None or self._own_flat.device != grads[0].device:
+            self._own_flat = torch.empty(self._numel, dtype=torch.float32, device=grads[0].device)
+        torch.cat(grads, out=self._own_flat)
+        self._flat = self._own_flat
         return self._flat
 
     def reduce_gradients(self, average: bool = True, grads=None) -> torch.Tensor:
@@ -78,11 +100,15 @@ class DataParallelGCN(nn.Module):
         flat = self.flat_gradient(grads)
         ws = self.world_size()
         if ws > 1 or self.force_collective:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
-            if average and ws > 1:
-                flat.div_(ws)
-        off = 0
-        for p in self._params:
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            if average and self._avg_ok:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)   # one collective, no div kernel
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+                if average and ws > 1:
+                    flat.div_(ws)
+        if not self._inplace:   # (in-place: the gradients the caller already holds ARE views of `flat`)
+            off = 0
+            for p in self._params:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         return flat

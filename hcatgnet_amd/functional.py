@@ -363,11 +363,25 @@ class _FusedModelFn(torch.autograd.Function):
         jobs = ctypes.create_string_buffer(jb * 4) if batched else None
         jaddr = ctypes.addressof(jobs) if batched else 0
         keep = []                                   # workspaces must outlive the batched reduction's enqueue
+        # All weight gradients are views of ONE flat buffer laid out in nn.Module parameter order
+        # (conv: bias, lin.weight; readout: weight, bias) -- the data-parallel wrapper can then all-reduce it
+        # in place, without first concatenating 8 small tensors.
+        sizes = []
+        for l in range(n_conv):
+            sizes += [D, convs[2 * l].numel()]
+        sizes += [R0w.numel(), D, R1w.numel(), C]
+        flat = torch.empty(sum(sizes), **f32)
+        views, off = [], 0
+        for n_el in sizes:
+            views.append(flat[off:off + n_el])
+            off += n_el
+        conv_db = [views[2 * l] for l in range(n_conv)]
+        conv_dW = [views[2 * l + 1].view_as(convs[2 * l]) for l in range(n_conv)]
+        dR0w, dR0b = views[2 * n_conv].view_as(R0w), views[2 * n_conv + 1]
+        dR1w, dR1b = views[2 * n_conv + 2].view_as(R1w), views[2 * n_conv + 3]
         # readout head
         dy = _f32c(dy) if dy is not None else torch.zeros(B, C, **f32)
         demb = torch.empty_like(emb)
-        dR0w, dR1w = torch.empty_like(R0w), torch.empty_like(R1w)
-        dR0b, dR1b = torch.empty(D, **f32), torch.empty(C, **f32)
         wsb = lib.hcg_readout2_workspace_bytes(B)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         keep.append(ws)
@@ -394,7 +408,7 @@ class _FusedModelFn(torch.autograd.Function):
             F = inp.shape[1]
             need_dx = l > 0 or ctx.needs_input_grad[3]
             dx = torch.empty_like(inp) if need_dx else None
-            dW, db = torch.empty_like(W), torch.empty(D, **f32)
+            dW, db = conv_dW[l], conv_db[l]
             wsb = lib.hcg_fused_workspace_bytes(B, F, D, gpts[l])
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             keep.append(ws)

@@ -507,3 +507,21 @@ def test_single_node_model_equals_per_layer_functions(H, oracle):
     (oracle.rmse_loss(o_out, sb.y) + 0.1 * o_emb.square().mean()).backward()
     for k, v in p.items():
         assert rel_inf(res[0][3][k], v.grad) <= (TOL_DW if k.endswith("weight") else TOL), k
+
+
+def test_fused_backward_writes_one_flat_gradient_buffer(H):
+    """The single-node backward lays all 8 gradients out in ONE buffer in parameter order, so the DP
+    wrapper all-reduces in place (no concatenation)."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.ddp import DataParallelGCN
+    sb = synth.make_config("C2", num_graphs=64)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    batch = sb.as_batch("cuda")
+    torch.sqrt(m.loss(m(batch), batch.y.unsqueeze(1))).backward()
+    dp = DataParallelGCN(m)
+    grads = [p.grad for p in m.parameters()]
+    flat = dp.flat_gradient()
+    assert flat.data_ptr() == grads[0].data_ptr() and flat.numel() == 16641
+    assert torch.equal(flat, torch.cat([g.reshape(-1) for g in grads]))
+    dp.reduce_gradients()                       # world size 1: views re-attached, values unchanged
+    assert all(torch.equal(p.grad, g) for p, g in zip(m.parameters(), grads))
