@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
     return ap.parse_args()
 
 
@@ -165,6 +167,8 @@ def main():
     y2 = y.unsqueeze(1)
 
     def step(with_opt=False):
+        if args.forward_only:
+            return step_body()
         model.optimizer.zero_grad(set_to_none=True)
         b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
         out = model(b)                                   # plan build + forward
@@ -194,10 +198,15 @@ def main():
         with torch.cuda.graph(g):
             step_body()
         static_grads.clear()
-        static_grads.extend(p.grad for p in model.parameters())   # the tensors every replay rewrites
+        if not args.forward_only:
+            static_grads.extend(p.grad for p in model.parameters())   # the tensors every replay rewrites
         return g
 
     def step_body():
+        if args.forward_only:
+            with torch.no_grad():
+                b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+                return model(b)
         model.optimizer.zero_grad(set_to_none=True)
         b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
         out = model(b)
@@ -255,7 +264,7 @@ def main():
         log(f"RCCL process group up: world {world}")
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
-    entry = args.roofline_entry or "hcg_fused_layer_bwd"
+    entry = args.roofline_entry or ("hcg_fused_stack2_fwd" if args.forward_only else "hcg_fused_layer_bwd")
     timer = EntryTimer(lib, entry)
     timer.install()
     timer.enabled = True
@@ -266,7 +275,7 @@ def main():
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
     dt_eager = timed(args.steps)
     log(f"timed eager: {dt_eager / args.steps * 1e3:.3f} ms/step")
-    dt_opt = timed(args.steps, with_opt=True)
+    dt_opt = timed(args.steps, with_opt=not args.forward_only)
     log(f"timed eager with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
     dt_best = dt_eager
     if graph is not None:
@@ -277,13 +286,14 @@ def main():
         dt_best = dt_graph
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
-    step_bytes = sum(bd.values())
+    step_bytes = sum(v for k, v in bd.items() if not args.forward_only or k.endswith("_fwd") or k == "csr_build")
     # algorithmic bytes of ONE launch of the timed entry point, averaged over its launches in a step
     # (layer 2 backward also carries the pool backward it fuses; layer 2 forward the pool forward)
     entry_bytes = {"hcg_gcn_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"]) / 2.0,
                    "hcg_gcn_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"]) / 2.0,
                    "hcg_fused_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
-                   "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0}.get(entry, float("nan"))
+                   "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
+                   "hcg_fused_stack2_fwd": bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]}.get(entry, float("nan"))
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950
     # correction of MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only valid for the config they were taken on
@@ -292,7 +302,7 @@ def main():
     if cfg_name in ("C2", "C3", "C4") and args.num_graphs is None and os.path.isfile(tpath):
         try:
             tj = json.load(open(tpath))
-            prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd", "hcg_fused_layer_fwd": "k_fused_layer_fwd"}.get(entry)
+            prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd"}.get(entry)   # (forward traffic: re-profile after STACK2)
             vals = [v["hbm_bytes"] for k, v in tj.items() if prefix and k.startswith(prefix)]
             traffic = sum(vals) / len(vals) if vals else None
         except (OSError, ValueError, KeyError):
@@ -301,7 +311,8 @@ def main():
     if rank == 0:
         ms_step = dt_best / args.steps * 1e3
         rec = {
-            "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s" if not args.forward_only
+                      else "molecular graphs/sec FORWARD ONLY (configs[1]; not the headline metric)",
             "value": world * B * args.steps / dt_best, "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
