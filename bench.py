@@ -330,7 +330,7 @@ def main():
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "breakdown": bd},
             "with_optimizer": {"value": world * B * args.steps / dt_opt, "unit": "graphs/s",
-                               "ms_per_step": dt_opt / args.steps * 1e3, "optimizer": "torch Adam(lr=0.01, eps=1e-9)"},
+                               "ms_per_step": dt_opt / args.steps * 1e3, "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), eager"},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3, "graph_capture_error": graph_err,
         }

@@ -1,0 +1,39 @@
+// Adam step for the model's parameters in ONE launch per contiguous segment (the step right
+// after the path).  The reference uses torch.optim.Adam(lr, eps=1e-9) (model/networks.py:38) on 8 small
+// tensors (16 641 floats): through torch's foreach implementation that is ~10 multi-tensor launches and
+// ~0.5 ms of host time per step -- more than the whole fwd+bwd here.  Same update rule as torch
+// (amsgrad=False, weight_decay=0, maximize=False):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   p -= (lr / (1 - b1^t)) * m / ( sqrt(v) / sqrt(1 - b2^t) + eps )
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                              float bc1, float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+// step = 1-based step count of this update; bias corrections are computed on the host in double like torch
+extern "C" int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int64_t step, hcg_stream_t stream) {
+  if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return HCG_ERR_INVALID_ARG;
+  if (n == 0) return HCG_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}

@@ -51,7 +51,9 @@ class BaseNetwork(nn.Module):
 
     def _make_optimizer(self, optimizer, lr):
         if optimizer == "Adam":
-            self.optimizer = torch.optim.Adam(self.parameters(), lr=lr, eps=1e-9)
+            # torch.optim.Adam(lr, eps=1e-9) in the reference (model/networks.py:38); same rule, one HIP launch
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(self.parameters(), lr=lr, eps=1e-9)
         elif optimizer == "SGD":
             self.optimizer = torch.optim.SGD(self.parameters(), lr=lr)
         elif optimizer == "rmsprop":

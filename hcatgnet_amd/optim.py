@@ -1,0 +1,98 @@
+"""FusedAdam: `torch.optim.Adam` semantics (the reference builds `Adam(self.parameters(), lr, eps=1e-9)`,
+model/networks.py:38) with the update done by ONE HIP launch when the gradients sit in one flat buffer
+(which the fused backward guarantees), one launch per parameter otherwise.
+
+It IS a `torch.optim.Optimizer` (param_groups, state_dict, zero_grad, lr schedulers -- e.g. the reference's
+`ReduceLROnPlateau` -- all work): `lr` is read from `param_groups` at every step.  Parameters and both
+moment buffers are re-based onto flat storages the first time `step()` sees them on the GPU; the
+`nn.Parameter` objects stay the same (only `.data` is re-pointed), so `state_dict()/load_state_dict()` of
+the module are unaffected.  Restrictions (checked): float32, amsgrad / weight_decay / maximize off.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._flat = {}      # group index -> dict(param, exp_avg, exp_avg_sq flat tensors)
+
+    def _rebase(self, gi, group):
+        """Move the group's parameters and moments onto flat buffers (in parameter order)."""
+        ps = [p for p in group["params"] if p.requires_grad]
+        dev = ps[0].device
+        n = sum(p.numel() for p in ps)
+        flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                if p.dtype != torch.float32:
+                    raise _lib.HcgError("FusedAdam handles float32 parameters only")
+                k = p.numel()
+                flat_p[off:off + k].copy_(p.reshape(-1))
+                st = self.state[p]
+                if "exp_avg" in st:            # keep moments restored by load_state_dict
+                    flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                p.data = flat_p[off:off + k].view(p.shape)
+                st["exp_avg"] = flat_m[off:off + k].view(p.shape)
+                st["exp_avg_sq"] = flat_v[off:off + k].view(p.shape)
+                st.setdefault("step", torch.tensor(0.0))
+                off += k
+        self._flat[gi] = dict(params=ps, p=flat_p, m=flat_m, v=flat_v, n=n, step=int(ps and self.state[ps[0]]["step"]) if ps else 0)
+        return self._flat[gi]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                continue
+            _lib.require_gpu(*ps)
+            fl = self._flat.get(gi)
+            if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
+                fl = self._rebase(gi, group)
+            grads = [p.grad for p in ps]
+            if any(g is None for g in grads):
+                raise _lib.HcgError("FusedAdam.step(): a parameter has no gradient")
+            fl["step"] += 1
+            step, lr, (b1, b2), eps = fl["step"], float(group["lr"]), group["betas"], float(group["eps"])
+            stream = _lib.stream_ptr()
+            # one launch when the gradients are one flat buffer in parameter order (fused backward / DP wrapper)
+            g0, off, flat_ok = grads[0], 0, grads[0].is_contiguous() and grads[0].dtype == torch.float32
+            if flat_ok:
+                base = g0.data_ptr()
+                for g in grads:
+                    if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
+                        flat_ok = False
+                        break
+                    off += g.numel()
+            if flat_ok:
+                _lib.check(lib.hcg_adam_step(fl["p"].data_ptr(), g0.data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(),
+                                             fl["n"], lr, b1, b2, eps, step, stream), "hcg_adam_step")
+            else:
+                off = 0
+                for p, g in zip(ps, grads):
+                    g = g.contiguous()
+                    if g.dtype != torch.float32:
+                        raise _lib.HcgError("FusedAdam handles float32 gradients only")
+                    k = p.numel()
+                    _lib.check(lib.hcg_adam_step(fl["p"].data_ptr() + 4 * off, g.data_ptr(), fl["m"].data_ptr() + 4 * off,
+                                                 fl["v"].data_ptr() + 4 * off, k, lr, b1, b2, eps, step, stream),
+                               "hcg_adam_step")
+                    off += k
+            for p in ps:
+                self.state[p]["step"] = torch.tensor(float(step))
+        return loss

@@ -218,6 +218,11 @@ int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64
                             float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
 
+/* ---- Adam update (f2) over one contiguous fp32 segment: torch.optim.Adam's rule (amsgrad / weight_decay /
+ *      maximize off).  `step` = 1-based count of this update.  One launch. */
+int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int64_t step, hcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -525,3 +525,76 @@ def test_fused_backward_writes_one_flat_gradient_buffer(H):
     assert torch.equal(flat, torch.cat([g.reshape(-1) for g in grads]))
     dp.reduce_gradients()                       # world size 1: views re-attached, values unchanged
     assert all(torch.equal(p.grad, g) for p, g in zip(m.parameters(), grads))
+
+
+def test_fused_adam_matches_torch_adam_and_scheduler(H):
+    """FusedAdam == torch.optim.Adam(lr=0.01, eps=1e-9) over several real training steps (flat-gradient
+    one-launch path), then with non-flat gradients (per-parameter path), and it honours lr changes made by
+    the reference's ReduceLROnPlateau scheduler."""
+    from hcatgnet_amd import synth
+    sb = synth.make_config("C2", num_graphs=96)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    ref_params = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=0.01, eps=1e-9)
+    batch = sb.as_batch("cuda")
+    for it in range(6):
+        m.optimizer.zero_grad()
+        loss = torch.sqrt(m.loss(m(batch), batch.y.unsqueeze(1)))
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in m.parameters()]
+        if it >= 3:   # break the flat layout on purpose -> per-parameter launches
+            for p, g in zip(m.parameters(), grads):
+                p.grad = g.clone()
+        m.optimizer.step()
+        for rp, g in zip(ref_params, grads):
+            rp.grad = g
+        ref_opt.step()
+        for p, rp in zip(m.parameters(), ref_params):
+            assert rel_inf(p, rp) <= 2e-6, it
+        if it == 1:   # scheduler writes param_groups[...]['lr']; mirror it on the torch optimiser
+            for _ in range(m.scheduler.patience + 2):
+                m.scheduler.step(1e9)
+            assert m.optimizer.param_groups[0]["lr"] < 0.01
+            ref_opt.param_groups[0]["lr"] = m.optimizer.param_groups[0]["lr"]
+    # module state dict still has the reference's keys / shapes and the updated values
+    sd = m.state_dict()
+    assert tuple(sd["conv1.lin.weight"].shape) == (64, 64) and torch.equal(sd["conv1.lin.weight"], m.conv1.lin.weight)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_path_random_batches(H, oracle, seed):
+    """Randomised sweep of the fused path: random graph sizes (1..32 nodes, empty slots), random
+    multigraph edges (duplicates, asymmetric directions, isolated nodes), random F in {7..64}."""
+    g = torch.Generator().manual_seed(100 + seed)
+    B = int(torch.randint(1, 70, (1,), generator=g))
+    F = int(torch.randint(7, 65, (1,), generator=g))
+    sizes = torch.randint(0, 33, (B,), generator=g)
+    if seed % 2 == 0:
+        sizes = sizes.clamp(max=10)                       # several graphs per 32-row tile
+    sizes[int(torch.randint(0, B, (1,), generator=g))] = max(1, int(sizes.max()))
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes.tolist()):
+        if n == 0:
+            continue
+        xs.append(torch.randn(n, F, generator=g))
+        bs.append(torch.full((n,), gi, dtype=torch.int64))
+        ne = int(torch.randint(0, 3 * n + 1, (1,), generator=g))
+        if ne:
+            eis.append(torch.randint(0, n, (2, ne), generator=g) + off)     # self loops / duplicates allowed
+        off += n
+    x, b = torch.cat(xs), torch.cat(bs)
+    ei = torch.cat(eis, 1) if eis else torch.zeros(2, 0, dtype=torch.int64)
+    y = torch.randn(B, generator=g)
+    params = _rand_params(F, 64, seed=200 + seed)
+    m = _model_from_params(H, params)
+    plan = H.BatchPlan.build(ei.cuda(), b.cuda(), x.shape[0], num_graphs=B, mode="blocked", max_nodes=int(sizes.max()))
+    from hcatgnet_amd import functional as HF
+    assert HF.fused_graphs_per_tile(plan, F, 64) >= 1
+    m.zero_grad()
+    out, emb = m(x.cuda(), ei.cuda(), None, b.cuda(), return_graph_embedding=True, plan=plan)
+    torch.sqrt(m.loss(out, y.cuda().unsqueeze(1))).backward()
+    assert plan.check_status() == 0
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, x, ei, b, y, B)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out, floor=1.0) <= TOL
+    for k, v in m.named_parameters():
+        assert rel_inf(v.grad, o_grads[k]) <= TOL, k

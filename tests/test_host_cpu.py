@@ -49,7 +49,8 @@ def test_module_surface_matches_reference_contract():
     opt = H.default_options()
     m = H.make_network("GCN", opt, 25)
     assert m.name == "GCN" and type(m.loss).__name__ == "MSELoss"
-    assert isinstance(m.optimizer, torch.optim.Adam) and m.optimizer.defaults["eps"] == 1e-9 and m.optimizer.defaults["lr"] == 0.01
+    assert isinstance(m.optimizer, torch.optim.Optimizer) and type(m.optimizer).__name__ == "FusedAdam"
+    assert m.optimizer.defaults["eps"] == 1e-9 and m.optimizer.defaults["lr"] == 0.01 and m.optimizer.defaults["betas"] == (0.9, 0.999)
     assert isinstance(m.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau)
     keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert keys == {"conv1.bias": (64,), "conv1.lin.weight": (64, 25), "conv_layers.0.bias": (64,),
