@@ -17,7 +17,8 @@ HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
-               16: "a graph exceeds the fused-kernel tile"}
+               16: "a graph exceeds the fused-kernel tile",
+               32: "explicit self-loop edge together with edge_weight (its weight as loop weight is not implemented)"}
 STATUS_EDGE_UNGROUPED = 8
 
 P, I64, SZ, F32, INT = c_void_p, c_int64, c_size_t, c_float, c_int

@@ -173,7 +173,9 @@ struct TileEdges {
       const unsigned sl = (unsigned)((int)s - ti.nbase), dl = (unsigned)((int)d - ti.nbase);
       const bool live = k0 + lane < ti.ne;
       const bool ok = sl < (unsigned)ti.n && dl < (unsigned)ti.n && (s >> 31) == 0 && (d >> 31) == 0;
-      if (live && ok) {
+      // an explicit (i, i) edge collapses into the unit self loop every node already has (PyG
+      // add_remaining_self_loops): it is neither counted nor added
+      if (live && ok && sl != dl) {
         atomicAdd(&L.cnt[dl * CS + sl], 1);                             // ds_add_u32: exact, order-independent
         atomicAdd(&degc[dl], 1);
       }

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ src
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     for (int32_t k = kb; k < ke; ++k) {
       const int32_t c = col[k];
+      if (c < 0) continue;   // explicit self loop: collapsed into the unit self loop below
       float w = dinv[c];
       if (ew) w *= ew[k];
       float val[VEC];

@@ -51,12 +51,20 @@ __global__ __launch_bounds__(256) void k_make_keys(const int64_t* __restrict__ e
 
 // sorted keys -> col (the OTHER endpoint) + eid; `other_row` = row of edge_index to read
 __global__ __launch_bounds__(256) void k_extract(const uint64_t* __restrict__ keys, const int64_t* __restrict__ other_row,
-                                                 int64_t N, int64_t E, int32_t* __restrict__ col, int32_t* __restrict__ eid) {
+                                                 int64_t N, int64_t E, int32_t* __restrict__ col, int32_t* __restrict__ eid,
+                                                 int32_t* __restrict__ status) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E) return;
   const uint32_t e = (uint32_t)(keys[k] & 0xffffffffu);
   int64_t o = other_row[e];
   if (o < 0 || o >= N) o = 0;
+  // explicit self loop (i, i): kept in its slot as -1 = "skip" (PyG add_remaining_self_loops collapses it
+  // into the unit self loop every node gets)
+  if ((int64_t)(keys[k] >> 32) == o) {
+    o = -1;
+    // with explicit edge weights PyG would use this edge's weight as the node's loop weight: not implemented
+    if (eid) atomicOr(status, HCG_STATUS_WEIGHTED_SELF_LOOP);
+  }
   col[k] = (int32_t)o;
   if (eid) eid[k] = (int32_t)e;
 }
@@ -81,19 +89,16 @@ __global__ __launch_bounds__(256) void k_permute_weights(const float* __restrict
 }
 
 // dinv[i] = (fill + sum_k w_k)^-1/2 over the incoming row (fixed CSR order), 0 where degree == 0
-__global__ __launch_bounds__(256) void k_dinv(const int32_t* __restrict__ rowptr, const float* __restrict__ ew_csr,
-                                              int64_t N, float fill, float* __restrict__ dinv) {
+__global__ __launch_bounds__(256) void k_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                              const float* __restrict__ ew_csr, int64_t N, float fill,
+                                              float* __restrict__ dinv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int32_t b = rowptr[i], e = rowptr[i + 1];
-  float deg;
-  if (ew_csr) {
-    deg = 0.f;
-    for (int32_t k = b; k < e; ++k) deg += ew_csr[k];
-    deg += fill;
-  } else {
-    deg = fill + (float)(e - b);
-  }
+  float deg = 0.f;
+  for (int32_t k = b; k < e; ++k)
+    if (col[k] >= 0) deg += ew_csr ? ew_csr[k] : 1.0f;   // col < 0: explicit self loop, not an edge
+  deg += fill;
   dinv[i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
 }
 
@@ -175,16 +180,16 @@ __global__ __launch_bounds__(64) void k_graph_csr(const int64_t* __restrict__ ei
   for (int c0 = 0; c0 < n; c0 += 64) {
     const int i = c0 + lane;
     const bool act = i < n;
-    int cin = 0, cout = 0;
+    int cin = 0, cout = 0, nself = 0;   // nself: explicit (i, i) edges -- slots kept (col = -1), not counted in the degree
     if (in_lds) {
-      for (int k = 0; k < ne; ++k) { const int2 sd = sedge[k]; cin += (sd.y == i); cout += (sd.x == i); }
+      for (int k = 0; k < ne; ++k) { const int2 sd = sedge[k]; cin += (sd.y == i); cout += (sd.x == i); nself += (sd.y == i && sd.x == i); }
     } else {
       for (int k = 0; k < ne; ++k) {
         const int s = (int)(ei[ebeg + k] - nbeg), d = (int)(ei[E + ebeg + k] - nbeg);
-        cin += (d == i); cout += (s == i);
+        cin += (d == i); cout += (s == i); nself += (d == i && s == i);
       }
     }
-    if (!act) { cin = 0; cout = 0; }
+    if (!act) { cin = 0; cout = 0; nself = 0; }
     // wave-wide inclusive scan of (cin, cout)
     int sin = cin, sout = cout;
 #pragma unroll
@@ -196,20 +201,28 @@ __global__ __launch_bounds__(64) void k_graph_csr(const int64_t* __restrict__ ei
     if (act) {
       rowptr[nbeg + i] = pin;
       rowptr_t[nbeg + i] = pout;
-      const float deg = fill + (float)cin;
+      const float deg = fill + (float)(cin - nself);
       dinv[nbeg + i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
       if (in_lds) {
         for (int k = 0; k < ne; ++k) {
           const int2 sd = sedge[k];
-          if (sd.y == i) { col[pin] = nbeg + sd.x; if (eid) eid[pin] = ebeg + k; ++pin; }
-          if (sd.x == i) { col_t[pout] = nbeg + sd.y; if (eid_t) eid_t[pout] = ebeg + k; ++pout; }
+          if (sd.y == i) {
+            col[pin] = sd.x == i ? -1 : nbeg + sd.x;
+            if (eid) { eid[pin] = ebeg + k; if (sd.x == i) atomicOr(status, HCG_STATUS_WEIGHTED_SELF_LOOP); }
+            ++pin;
+          }
+          if (sd.x == i) { col_t[pout] = sd.y == i ? -1 : nbeg + sd.y; if (eid_t) eid_t[pout] = ebeg + k; ++pout; }
         }
       } else {
         for (int k = 0; k < ne; ++k) {
           int s = (int)(ei[ebeg + k] - nbeg), d = (int)(ei[E + ebeg + k] - nbeg);
           if (s < 0 || s >= n || d < 0 || d >= n) { s = 0; d = 0; atomicOr(status, HCG_STATUS_EDGE_UNGROUPED); }
-          if (d == i) { col[pin] = nbeg + s; if (eid) eid[pin] = ebeg + k; ++pin; }
-          if (s == i) { col_t[pout] = nbeg + d; if (eid_t) eid_t[pout] = ebeg + k; ++pout; }
+          if (d == i) {
+            col[pin] = s == i ? -1 : nbeg + s;
+            if (eid) { eid[pin] = ebeg + k; if (s == i) atomicOr(status, HCG_STATUS_WEIGHTED_SELF_LOOP); }
+            ++pin;
+          }
+          if (s == i) { col_t[pout] = d == i ? -1 : nbeg + d; if (eid_t) eid_t[pout] = ebeg + k; ++pout; }
         }
       }
     }
@@ -297,7 +310,7 @@ extern "C" int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, c
       // CSR by target
       HCG_TRY(hcg_hip_err(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, (const uint64_t*)k0, k2, (int)E, 0,
                                                              end_bit, stream)));
-      hipLaunchKernelGGL(k_extract, dim3(gE), dim3(256), 0, stream, (const uint64_t*)k2, edge_index, N, E, col, eid);
+      hipLaunchKernelGGL(k_extract, dim3(gE), dim3(256), 0, stream, (const uint64_t*)k2, edge_index, N, E, col, eid, status);
       HCG_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_rowptr_search, dim3(gN), dim3(256), 0, stream, (const uint64_t*)k2, N, E, rowptr);
       HCG_CHECK_LAUNCH();
@@ -305,7 +318,7 @@ extern "C" int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, c
       HCG_TRY(hcg_hip_err(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, (const uint64_t*)k1, k2, (int)E, 0,
                                                              end_bit, stream)));
       hipLaunchKernelGGL(k_extract, dim3(gE), dim3(256), 0, stream, (const uint64_t*)k2, edge_index + E, N, E, col_t,
-                         eid_t);
+                         eid_t, status);
       HCG_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_rowptr_search, dim3(gN), dim3(256), 0, stream, (const uint64_t*)k2, N, E, rowptr_t);
       HCG_CHECK_LAUNCH();
@@ -325,12 +338,12 @@ extern "C" int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, c
   }
   if (N > 0 && (mode == HCG_PLAN_GENERAL || edge_weight)) {
     hipLaunchKernelGGL(k_dinv, dim3((unsigned)hcg_cdiv(N, 256)), dim3(256), 0, stream, (const int32_t*)rowptr,
-                       (const float*)(edge_weight ? ew_csr : nullptr), N, fill, dinv);
+                       (const int32_t*)col, (const float*)(edge_weight ? ew_csr : nullptr), N, fill, dinv);
     HCG_CHECK_LAUNCH();
   }
   if (N > 0 && edge_weight) {
     hipLaunchKernelGGL(k_dinv, dim3((unsigned)hcg_cdiv(N, 256)), dim3(256), 0, stream, (const int32_t*)rowptr,
-                       (const float*)nullptr, N, 1.0f, dinv_unw);
+                       (const int32_t*)col, (const float*)nullptr, N, 1.0f, dinv_unw);
     HCG_CHECK_LAUNCH();
   }
   return HCG_OK;

@@ -57,6 +57,8 @@ extern "C" {
 #define HCG_STATUS_BATCH_RANGE 4   /* a batch id outside [0,B)                           */
 #define HCG_STATUS_EDGE_UNGROUPED 8 /* blocked mode: edges not grouped by graph / cross   */
 #define HCG_STATUS_SHAPE_LIMIT 16  /* fused mode: a graph exceeds the tile the host chose */
+#define HCG_STATUS_WEIGHTED_SELF_LOOP 32 /* explicit (i,i) edge together with edge_weight: PyG would take its
+                                            weight as the node's loop weight; not implemented (loop weight = fill) */
 
 /* activation codes of hcg_linear_* */
 #define HCG_ACT_NONE 0
@@ -75,7 +77,10 @@ size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode);
  *   graph_ptr [B+1]  node range of each graph                    (a9's `batch`)
  *   edge_ptr  [B+1]  edge range of each graph in CSR order (blocked mode; may be NULL in general)
  *   rowptr [N+1], col [E], eid [E]      incoming edges of each node, stable in input order:
- *                                       col = source id, eid = position in edge_index
+ *                                       col = source id, eid = position in edge_index;
+ *                                       col = -1 marks an explicit self-loop edge (i, i): as in PyG's
+ *                                       add_remaining_self_loops it is not an edge of its own (every node
+ *                                       gets exactly one self loop of weight `fill`) and is not counted in dinv
  *   rowptr_t [N+1], col_t [E], eid_t [E] outgoing edges (the transpose, for the backward)
  *   dinv [N]         (fill + sum of incoming weights)^-1/2, 0 where the degree is 0
  *   ew_csr, ew_csc [E]  edge weights permuted to CSR / CSC order (only when edge_weight != NULL)

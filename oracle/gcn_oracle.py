@@ -51,10 +51,19 @@ def gcn_norm(edge_index: torch.Tensor, num_nodes: int, edge_weight: Optional[tor
     else:
         fill = 2.0 if improved else 1.0
         w = edge_weight.to(dtype)
+    # PyG `add_remaining_self_loops`: explicit (i, i) edges are REMOVED and every node gets exactly one
+    # self loop; a node that had an explicit one keeps that edge's weight as its loop weight (published
+    # torch_geometric.utils.loop semantics; the reference's molecular graphs contain no self loops, so this
+    # branch is not pinned by any artefact).
+    keep = src != dst
     loop = torch.arange(num_nodes, dtype=src.dtype, device=src.device)
-    src_f = torch.cat([src, loop])
-    dst_f = torch.cat([dst, loop])
-    w_f = torch.cat([w, torch.full((num_nodes,), fill, dtype=dtype, device=src.device)])
+    loop_w = torch.full((num_nodes,), fill, dtype=dtype, device=src.device)
+    if edge_weight is not None and bool((~keep).any()):
+        loop_w = loop_w.clone()
+        loop_w[src[~keep]] = w[~keep]
+    src_f = torch.cat([src[keep], loop])
+    dst_f = torch.cat([dst[keep], loop])
+    w_f = torch.cat([w[keep], loop_w])
     deg = torch.zeros(num_nodes, dtype=dtype, device=src.device).scatter_add_(0, dst_f, w_f)
     dinv = deg.pow(-0.5)
     dinv = torch.where(torch.isinf(dinv), torch.zeros_like(dinv), dinv)

@@ -70,13 +70,14 @@ def _check_plan_against_input(plan, edge_index, batch, B):
     # bit-exact reconstruction of the (src, dst) multiset, and STABLE order inside every row
     order = np.lexsort((np.arange(E), ei[1]))                       # stable by target
     assert np.array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))]))
-    assert np.array_equal(col, ei[0][order])
+    selfloop = ei[0] == ei[1]                                        # explicit (i, i): slot kept, marked -1
+    assert np.array_equal(col, np.where(selfloop, -1, ei[0])[order])
     order_t = np.lexsort((np.arange(E), ei[0]))
     assert np.array_equal(rowptr_t, np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))]))
-    assert np.array_equal(col_t, ei[1][order_t])
+    assert np.array_equal(col_t, np.where(selfloop, -1, ei[1])[order_t])
     gp = plan.graph_ptr.cpu().numpy()
     assert np.array_equal(gp, np.searchsorted(batch.cpu().numpy(), np.arange(B + 1), side="left"))
-    deg = 1.0 + np.bincount(ei[1], minlength=N).astype(np.float32)
+    deg = 1.0 + np.bincount(ei[1][~selfloop], minlength=N).astype(np.float32)
     assert np.array_equal(plan.dinv.cpu().numpy()[:N], (1.0 / np.sqrt(deg)).astype(np.float32))
 
 
@@ -598,3 +599,33 @@ def test_fused_path_random_batches(H, oracle, seed):
     assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out, floor=1.0) <= TOL
     for k, v in m.named_parameters():
         assert rel_inf(v.grad, o_grads[k]) <= TOL, k
+
+
+def test_explicit_self_loop_edges_collapse_like_pyg(H, oracle):
+    """(i, i) edges in the input: PyG's add_remaining_self_loops removes them and gives every node exactly
+    one unit self loop -- on the fused path, the blocked and the general any-shape plans."""
+    x = torch.randn(7, 64, generator=torch.Generator().manual_seed(0))
+    ei = torch.tensor([[0, 1, 1, 2, 2, 2, 3, 5, 6, 6], [1, 0, 1, 2, 1, 2, 3, 6, 5, 6]], dtype=torch.int64)
+    b = torch.tensor([0, 0, 0, 1, 2, 2, 2], dtype=torch.int64)
+    params = _rand_params(64, 64, seed=43)
+    ref, remb = oracle.gcn_forward(params, x, ei, b, 3)
+    no_loops = ei[:, ei[0] != ei[1]]
+    ref2, _ = oracle.gcn_forward(params, x, no_loops, b, 3)
+    assert torch.allclose(ref, ref2)                     # the oracle itself: loops change nothing
+    m = _model_from_params(H, params)
+    for fused, mode in ((True, "blocked"), (False, "blocked"), (False, "general")):
+        m.use_fused = fused
+        plan = H.BatchPlan.build(ei.cuda(), b.cuda(), 7, num_graphs=3, mode=mode, max_nodes=3)
+        with torch.no_grad():
+            out, emb = m(x.cuda(), ei.cuda(), None, b.cuda(), return_graph_embedding=True, plan=plan)
+        assert rel_inf(emb, remb) <= TOL and rel_inf(out, ref, floor=1.0) <= TOL, (fused, mode)
+
+
+def test_weighted_explicit_self_loop_is_flagged(H):
+    """edge_weight + an explicit (i, i) edge: PyG would use that edge's weight as the loop weight; this
+    build does not implement it and must say so instead of returning different numbers silently."""
+    ei = torch.tensor([[0, 1, 1], [1, 0, 1]], dtype=torch.int64).cuda()
+    b = torch.zeros(2, dtype=torch.int64).cuda()
+    with pytest.raises(ValueError, match="self-loop"):
+        H.BatchPlan.build(ei, b, 2, num_graphs=1, edge_weight=torch.ones(3).cuda(), mode="general")
+    H.BatchPlan.build(ei, b, 2, num_graphs=1, mode="general")      # unweighted: fine
