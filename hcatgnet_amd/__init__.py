@@ -5,6 +5,7 @@ Public surface (mirrors the reference's names for this path):
     GCN, GCN_explain, BaseNetwork               reference model/gcn.py, model/networks.py
     Data, Batch, collate, DataLoader            stand-ins for the PyG containers the loops touch
     BatchPlan                                   per-batch CSR / gcn_norm plan (GPU)
+    DeviceGraphStore, DeviceLoader              dataset resident in HBM, batches collated on the GPU
     DataParallelGCN                             one-process-per-GPU gradient all-reduce (RCCL)
 Compute lives in csrc/libhcatgnet_hip.so (hand-written HIP for gfx950) behind include/hcatgnet_hip.h.
 """
@@ -13,6 +14,7 @@ from .call_methods import default_options, make_network  # noqa: F401
 from .gcn import GCN, GCN_explain, GCNConv  # noqa: F401
 from .networks import BaseNetwork  # noqa: F401
 from .plan import BatchPlan  # noqa: F401
+from .store import DeviceGraphStore, DeviceLoader  # noqa: F401
 
 __all__ = ["make_network", "default_options", "GCN", "GCN_explain", "GCNConv", "BaseNetwork", "Data", "Batch",
-           "collate", "DataLoader", "BatchPlan"]
+           "collate", "DataLoader", "BatchPlan", "DeviceGraphStore", "DeviceLoader"]

@@ -85,6 +85,8 @@ class BatchPlan:
     def ensure_csr(self):
         """Build rowptr/col/dinv (and the transpose) if this plan so far only holds the pointers."""
         if not self.has_csr:
+            if self.status is None:
+                self.status = _shared_status(self.edge_index.device)
             self._run(self.mode, csr=True)
         return self
 

@@ -1,0 +1,112 @@
+"""DeviceGraphStore / DeviceLoader: the dataset resident in HBM, batches collated ON the GPU.
+
+Replaces, for this path, the reference's per-graph `torch.load` (data/datasets.py:74-78) and PyG
+`DataLoader(dataset, batch_size, shuffle)` collate (call_methods.py:41-46): one gather launch per batch
+(csrc/collate.hip), and because the host knows every graph's size the batch plan (graph_ptr / edge_ptr)
+comes for free -- the batch object carries a ready `BatchPlan`, so the fused path launches no plan kernel.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batch import Batch, Data
+from .plan import BatchPlan, _shared_status
+
+
+class DeviceGraphStore:
+    def __init__(self, graphs: Sequence[Data], device="cuda"):
+        if len(graphs) == 0:
+            raise ValueError("empty dataset")
+        dev = torch.device(device)
+        n = np.array([g.num_nodes for g in graphs], np.int64)
+        e = np.array([g.num_edges for g in graphs], np.int64)
+        self.num_graphs, self.F = len(graphs), int(graphs[0].x.shape[1])
+        self.n_host, self.e_host = n, e
+        self.node_ptr_host = np.concatenate([[0], np.cumsum(n)])
+        self.edge_ptr_host = np.concatenate([[0], np.cumsum(e)])
+        x = torch.cat([g.x.to(torch.float32) for g in graphs], 0)
+        ei = torch.cat([g.edge_index for g in graphs], 1) if int(e.sum()) else torch.zeros(2, 0, dtype=torch.int64)
+        for g in graphs:
+            if g.num_edges and (int(g.edge_index.min()) < 0 or int(g.edge_index.max()) >= g.num_nodes):
+                raise ValueError("edge_index of a graph refers to a node outside the graph")
+        self.x_all = x.contiguous().to(dev)
+        self.src_all = ei[0].to(torch.int32).contiguous().to(dev)
+        self.dst_all = ei[1].to(torch.int32).contiguous().to(dev)
+        self.node_ptr_all = torch.from_numpy(self.node_ptr_host).to(dev)
+        self.edge_ptr_all = torch.from_numpy(self.edge_ptr_host).to(dev)
+        ys = [getattr(g, "y", None) for g in graphs]
+        self.y_all = torch.cat([torch.as_tensor(v, dtype=torch.float32).reshape(-1)[:1] for v in ys]).to(dev) \
+            if all(v is not None for v in ys) else None
+        ids = [getattr(g, "idx", None) for g in graphs]
+        self.idx_all = torch.tensor([int(v) for v in ids], dtype=torch.int64, device=dev) if all(v is not None for v in ids) else None
+        self.device = dev
+
+    def __len__(self):
+        return self.num_graphs
+
+    def collate(self, graph_ids: Iterable[int]) -> Batch:
+        """Batch of the given graphs (host list / array of indices), gathered on the device."""
+        lib = _lib.load()
+        ids = np.asarray(list(graph_ids) if not isinstance(graph_ids, np.ndarray) else graph_ids, np.int64)
+        if ids.size == 0:
+            raise ValueError("cannot collate an empty selection")
+        if ids.min() < 0 or ids.max() >= self.num_graphs:
+            raise IndexError("graph index out of range")
+        B = int(ids.size)
+        n, e = self.n_host[ids], self.e_host[ids]
+        gp = np.zeros(B + 1, np.int32); gp[1:] = np.cumsum(n)
+        ep = np.zeros(B + 1, np.int32); ep[1:] = np.cumsum(e)
+        N, E = int(gp[-1]), int(ep[-1])
+        dev = self.device
+        ids_d = torch.from_numpy(ids).to(dev, non_blocking=True)
+        gp_d = torch.from_numpy(gp).to(dev, non_blocking=True)
+        ep_d = torch.from_numpy(ep).to(dev, non_blocking=True)
+        x = torch.empty(N, self.F, dtype=torch.float32, device=dev)
+        ei = torch.empty(2, E, dtype=torch.int64, device=dev)
+        bvec = torch.empty(N, dtype=torch.int64, device=dev)
+        y = torch.empty(B, dtype=torch.float32, device=dev) if self.y_all is not None else None
+        idx = torch.empty(B, dtype=torch.int64, device=dev) if self.idx_all is not None else None
+        p = _lib.ptr
+        rc = lib.hcg_collate(p(self.x_all), p(self.src_all), p(self.dst_all), p(self.node_ptr_all), p(self.edge_ptr_all),
+                             p(self.y_all), p(self.idx_all), p(ids_d), p(gp_d), p(ep_d), B, self.F, N, E, p(x), p(ei), p(bvec),
+                             p(y), p(idx), _lib.stream_ptr())
+        _lib.check(rc, "hcg_collate")
+        batch = Batch(x, ei, bvec, B, y=y, idx=idx, max_nodes=int(n.max()), max_edges=int(e.max()), edges_grouped=True)
+        # the plan of the fused path is exactly (graph_ptr, edge_ptr): attach it, nothing left to launch
+        plan = BatchPlan()
+        plan.N, plan.E, plan.B, plan.fill, plan.mode = N, E, B, 1.0, "blocked"
+        plan.edge_index, plan.batch, plan.edge_weight = ei, bvec, None
+        plan.graph_ptr, plan.edge_ptr = gp_d, ep_d
+        plan.max_nodes, plan.max_edges, plan.validated, plan.has_csr = batch.max_nodes, batch.max_edges, True, False
+        plan.shared_status, plan.status = True, _shared_status(dev)
+        plan.rowptr = plan.col = plan.eid = plan.rowptr_t = plan.col_t = plan.eid_t = None
+        plan.dinv = plan.ew_csr = plan.ew_csc = plan.dinv_unw = None
+        batch._hcg_plan = plan
+        return batch
+
+
+class DeviceLoader:
+    """`DataLoader(dataset, batch_size, shuffle)` over a DeviceGraphStore: the permutation is drawn on the
+    host (a few KB), everything else happens on the GPU."""
+
+    def __init__(self, store: DeviceGraphStore, batch_size: int = 1, shuffle: bool = False, seed: Optional[int] = None,
+                 drop_last: bool = False):
+        self.store, self.batch_size, self.shuffle, self.drop_last = store, int(batch_size), shuffle, drop_last
+        self.rng = np.random.default_rng(seed)
+        self.dataset = store       # `len(loader.dataset)` is what the reference's loops divide by (utils_model.py:70)
+
+    def __len__(self):
+        n = len(self.store)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = self.rng.permutation(len(self.store)) if self.shuffle else np.arange(len(self.store))
+        for i in range(0, len(order), self.batch_size):
+            ids = order[i:i + self.batch_size]
+            if self.drop_last and ids.size < self.batch_size:
+                return
+            yield self.store.collate(ids)

@@ -228,6 +228,19 @@ int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t st
 int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int64_t step, hcg_stream_t stream);
 
+/* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
+ * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),
+ * node_ptr_all / edge_ptr_all [G+1] (int64), y_all [G], idx_all [G].  `ids` [B] selects graphs (device).
+ * graph_ptr / edge_ptr [B+1] (int32) are the batch's prefix sums (the host knows the sizes; they double
+ * as the fused path's plan).  Writes x_out [N_out, F], edge_index_out [2, E_out] (global ids), batch_out
+ * [N_out], y_out / idx_out [B] (nullable).  Replaces reference data/datasets.py:74-78 + PyG collate. */
+int hcg_collate(const float* x_all, const int32_t* src_all, const int32_t* dst_all,
+                const int64_t* node_ptr_all, const int64_t* edge_ptr_all, const float* y_all,
+                const int64_t* idx_all, const int64_t* ids, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                int64_t B, int64_t F, int64_t N_out, int64_t E_out,
+                float* x_out, int64_t* edge_index_out, int64_t* batch_out, float* y_out /*nullable*/,
+                int64_t* idx_out /*nullable*/, hcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

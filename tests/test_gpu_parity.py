@@ -629,3 +629,35 @@ def test_weighted_explicit_self_loop_is_flagged(H):
     with pytest.raises(ValueError, match="self-loop"):
         H.BatchPlan.build(ei, b, 2, num_graphs=1, edge_weight=torch.ones(3).cuda(), mode="general")
     H.BatchPlan.build(ei, b, 2, num_graphs=1, mode="general")      # unweighted: fine
+
+
+def test_device_collate_equals_host_collate_and_feeds_the_model(H):
+    """f1: DeviceGraphStore.collate (one gather launch, plan attached) == host PyG-rule collate, bitwise;
+    the model gives identical numbers on both; DeviceLoader covers the dataset once per epoch."""
+    g = torch.Generator().manual_seed(7)
+    graphs = []
+    for i in range(37):
+        n = int(torch.randint(1, 31, (1,), generator=g)); ne = int(torch.randint(0, 3 * n, (1,), generator=g))
+        graphs.append(H.Data(x=torch.randn(n, 25, generator=g), edge_index=torch.randint(0, n, (2, ne), generator=g),
+                             y=torch.randn(1, generator=g), idx=1000 + i))
+    store = H.DeviceGraphStore(graphs, "cuda")
+    ids = [5, 0, 36, 17, 17, 3]
+    db = store.collate(ids)
+    hb = H.collate([graphs[i] for i in ids])
+    assert torch.equal(db.x.cpu(), hb.x) and torch.equal(db.edge_index.cpu(), hb.edge_index)
+    assert torch.equal(db.batch.cpu(), hb.batch) and torch.equal(db.y.cpu(), hb.y) and torch.equal(db.idx.cpu(), hb.idx)
+    assert db.num_graphs == 6 and db.max_nodes == hb.max_nodes and db._hcg_plan is not None
+    assert torch.equal(db._hcg_plan.graph_ptr.cpu().long(), hb.ptr) and torch.equal(db._hcg_plan.edge_ptr.cpu().long(), hb.edge_ptr)
+    m = H.make_network("GCN", H.default_options(), 25).cuda()
+    with torch.no_grad():
+        o_dev = m(db)
+        o_host = m(hb.to("cuda"))
+    assert torch.equal(o_dev, o_host)
+    m.use_fused = False                      # the attached pointer-only plan must grow a CSR on demand
+    with torch.no_grad():
+        o_any = m(store.collate(ids))
+    assert rel_inf(o_any, o_dev, floor=1.0) <= 2e-6
+    seen = []
+    for bt in H.DeviceLoader(store, batch_size=8, shuffle=True, seed=1):
+        seen += bt.idx.cpu().tolist()
+    assert sorted(seen) == [1000 + i for i in range(37)]
