@@ -2,26 +2,35 @@
 //
 // One GCN layer (reference: PyG GCNConv + nn.LeakyReLU, call sites model/gcn.py:58-63; SURVEY rows
 // a3-a8, and a9 for the last layer) is ONE kernel: a tile of whole graphs (<= 32 node rows) is
-// brought on chip once, transformed AND aggregated on the f32 matrix cores, biased/activated,
+// brought on chip once, transformed AND aggregated on the matrix cores, biased/activated,
 // (pooled) and written once -- the "layer-fused minimum" HBM traffic of SURVEY 8(d).
 //
 // CDNA4 mapping
 //   * wavefront-autonomous tiles: each 64-lane wave owns a stream of tiles and a private LDS region
-//     (one [32][68] fp32 tile + a [32][33] int adjacency-count matrix); no workgroup barrier in the
-//     steady state.  512-thread workgroup (8 waves = 2 per SIMD) per CU.
+//     (one [32][68] fp32 tile; the [32][33] adjacency-count matrix of the forward lives in the same
+//     bytes until the tile is staged); no workgroup barrier in the steady state.  512-thread
+//     workgroup (8 waves = 2 per SIMD) per CU.
 //   * gcn_norm without any index structure: the tile's raw COO edges (int64 `edge_index`, grouped by
 //     graph as PyG collation emits them) are scattered into C[dst][src] += 1 with LDS integer atomics
 //     (order-independent -> deterministic), C += I, deg = row sums, dinv = deg^-1/2.  No CSR, no
 //     sort: the fused path needs only graph_ptr / edge_ptr from the batch plan.
-//   * every contraction is v_mfma_f32_32x32x2_f32 (exact f32, a k-ordered fmaf chain):
-//       H   = X W^T                      W in 64 VGPRs; X rows from LDS by ds_read_b128 (k = 8t+4h+u)
-//       Y   = (C + I) (dinv . H)         B operand = the H ACCUMULATORS themselves: MFMA sums over k,
-//                                        so k-step i may use k = krow(i, h) = (i&3) + 8(i>>2) + 4h,
-//                                        exactly the rows accumulator register i holds on lane-half h
+//   * every contraction runs on v_mfma_f32_32x32x16_bf16 with SPLIT operands: an f32 value is the sum
+//     of three bf16 pieces (round-to-nearest residuals: x = p1 + p2 + p3 to 2^-24 |x|), a product
+//     keeps the six cross terms down to 2^-24 (p1q1, p1q2, p2q1, p1q3, p2q2, p3q1), products of bf16
+//     pairs are exact in the f32 accumulator.  Measured against fp64 the result is as accurate as the
+//     exact-f32 MFMA chain (v_mfma_f32_32x32x2_f32: 1.5e-7 vs 2.1e-7 |err|inf/|ref|inf on a 64-term
+//     dot, tools/probe_bf16x.hip) at 1/16 of its cycles per product: 6 bf16 MFMAs replace 8 f32 ones
+//     of 2x the cycles each, the f32 matrix rate (64 FLOP/clk/SIMD) having been the compute floor of
+//     these kernels.  Small integer operands (the adjacency counts) are exact in ONE piece.
+//       H   = X W^T                      X pieces split on the fly from the fp32 LDS tile,
+//                                        W pieces pre-split once per workgroup into LDS
+//       Y   = (C + I) (dinv . H)         B operand = the H ACCUMULATORS themselves (split in registers):
+//                                        an MFMA sums over k, so slot j of k-step s on lane-half h may
+//                                        stand for k = krow(8s + j, h) -- exactly the rows accumulator
+//                                        register 8s + j holds there
 //       out = LeakyReLU(dinv . Y + b)    epilogue / pooling in accumulator layout
 //     backward: dH = (C + I)^T (dinv . dY), dW += dH^T X (A operand = dH accumulators, same trick),
-//     dX = dH W (one LDS transpose).  The non-MFMA instruction stream per tile is a few hundred
-//     instructions; as a VALU/LDS segmented sum it was ~1500 and bound the kernel.
+//     dX = dH W (one LDS transpose).
 //   * backward: dW accumulates in MFMA accumulators ACROSS all tiles of a wave; waves combine
 //     through LDS, workgroups through a [grid][D*KPAD+D] slab reduced in a fixed order by a second
 //     kernel -> bitwise reproducible gradients.
@@ -52,34 +61,95 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP_FLUSH() do { } while (0)
 #define STAMP(idx) do { } while (0)
 #endif
-// tools/probe_fused.hip -DHCG_ABLATE=<bits> (timing-only diagnostic builds; results are wrong on purpose):
-//   1 = no MFMA in the forward GEMM, 2 = no aggregation MFMA, 4 = no output stores, 8 = no x loads,
-//   16 = no zero-fill of the count matrix, 32 = no x -> LDS write for prefetched tiles
-#ifndef HCG_ABLATE
-#define HCG_ABLATE 0
-#endif
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // one MFMA A/B fragment: 8 bf16 in 4 VGPRs
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 32;          // node rows per wave tile
 constexpr int DD = 64;          // layer width handled by this file (embedding_dim = 64)
 constexpr int HS = DD + 4;      // LDS row stride (floats) of the [TM][DD] tile buffer
 constexpr int CS = TM + 1;      // row stride of the adjacency-count matrix (conflict-free rows AND columns)
-constexpr int CNT_WORDS = 1280; // >= TM * CS, multiple of 256 (zero-filled with 5 float4 stores per lane)
+constexpr int CNT_WORDS = 1280; // >= TM * CS, multiple of 256 (zero-filled with 5 int4 stores per lane)
 constexpr int WAVES = 8;        // waves per workgroup
 constexpr int BUF_FLOATS = TM * HS;
-
-struct WaveLds {
-  float buf[BUF_FLOATS];   // forward: x tile.  backward: dY', then x tile, then dH (for the dX transpose)
-  int cnt[CNT_WORDS];      // C + I of the tile: cnt[dst * CS + src]
-  float ldinv[TM];         // in-degree counter while the edges are scattered, then (1 + deg)^-1/2
-  int lgp[TM + 4];         // node offset of every graph of the tile (a tile holds <= TM graphs)
-};
+constexpr int WPAD = 8;         // bf16 padding of a pre-split weight row: rows of (K + 8) * 2 bytes are 16-byte
+                                // aligned and 16 consecutive rows cover all 64 LDS banks (ds_read_b128, conflict-free)
+constexpr int CNT_EXACT = 256;  // adjacency counts up to here are exact in one bf16 piece
+static_assert(CNT_WORDS * 4 <= BUF_FLOATS * 4, "the count matrix must fit inside the tile buffer it aliases");
 
 // rows of a 32x32 MFMA accumulator: register i of lane-half h holds row krow(i, h)
 __device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// ---- split-bf16 arithmetic ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+struct Split3 { bf16x8 p1, p2, p3; };
+// 8 f32 -> three bf16 fragments with x = p1 + p2 + p3 (each residual is exact in f32)
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+  u32x4 a, b, c;
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = pk_bf16(x[2 * j], x[2 * j + 1]);
+    a[j] = u;
+    r[2 * j] = x[2 * j] - __uint_as_float(u << 16);
+    r[2 * j + 1] = x[2 * j + 1] - __uint_as_float(u & 0xffff0000u);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = pk_bf16(r[2 * j], r[2 * j + 1]);
+    b[j] = u;
+    r[2 * j] -= __uint_as_float(u << 16);
+    r[2 * j + 1] -= __uint_as_float(u & 0xffff0000u);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = pk_bf16(r[2 * j], r[2 * j + 1]);
+  Split3 s;
+  s.p1 = __builtin_bit_cast(bf16x8, a);
+  s.p2 = __builtin_bit_cast(bf16x8, b);
+  s.p3 = __builtin_bit_cast(bf16x8, c);
+  return s;
+}
+
+#define HCG_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+
+// acc += a * b with both operands split: the six cross terms >= 2^-24, smallest first
+__device__ __forceinline__ void mfma_split(f32x16& acc, const Split3& a, const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) {
+  acc = HCG_MFMA(a.p3, b1, acc);
+  acc = HCG_MFMA(a.p1, b3, acc);
+  acc = HCG_MFMA(a.p2, b2, acc);
+  acc = HCG_MFMA(a.p2, b1, acc);
+  acc = HCG_MFMA(a.p1, b2, acc);
+  acc = HCG_MFMA(a.p1, b1, acc);
+}
+// acc += a * b with an EXACT one-piece a (small integers) and a split b
+__device__ __forceinline__ void mfma_exact_a(f32x16& acc, const bf16x8& a, const Split3& b) {
+  acc = HCG_MFMA(a, b.p3, acc);
+  acc = HCG_MFMA(a, b.p2, acc);
+  acc = HCG_MFMA(a, b.p1, acc);
+}
+
+// per-wave LDS.  Forward: the count matrix occupies the first CNT_WORDS words of `buf` while the tile's
+// adjacency fragments are being built, then the x tile is staged over it.  Backward: `cnt` is separate.
+struct WaveLdsF {
+  float buf[BUF_FLOATS];   // adjacency counts, then the x tile / activated output tile
+  float ldinv[TM];         // in-degree counter while the edges are scattered, then (1 + deg)^-1/2
+  int lgp[TM + 4];         // node offset of every graph of the tile (a tile holds <= TM graphs)
+};
+struct WaveLdsB {
+  float buf[BUF_FLOATS];   // dY', then x tile, then dH (for the dX transpose), then dX (wide stores)
+  int cnt[CNT_WORDS];      // C + I of the tile: cnt[dst * CS + src]
+  float ldinv[TM];
+  int lgp[TM + 4];
+};
 
 // All four tile scalars come from ONE round of (scalar) loads of the blocked plan's graph_ptr / edge_ptr.
 // Rule for every global load in this file: never guard a load with a per-lane branch (hipcc then
@@ -123,11 +193,6 @@ __device__ __forceinline__ TileInfo tile_finish(const TileRaw& w, int gpt, int l
   return ti;
 }
 
-__device__ __forceinline__ TileInfo tile_scalars(int t, int gpt, int B, const int32_t* __restrict__ graph_ptr,
-                                                 const int32_t* __restrict__ edge_ptr, int lane, int32_t* status) {
-  return tile_finish(tile_raw(t, t + 1, gpt, B, graph_ptr, edge_ptr), gpt, lane, status);
-}
-
 // per-lane index data of a tile (first 64 edges + graph offsets), loaded into registers by load() and
 // turned into the LDS count matrix by build() -- split so the NEXT tile can be in flight while the
 // current one computes.
@@ -149,18 +214,16 @@ struct TileEdges {
   }
 
   // C = I + sum_e [dst_e][src_e],  ldinv = (row sum)^-1/2 ; edges beyond the first 64 are read here
-  __device__ __forceinline__ void build(WaveLds& L, const TileInfo& ti, const int64_t* __restrict__ ei, int64_t E,
-                                        int lane, int32_t* status) const {
-    if (!(HCG_ABLATE & 16)) {
+  __device__ __forceinline__ void build(int* cnt, float* ldinv, int* lgp, const TileInfo& ti,
+                                        const int64_t* __restrict__ ei, int64_t E, int lane, int32_t* status) const {
 #pragma unroll
-      for (int j = 0; j < CNT_WORDS / 256; ++j)
-        *reinterpret_cast<int4*>(&L.cnt[(lane + 64 * j) * 4]) = make_int4(0, 0, 0, 0);
-    }
-    if (lane < TM) L.ldinv[lane] = 0.f;
-    int* degc = reinterpret_cast<int*>(L.ldinv);
-    if (lane < ti.n) L.cnt[lane * CS + lane] = 1;                       // self loop, weight 1
+    for (int j = 0; j < CNT_WORDS / 256; ++j)
+      *reinterpret_cast<int4*>(&cnt[(lane + 64 * j) * 4]) = make_int4(0, 0, 0, 0);
+    if (lane < TM) ldinv[lane] = 0.f;
+    int* degc = reinterpret_cast<int*>(ldinv);
+    if (lane < ti.n) cnt[lane * CS + lane] = 1;                         // self loop, weight 1
     const int ng = ti.g1 - ti.g0;
-    if (lane <= ng) L.lgp[lane] = gp_raw - ti.nbase;
+    if (lane <= ng) lgp[lane] = gp_raw - ti.nbase;
     for (int k0 = 0; k0 < ti.ne; k0 += 64) {
       long long s = es, d = ed;
       if (k0 > 0) {   // wave-uniform: only tiles with more than 64 edges come here
@@ -176,7 +239,7 @@ struct TileEdges {
       // an explicit (i, i) edge collapses into the unit self loop every node already has (PyG
       // add_remaining_self_loops): it is neither counted nor added
       if (live && ok && sl != dl) {
-        atomicAdd(&L.cnt[dl * CS + sl], 1);                             // ds_add_u32: exact, order-independent
+        atomicAdd(&cnt[dl * CS + sl], 1);                               // ds_add_u32: exact, order-independent
         atomicAdd(&degc[dl], 1);
       }
       if (__ballot(live && !ok) != 0ull) {                              // edge leaves its graph: ignored, flagged
@@ -185,7 +248,37 @@ struct TileEdges {
     }
     if (lane < TM) {
       const float deg = 1.0f + (float)degc[lane];
-      L.ldinv[lane] = lane < ti.n ? 1.0f / sqrtf(deg) : 0.f;
+      ldinv[lane] = lane < ti.n ? 1.0f / sqrtf(deg) : 0.f;
+    }
+  }
+};
+
+// The tile adjacency as the (exact, one-piece) A operand of the aggregation MFMAs, k-steps s = 0, 1.
+//   forward  (Y  = (C + I) H'):    A[m = r][slot j] = C[r][krow(8s + j, h)]   (k order of the H accumulators)
+//   backward (dH = (C + I)^T dY'): A[m = r][slot j] = C[16s + 8h + j][r]       (natural k order, B read from LDS)
+// Counts above CNT_EXACT (that many parallel edges between one pair of atoms) are not exact in bf16: flagged.
+struct AdjFrags {
+  bf16x8 f[2];
+  template <bool TRANSPOSED>
+  __device__ __forceinline__ void read(const int* cnt, int r, int h, int lane, int32_t* status) {
+    int worst = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 u;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k0 = TRANSPOSED ? 16 * s + 8 * h + 2 * jj : krow(8 * s + 2 * jj, h);
+        const int k1 = TRANSPOSED ? k0 + 1 : krow(8 * s + 2 * jj + 1, h);
+        const int c0 = TRANSPOSED ? cnt[k0 * CS + r] : cnt[r * CS + k0];
+        const int c1 = TRANSPOSED ? cnt[k1 * CS + r] : cnt[r * CS + k1];
+        worst = worst > c0 ? worst : c0;
+        worst = worst > c1 ? worst : c1;
+        u[jj] = pk_bf16((float)c0, (float)c1);
+      }
+      f[s] = __builtin_bit_cast(bf16x8, u);
+    }
+    if (__ballot(worst > CNT_EXACT) != 0ull) {
+      if (lane == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
     }
   }
 };
@@ -213,7 +306,6 @@ struct Stager {
       for (int it = 0; it < TM / 4; ++it) {
         int64_t row = (int64_t)nbase + it * 4 + r4;
         if (row > Nrows - 1) row = Nrows - 1;
-        if (HCG_ABLATE & 8) { v4[it] = make_float4((float)row, 1.f, 2.f, 3.f); continue; }
         v4[it] = *reinterpret_cast<const float4*>(g + (size_t)row * F + (4 * q < KPAD ? 4 * q : 0));
       }
     } else {
@@ -252,52 +344,60 @@ struct Stager {
   }
 };
 
-// acc{0,1}[TM x 64] = buf[TM x KPAD] * Wreg  (Wreg[nb][s]: B operand of k-step s, column block nb)
-template <int KPAD>
-__device__ __forceinline__ void tile_gemm(const float* buf, const float (&wreg)[2][KPAD / 2], f32x16& acc0,
-                                          f32x16& acc1, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < KPAD / 8; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(buf + r * HS + 8 * t + 4 * h);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wreg[0][4 * t + 0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wreg[1][4 * t + 0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wreg[0][4 * t + 1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wreg[1][4 * t + 1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wreg[0][4 * t + 2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wreg[1][4 * t + 2], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wreg[0][4 * t + 3], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wreg[1][4 * t + 3], acc1, 0, 0, 0);
-  }
-}
-
-// same contraction with the weight operand read from a workgroup-shared LDS image [64][KPAD + 1]
-// (used for the second layer of the stacked forward: its 64 weight registers would not fit)
-template <int KPAD>
-__device__ __forceinline__ void tile_gemm_ldsw(const float* buf, const float* wl, f32x16& acc0, f32x16& acc1, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const float* w0 = wl + r * (KPAD + 1) + 4 * h;
-  const float* w1 = wl + (32 + r) * (KPAD + 1) + 4 * h;
-#pragma unroll
-  for (int t = 0; t < KPAD / 8; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(buf + r * HS + 8 * t + 4 * h);
-    const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], w0[8 * t + u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], w1[8 * t + u], acc1, 0, 0, 0);
+// Pre-split weight image in LDS: three bf16 planes [rows][K + WPAD]; plane p at wl + p * rows * (K + WPAD).
+// Block-cooperative (every thread of the 512-thread workgroup takes part), coalesced global reads.
+//   TRANS = false: image row n, column k  <-  g[n * cols + k]   (B[k][n] = W[n][k]: the H = X W^T operand)
+//   TRANS = true : image row f, column d  <-  g[d * cols + f]   (B[d][f] = W[d][f]: the dX = dH W operand)
+// `rows_img` x `K` is the image extent (zero padded past the matrix), `g` is [grows][cols] row-major.
+template <bool TRANS>
+__device__ __forceinline__ void stage_weight_split(short* wl, int rows_img, int K, const float* __restrict__ g, int grows,
+                                                   int cols) {
+  const int ld = K + WPAD, plane = rows_img * ld;
+  const int total = TRANS ? grows * rows_img : rows_img * K;    // iterate in global-memory order where possible
+  for (int idx = threadIdx.x; idx < total; idx += WAVES * 64) {
+    int ir, ic;       // image row / column
+    float v;
+    if (TRANS) {      // idx = d * rows_img + f
+      const int d = idx / rows_img, f = idx - d * rows_img;
+      v = g[(size_t)d * cols + (f < cols ? f : cols - 1)];
+      if (f >= cols) v = 0.f;
+      ir = f;
+      ic = d;
+    } else {          // idx = n * K + k
+      const int n = idx / K, k = idx - n * K;
+      v = g[(size_t)(n < grows ? n : grows - 1) * cols + (k < cols ? k : cols - 1)];
+      if (k >= cols || n >= grows) v = 0.f;
+      ir = n;
+      ic = k;
     }
+    const unsigned u1 = pk_bf16(v, 0.f) & 0xffffu;
+    const float r1 = v - __uint_as_float(u1 << 16);
+    const unsigned u2 = pk_bf16(r1, 0.f) & 0xffffu;
+    const float r2 = r1 - __uint_as_float(u2 << 16);
+    const unsigned u3 = pk_bf16(r2, 0.f) & 0xffffu;
+    wl[ir * ld + ic] = (short)u1;
+    wl[plane + ir * ld + ic] = (short)u2;
+    wl[2 * plane + ir * ld + ic] = (short)u3;
   }
 }
 
-// Block-cooperative staging of a [rows x cols] row-major global matrix into LDS as dst[r * ld + c]
-// (zero padded to cols_pad); every thread of the 512-thread workgroup takes part.
-__device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __restrict__ g, int rows, int cols,
-                                             int cols_pad) {
-  for (int idx = threadIdx.x; idx < rows * cols_pad; idx += WAVES * 64) {
-    const int r = idx / cols_pad, c = idx - r * cols_pad;
-    const float v = g[(size_t)r * cols + (c < cols ? c : cols - 1)];
-    dst[r * ld + c] = c < cols ? v : 0.f;
+// acc{0,1}[TM x 64] += buf[TM x K] * (weight image: 64 rows n, K columns k)
+template <int K>
+__device__ __forceinline__ void tile_gemm_split(const float* buf, const short* wl, f32x16& acc0, f32x16& acc1, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int ld = K + WPAD, plane = DD * ld;
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    const float4 a0 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h);
+    const float4 a1 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h + 4);
+    const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const Split3 A = split3(xa);
+    const short* w0 = wl + r * ld + 16 * s + 8 * h;
+    const short* w1 = w0 + 32 * ld;
+    mfma_split(acc0, A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
+               *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
+    mfma_split(acc1, A, *reinterpret_cast<const bf16x8*>(w1), *reinterpret_cast<const bf16x8*>(w1 + plane),
+               *reinterpret_cast<const bf16x8*>(w1 + 2 * plane));
   }
 }
 
@@ -305,9 +405,9 @@ __device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __
 // forward:  out = LeakyReLU( Ahat (x W^T) + b ),  optional pooled epilogue emb[g] = [max, mean]
 // =====================================================================================================
 // STACK2: TWO conv layers per launch -- the first layer's output tile is already in LDS in exactly the
-// layout the next GEMM reads (the epilogue puts it there for the wide stores), the adjacency counts and
-// dinv are shared, and the second launch's prologue / tile staging / count build disappear.  The second
-// layer (64 -> 64) takes its weights from a workgroup-shared LDS image; POOL then refers to layer 2.
+// layout the next GEMM reads (the epilogue puts it there for the wide stores), the adjacency fragments and
+// dinv are shared, and the second launch's prologue / tile staging / count build disappear.  POOL then
+// refers to layer 2.
 template <int KPAD, bool VEC, bool POOL, bool STACK2>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
@@ -315,13 +415,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
     float* __restrict__ out, float* __restrict__ out2, float* __restrict__ emb, int32_t* __restrict__ status) {
-  __shared__ WaveLds lds[WAVES];
-  __shared__ float w2l[STACK2 ? DD * (DD + 1) : 4];
-  __shared__ float w1l[STACK2 ? DD * (KPAD + 1) : 4];   // stacked: layer-1 weights stay in LDS too (frees 64 VGPRs)
+  __shared__ WaveLdsF lds[WAVES];
+  __shared__ __attribute__((aligned(16))) short w1l[3 * DD * (KPAD + WPAD)];
+  __shared__ __attribute__((aligned(16))) short w2l[STACK2 ? 3 * DD * (DD + WPAD) : 8];
   STAMP_DECL
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  WaveLds& L = lds[wave];
+  WaveLdsF& L = lds[wave];
+  int* cnt = reinterpret_cast<int*>(L.buf);
   const int r = lane & 31, h = lane >> 5;
   const int stride = gridDim.x * WAVES;
   int t = blockIdx.x * WAVES + wave;
@@ -340,34 +441,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     te.load(ti, graph_ptr, ei, E, lane);
   }
 
-  // weight operand: W [64][F] -> LDS (coalesced, once per workgroup) -> 64 VGPRs per lane.
-  // B[k][j] = W[j][k]; k-step s = 4t+u <-> k = 8t + 4h + u.  LDS image [n][KPAD + 1]: lane r reads
-  // row nb*32 + r at a fixed k -> stride KPAD + 1 floats -> conflict-free.
-  float wreg[STACK2 ? 1 : 2][STACK2 ? 1 : KPAD / 2];
-  if (STACK2) {
-    stage_matrix(w1l, KPAD + 1, W, DD, F, KPAD);
-    stage_matrix(w2l, DD + 1, W2, DD, DD, DD);
-    __syncthreads();
-  } else {
-    float* wl = reinterpret_cast<float*>(&lds[0]);   // flat view of the workgroup's LDS (64*(KPAD+1) floats)
-    stage_matrix(wl, KPAD + 1, W, DD, F, KPAD);
-    __syncthreads();
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int s = 0; s < KPAD / 2; ++s) wreg[nb][s] = wl[(nb * 32 + r) * (KPAD + 1) + 8 * (s >> 2) + 4 * h + (s & 3)];
-    __syncthreads();
-  }
+  // weight operands: W [64][F] -> three bf16 planes in LDS, once per workgroup
+  stage_weight_split<false>(w1l, DD, KPAD, W, DD, F);
+  if (STACK2) stage_weight_split<false>(w2l, DD, DD, W2, DD, DD);
   float b0 = bias[r], b1 = bias[32 + r];
   float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
   // retire the bias loads HERE: left pending, their first use (in the epilogue of the tile loop) makes
   // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
+  __syncthreads();
   STAMP(0);
   int stamp_it = 0;
+  // adjacency fragments + dinv of this lane's 16 accumulator rows: read ONCE per tile into registers, shared by
+  // both layers of a stacked launch.  Order per tile: count matrix (in the tile buffer's bytes) -> fragments
+  // -> x tile staged over it.
+  AdjFrags adj;
+  float dvr[16];
   if (have) {
+    te.build(cnt, L.ldinv, L.lgp, ti, ei, E, lane, status);
+    adj.read<false>(cnt, r, h, lane, status);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
     sx.write(L.buf, F, ti.n, lane);
-    te.build(L, ti, ei, E, lane, status);
   }
   while (have) {
     STAMP(1 + 8 * stamp_it);
@@ -386,15 +481,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     }
     STAMP(2 + 8 * stamp_it);
 
-    // dinv of this lane's 16 accumulator rows and the adjacency operand: read ONCE per tile into registers
-    // (re-reading them per use cost serialized LDS round trips: the compiler cannot prove the tile stores
-    // don't alias); shared by both layers of a stacked launch
-    float dvr[16], av[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      dvr[i] = L.ldinv[krow(i, h)];
-      av[i] = (float)L.cnt[r * CS + krow(i, h)];   // A[m = r][k = krow(i, h)] of the aggregation
-    }
     f32x16 y0, y1;
 #pragma unroll
     for (int layer = 0; layer < (STACK2 ? 2 : 1); ++layer) {
@@ -402,17 +488,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       f32x16 acc0, acc1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-      if (!(HCG_ABLATE & 1)) {
-        if constexpr (STACK2) {
-          if (layer == 0) tile_gemm_ldsw<KPAD>(L.buf, w1l, acc0, acc1, lane);
-          else tile_gemm_ldsw<DD>(L.buf, w2l, acc0, acc1, lane);
-        } else {
-          tile_gemm<KPAD>(L.buf, wreg, acc0, acc1, lane);
-        }
+      if constexpr (STACK2) {
+        if (layer == 0) tile_gemm_split<KPAD>(L.buf, w1l, acc0, acc1, lane);
+        else tile_gemm_split<DD>(L.buf, w2l, acc0, acc1, lane);
+      } else {
+        tile_gemm_split<KPAD>(L.buf, w1l, acc0, acc1, lane);
       }
       if (layer == 0) STAMP(3 + 8 * stamp_it);
 
-      // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H'
+      // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H': B operand = the H' accumulators, split in
+      //      registers; slot j of k-step s <-> accumulator register 8s + j
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         acc0[i] *= dvr[i];
@@ -421,15 +506,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         y1[i] = 0.f;
       }
       if (layer == 0) STAMP(4 + 8 * stamp_it);
-      if (!(HCG_ABLATE & 2)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {                                            // B[k][j] = acc[i]
-          y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc0[i], y0, 0, 0, 0);
-          y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], acc1[i], y1, 0, 0, 0);
-        }
-      } else {
-        y0 = acc0;
-        y1 = acc1;
+      for (int s = 0; s < 2; ++s) {
+        const float h0[8] = {acc0[8 * s], acc0[8 * s + 1], acc0[8 * s + 2], acc0[8 * s + 3],
+                             acc0[8 * s + 4], acc0[8 * s + 5], acc0[8 * s + 6], acc0[8 * s + 7]};
+        const float h1[8] = {acc1[8 * s], acc1[8 * s + 1], acc1[8 * s + 2], acc1[8 * s + 3],
+                             acc1[8 * s + 4], acc1[8 * s + 5], acc1[8 * s + 6], acc1[8 * s + 7]};
+        mfma_exact_a(y0, adj.f[s], split3(h0));
+        mfma_exact_a(y1, adj.f[s], split3(h1));
       }
       if (layer == 0) STAMP(6 + 8 * stamp_it);
 
@@ -464,11 +548,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 #pragma unroll
         for (int it = 0; it < TM / 4; ++it) {
           const int row = it * 4 + r4 < ti.n ? it * 4 + r4 : ti.n - 1;
-          if (!(HCG_ABLATE & 4)) {
-            *reinterpret_cast<float4*>(dst + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
-          } else if (ov[it].x == 12345.678f) {
-            dst[0] = ov[it].y;
-          }
+          *reinterpret_cast<float4*>(dst + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
         }
       }
     }
@@ -487,13 +567,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         s1 += __shfl_xor(s1, 32, 64);
         if (h == 0) {
           const int n = ge - gb;
-          const float cnt = (float)(n > 0 ? n : 1);
+          const float cntf = (float)(n > 0 ? n : 1);
           if (n <= 0) { m0 = 0.f; m1 = 0.f; }
           float* e = emb + (size_t)g * 2 * DD;
           e[r] = m0;
           e[32 + r] = m1;
-          e[DD + r] = s0 / cnt;
-          e[DD + 32 + r] = s1 / cnt;
+          e[DD + r] = s0 / cntf;
+          e[DD + 32 + r] = s1 / cntf;
         }
       }
     }
@@ -510,10 +590,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       t = tn;
       ti = tin;
       STAMP(56);
-      if (!(HCG_ABLATE & 32)) sxn.write(L.buf, F, ti.n, lane);
-      else if (sxn.v4[0].x == 12345.678f) L.buf[lane] = sxn.v4[1].y + sxn.v4[2].x + sxn.v4[3].x + sxn.v4[4].x + sxn.v4[5].x + sxn.v4[6].x + sxn.v4[7].x;
+      ten.build(cnt, L.ldinv, L.lgp, ti, ei, E, lane, status);
+      adj.read<false>(cnt, r, h, lane, status);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
       STAMP(57);
-      ten.build(L, ti, ei, E, lane, status);
+      sxn.write(L.buf, F, ti.n, lane);
       STAMP(58);
     }
   }
@@ -534,11 +616,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
     float* __restrict__ dx, float* __restrict__ partials, int32_t* __restrict__ status) {
-  __shared__ WaveLds lds[WAVES];
-  __shared__ float wlds[NEEDS_DX ? DD * KPAD : 4];   // dx operand W [d][f], shared by the 8 waves
+  __shared__ WaveLdsB lds[WAVES];
+  // dx operand: image row f, column d <- W[d][f], three bf16 planes, shared by the 8 waves
+  __shared__ __attribute__((aligned(16))) short wtl[NEEDS_DX ? 3 * KPAD * (DD + WPAD) : 8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  WaveLds& L = lds[wave];
+  WaveLdsB& L = lds[wave];
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   constexpr int NBF = KPAD / 32;  // column blocks of dW (input-feature dimension)
   const int stride = gridDim.x * WAVES;
@@ -560,7 +643,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   }
 
   if (NEEDS_DX) {
-    stage_matrix(wlds, KPAD, W, DD, F, KPAD);
+    stage_weight_split<true>(wtl, KPAD, DD, W, DD, F);
     __syncthreads();
   }
 
@@ -574,7 +657,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   while (have) {
-    te.build(L, ti, ei, E, lane, status);
+    te.build(L.cnt, L.ldinv, L.lgp, ti, ei, E, lane, status);
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> buf (rows >= n zero); A / dA stay in registers
     float4 dy[TM / 4];
@@ -587,8 +670,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         const float4 gmx = *reinterpret_cast<const float4*>(emb + (size_t)g * 2 * DD + 4 * q);
         const float4 dmx = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + 4 * q);
         float4 dmean = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + DD + 4 * q);
-        const float cnt = (float)(ge - gb);
-        dmean = make_float4(dmean.x / cnt, dmean.y / cnt, dmean.z / cnt, dmean.w / cnt);
+        const float cntf = (float)(ge - gb);
+        dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
         float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int it = 0; it < TM / 4; ++it) {
@@ -634,8 +717,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       *reinterpret_cast<float4*>(L.buf + i * HS + 4 * q) = d;
     }
 
-    // next tile of this wave: its A / dA rows, edges and (one tile further) scalars go in flight now --
-    // the registers that held this tile's A / dA are free again -- and land while steps 2-4 compute
+    // next tile of this wave: scalars one tile further ahead (the row loads wait until the accumulators leave room:
+    // measured with the loads here, the dx / pooled variants spill 24-89 VGPRs and run 20-30 % SLOWER)
     const int tn = t + stride;
     const bool have_next = tn < num_tiles;
     const TileRaw raw_cur = raw_next;
@@ -643,33 +726,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     TileInfo tin;
     Stager<DD, true> san, sdn;
     TileEdges ten;
-    // (measured: with the prefetch on, the dx / pooled variants spill 24-89 VGPRs and run 20-30 % SLOWER;
-    //  it stays off until the accumulators leave room -- tools/probe_fused.hip -DHCG_BWD_PREFETCH=1)
-#ifndef HCG_BWD_PREFETCH
-#define HCG_BWD_PREFETCH 0
-#endif
-    if (HCG_BWD_PREFETCH && have_next) {
-      tin = tile_finish(raw_cur, gpt, lane, status);
-      san.load(a_out, DD, N, tin.nbase, tin.n, lane);
-      if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
-      ten.load(tin, graph_ptr, ei, E, lane);
-    }
 
-    // x rows: issued now (the A / dA registers are free again), consumed after dH
-    Stager<KPAD, VEC> sx;
-    constexpr bool EARLY_X = false;   // registers go to the next-tile prefetch instead: x is loaded right before its use
-    if (EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
-
-    // ---- 2. dH = dinv (.) ( (C + I)^T dY' ):  A[m = j][k = i] = cnt[i][j],  B[k = i][col] = dY'[i][col]
+    // ---- 2. dH = dinv (.) ( (C + I)^T dY' ):  A[m = j][k = i] = cnt[i][j] (exact),  B[k = i][col] = dY'[i][col] (split)
+    AdjFrags adj;
+    adj.read<true>(L.cnt, r, h, lane, status);
     f32x16 dh0, dh1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dh0[i] = 0.f; dh1[i] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < TM / 2; ++s) {
-      const int k = 2 * s + h;
-      const float a = (float)L.cnt[k * CS + r];
-      dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + r], dh0, 0, 0, 0);
-      dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.buf[k * HS + 32 + r], dh1, 0, 0, 0);
+    for (int s = 0; s < 2; ++s) {
+      float g0[8], g1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        g0[j] = L.buf[(16 * s + 8 * h + j) * HS + r];
+        g1[j] = L.buf[(16 * s + 8 * h + j) * HS + 32 + r];
+      }
+      mfma_exact_a(dh0, adj.f[s], split3(g0));
+      mfma_exact_a(dh1, adj.f[s], split3(g1));
     }
     {
       float dvr[16];
@@ -679,22 +752,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int i = 0; i < 16; ++i) { dh0[i] *= dvr[i]; dh1[i] *= dvr[i]; }
     }
 
-    // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (k-step i <-> node krow(i, h))
-    if (!EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
+    // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (slot j of k-step s <-> node krow(8s + j, h)),
+    //         B[k = node][f] read down the columns of the x tile
+    Stager<KPAD, VEC> sx;
+    sx.load(x, F, N, ti.nbase, ti.n, lane);
     sx.write(L.buf, F, ti.n, lane);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int node = krow(i, h);
+    for (int s = 0; s < 2; ++s) {
+      const float a0[8] = {dh0[8 * s], dh0[8 * s + 1], dh0[8 * s + 2], dh0[8 * s + 3],
+                           dh0[8 * s + 4], dh0[8 * s + 5], dh0[8 * s + 6], dh0[8 * s + 7]};
+      const float a1[8] = {dh1[8 * s], dh1[8 * s + 1], dh1[8 * s + 2], dh1[8 * s + 3],
+                           dh1[8 * s + 4], dh1[8 * s + 5], dh1[8 * s + 6], dh1[8 * s + 7]};
+      const Split3 A0 = split3(a0), A1 = split3(a1);
 #pragma unroll
       for (int nb = 0; nb < NBF; ++nb) {
-        const float b = L.buf[node * HS + nb * 32 + r];
-        dw[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(dh0[i], b, dw[0][nb], 0, 0, 0);
-        dw[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(dh1[i], b, dw[1][nb], 0, 0, 0);
+        float xb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xb[j] = L.buf[krow(8 * s + j, h) * HS + nb * 32 + r];
+        const Split3 Bx = split3(xb);
+        mfma_split(dw[0][nb], A0, Bx.p1, Bx.p2, Bx.p3);
+        mfma_split(dw[1][nb], A1, Bx.p1, Bx.p2, Bx.p3);
       }
     }
 
     // ---- 4. dx = dH W: dH -> buf as [node][d] (the contraction runs over the accumulator's LANE
-    //         dimension, so this one needs the LDS transpose), B[k = d][j = f] = W[d][f] from LDS
+    //         dimension, so this one needs the LDS transpose), B[k = d][j = f] = W[d][f] from the pre-split image
     if (NEEDS_DX) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -707,16 +789,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dxa[nb][i] = 0.f;
+      constexpr int ld = DD + WPAD, plane = KPAD * ld;
 #pragma unroll
-      for (int t8 = 0; t8 < DD / 8; ++t8) {
-        const float4 a = *reinterpret_cast<const float4*>(L.buf + r * HS + 8 * t8 + 4 * h);
-        const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int s = 0; s < DD / 16; ++s) {
+        const float4 a0 = *reinterpret_cast<const float4*>(L.buf + r * HS + 16 * s + 8 * h);
+        const float4 a1 = *reinterpret_cast<const float4*>(L.buf + r * HS + 16 * s + 8 * h + 4);
+        const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const Split3 A = split3(xa);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int d = 8 * t8 + 4 * h + u;
-#pragma unroll
-          for (int nb = 0; nb < NBF; ++nb)
-            dxa[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wlds[d * KPAD + nb * 32 + r], dxa[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBF; ++nb) {
+          const short* w0 = wtl + (nb * 32 + r) * ld + 16 * s + 8 * h;
+          mfma_split(dxa[nb], A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
+                     *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
         }
       }
       if (VEC) {   // F == KPAD: rows are whole float4 groups -> transpose through LDS, dwordx4 stores
@@ -755,12 +839,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 
     have = have_next;
     if (have_next) {
-      if (!HCG_BWD_PREFETCH) {
-        tin = tile_finish(raw_cur, gpt, lane, status);
-        san.load(a_out, DD, N, tin.nbase, tin.n, lane);
-        if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
-        ten.load(tin, graph_ptr, ei, E, lane);
-      }
+      tin = tile_finish(raw_cur, gpt, lane, status);
+      san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+      if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
+      ten.load(tin, graph_ptr, ei, E, lane);
       t = tn;
       ti = tin;
       sa = san;
@@ -773,6 +855,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   //      view of the LDS) and publish one partial slab
   constexpr int SLABF = DD * KPAD + DD;
   constexpr int PER_T = (SLABF + WAVES * 64 - 1) / (WAVES * 64);
+  static_assert(sizeof(WaveLdsB) * WAVES >= 4 * SLABF * sizeof(float), "wave-combine scratch must fit in the tile buffers");
   float* flat = reinterpret_cast<float*>(&lds[0]);
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 16));
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 32));
