@@ -7,8 +7,9 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
     -> sqrt(MSE) loss (reference utils/utils_model.py:64)
     -> backward (all weight gradients)
     -> [N > 1] RCCL all-reduce of the flat gradient buffer.
-The optimiser is excluded from `value` (the metric is "fwd+bwd", and so is the CPU baseline's
-step); `with_optimizer` reports the same loop with the reference's Adam step added.
+    -> Adam update (the reference's optimiser, model/networks.py:38).
+`value` times ALL of it (hipGraph replay of the captured step when capture succeeds); `fwd_bwd_only` reports the
+same step without the update, and the CPU baseline runs the same full step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C5|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -115,10 +116,11 @@ def cpu_baseline(cfg_name, num_graphs, steps):
     cfg = synth.CONFIGS[cfg_name]
     model = H.make_network("GCN", H.default_options(embedding_dim=cfg["hidden"]), cfg["feat"])
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p, opt = gcn_oracle.make_train_state(params)
     ts = []
     for i in range(3 + steps):
         t0 = time.perf_counter()
-        gcn_oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+        gcn_oracle.train_step(p, opt, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
         ts.append(time.perf_counter() - t0)
         if i % 5 == 0:
             log(f"cpu_baseline step {i}: {ts[-1] * 1e3:.1f} ms")
@@ -133,7 +135,7 @@ def cpu_baseline(cfg_name, num_graphs, steps):
     except OSError:
         pass
     return {"value": sb.num_graphs / med, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed fwd+bwd steps (median, 3 warm-up) of the full {cfg_name} batch "
+            "sample": f"{steps} timed training steps (fwd + sqrt(MSE) + bwd + Adam; median, 3 warm-up) of the full {cfg_name} batch "
                       f"({sb.num_graphs} graphs) with the torch CPU restatement of the reference's PyG scatter path, "
                       f"{cores} threads; PyG itself is not installable here",
             "ms_per_step": med * 1e3, "cpu_model": model_name}
@@ -166,12 +168,20 @@ def main():
     dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
     y2 = y.unsqueeze(1)
 
-    def step(with_opt=False):
-        if args.forward_only:
-            return step_body()
+    from hcatgnet_amd.train import FusedTrainStep
+
+    def make_batch():      # a fresh Batch per step: its plan (graph_ptr / edge_ptr from the int64 inputs) is rebuilt every step
+        return H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+
+    fused_ok = (not args.forward_only) and FusedTrainStep.unsupported_reason(model, make_batch()) is None
+    # the training step of the reference's loop (utils/utils_model.py:60-68) WITH the Adam update; `fwdbwd` stops
+    # after the backward (gradients only), for the secondary "fwd+bwd only" figure
+    trainer = FusedTrainStep(model, optimizer_step=True) if fused_ok else None
+    fwdbwd = FusedTrainStep(model, optimizer_step=False) if fused_ok else None
+
+    def autograd_step(with_opt=True):
         model.optimizer.zero_grad(set_to_none=True)
-        b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
-        out = model(b)                                   # plan build + forward
+        out = model(make_batch())                        # plan build + forward
         loss = torch.sqrt(model.loss(out, y2))
         loss.backward()
         if dp is not None:
@@ -180,55 +190,58 @@ def main():
             model.optimizer.step()
         return loss
 
-    graph = None
-    static_grads = []
+    def forward_step():
+        with torch.no_grad():
+            return model(make_batch())
 
-    def capture():
-        """Capture plan build + forward + loss + backward (everything the library enqueues; no host
-        sync inside) into ONE hipGraph; the RCCL all-reduce stays an eager call after each replay."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step_body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        model.optimizer.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step_body()
-        static_grads.clear()
-        if not args.forward_only:
-            static_grads.extend(p.grad for p in model.parameters())   # the tensors every replay rewrites
-        return g
-
-    def step_body():
+    def eager_step(with_opt=True):
         if args.forward_only:
-            with torch.no_grad():
-                b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
-                return model(b)
-        model.optimizer.zero_grad(set_to_none=True)
-        b = H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
-        out = model(b)
-        loss = torch.sqrt(model.loss(out, y2))
-        loss.backward()
-        return loss
+            return forward_step()
+        if not fused_ok:
+            return autograd_step(with_opt)
+        return (trainer if with_opt else fwdbwd)(make_batch())
 
-    def graphed_step(with_opt=False):
-        graph.replay()
-        if dp is not None:
-            dp.reduce_gradients(grads=static_grads)
-        if with_opt:
-            model.optimizer.step()
+    replay = {}
 
-    def timed(k, with_opt=False, use_graph=False):
-        fn = graphed_step if use_graph else step
+    def capture_all():
+        """Everything the step enqueues (plan build, forward, head with loss, backward, slab reduction, Adam) goes
+        into hipGraphs; the RCCL all-reduce stays an eager call between the backward graph and the update graph."""
+        if args.forward_only or not fused_ok:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    forward_step() if args.forward_only else autograd_step(False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if not args.forward_only:
+                model.optimizer.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                forward_step() if args.forward_only else autograd_step(False)
+            grads = [] if args.forward_only else [p.grad for p in model.parameters()]
+
+            def run(with_opt=True):
+                g.replay()
+                if dp is not None:
+                    dp.reduce_gradients(grads=grads)
+                if with_opt and not args.forward_only:
+                    model.optimizer.step()
+            replay["full"] = run
+            replay["fwdbwd"] = lambda: run(False)
+            return
+        trainer.capture(make_batch)
+        fwdbwd.capture(make_batch)
+        replay["full"] = trainer.replay
+        replay["fwdbwd"] = fwdbwd.replay
+
+    def timed(k, fn):
         if world > 1:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            fn(with_opt)
+            fn()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier(device_ids=[local_rank])
@@ -239,28 +252,34 @@ def main():
             dt = float(t.item())
         return dt
 
-    log(f"inputs resident: N={N} E={E} B={B} F={F} D={D}")
+    log(f"inputs resident: N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
     for _ in range(args.warmup):
-        step()
+        eager_step()
     torch.cuda.synchronize()
     log("warm-up done")
 
     launch_mode, graph_err = "eager", None
     if not args.no_graph:
         try:
-            graph = capture()
+            if world > 1 and fused_ok:          # the exchange sits between backward and update: two graphs per step
+                trainer.grad_sync = fwdbwd.grad_sync = (lambda flat: None)
+            capture_all()                       # before RCCL comes up: no collective activity while a stream is capturing
             launch_mode = "hipgraph"
-            log("step captured into a hipGraph")
+            log("step captured into hipGraphs")
         except Exception as exc:  # report, never hide: the eager number stands
-            graph, graph_err = None, f"{type(exc).__name__}: {exc}"
+            replay.clear()
+            graph_err = f"{type(exc).__name__}: {exc}"
             log(f"graph capture failed, keeping eager launches: {graph_err}")
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-        dp = DataParallelGCN(model)           # broadcasts rank-0 weights (in place: the graph sees them)
+        dp = DataParallelGCN(model)           # broadcasts rank-0 weights (in place: the graphs see them)
+        if fused_ok:
+            trainer.grad_sync = dp.reduce_flat
+            fwdbwd.grad_sync = dp.reduce_flat
         for _ in range(3):
-            step()
+            eager_step()
         log(f"RCCL process group up: world {world}")
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
@@ -268,22 +287,27 @@ def main():
     timer = EntryTimer(lib, entry)
     timer.install()
     timer.enabled = True
-    dt = timed(args.steps)
+    dt = timed(args.steps, eager_step)
     timer.enabled = False
     k_ms, k_calls = timer.mean_ms(args.steps)
     timer.uninstall()
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
-    dt_eager = timed(args.steps)
-    log(f"timed eager: {dt_eager / args.steps * 1e3:.3f} ms/step")
-    dt_opt = timed(args.steps, with_opt=not args.forward_only)
-    log(f"timed eager with Adam: {dt_opt / args.steps * 1e3:.3f} ms/step")
-    dt_best = dt_eager
-    if graph is not None:
+    dt_eager = timed(args.steps, eager_step)
+    log(f"timed eager (full step): {dt_eager / args.steps * 1e3:.3f} ms/step")
+    dt_best, dt_fb = dt_eager, None
+    if "full" in replay:
         for _ in range(max(3, args.warmup // 2)):
-            graphed_step()
-        dt_graph = timed(args.steps, use_graph=True)
-        log(f"timed hipGraph replay: {dt_graph / args.steps * 1e3:.3f} ms/step")
+            replay["full"]()
+        dt_graph = timed(args.steps, replay["full"])
+        log(f"timed hipGraph replay (full step): {dt_graph / args.steps * 1e3:.3f} ms/step")
         dt_best = dt_graph
+        if not args.forward_only:
+            for _ in range(3):
+                replay["fwdbwd"]()
+            dt_fb = timed(args.steps, replay["fwdbwd"])
+            log(f"timed hipGraph replay (fwd+bwd only, no update): {dt_fb / args.steps * 1e3:.3f} ms/step")
+    elif not args.forward_only:
+        dt_fb = timed(args.steps, lambda: eager_step(False))
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(v for k, v in bd.items() if not args.forward_only or k.endswith("_fwd") or k == "csr_build")
@@ -318,8 +342,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {B} synthetic graphs/GPU x {N // B} atoms x {E // B} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
-                                   f"full fwd+bwd step incl. per-step CSR/gcn_norm build and sqrt(MSE) loss; "
-                                   f"launch={launch_mode}",
+                                   f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
+                                   f"{'RCCL all-reduce, ' if world > 1 else ''}Adam update; launch={launch_mode}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -329,8 +353,11 @@ def main():
             "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "breakdown": bd},
-            "with_optimizer": {"value": world * B * args.steps / dt_opt, "unit": "graphs/s",
-                               "ms_per_step": dt_opt / args.steps * 1e3, "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), eager"},
+            "fwd_bwd_only": None if dt_fb is None else {"value": world * B * args.steps / dt_fb, "unit": "graphs/s",
+                                                        "ms_per_step": dt_fb / args.steps * 1e3,
+                                                        "note": "same step without the Adam update (gradients only)"},
+            "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), inside the timed step",
+            "step_path": "FusedTrainStep (no autograd)" if fused_ok else "autograd",
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3, "graph_capture_error": graph_err,
         }

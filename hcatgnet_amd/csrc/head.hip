@@ -1,0 +1,354 @@
+// Regression head, forward + loss + backward in ONE launch (SURVEY rows a10, a12 and their part of a11; f2):
+//     z    = LeakyReLU(emb W0^T + b0)            [B, 2D] -> [B, D]        reference model/gcn.py:36-45, 70-71
+//     out  = z W1^T + b1                         [B, D]  -> [B, C]
+//     mse  = mean((out - y)^2) ; loss = sqrt(mse) reference utils/utils_model.py:64 (`torch.sqrt(model.loss(out, y))`)
+//     dout = dloss/dout ; dz, demb, dW0, db0, dW1, db1   (`loss.backward()`, utils/utils_model.py:65, upstream grad 1)
+// As separate launches (readout fwd, mse fwd, sqrt, three torch kernels of sqrt's backward, mse bwd, readout bwd)
+// this dependent chain of eight tiny kernels cost ~39 us of a 132 us training step: pure launch latency around
+// 67 MFLOP.  Here one kernel walks the chain; the only global dependence (every graph's gradient needs the batch
+// loss) is a grid barrier in the middle: per-workgroup partial sums of squared errors -> sense-reversing barrier
+// on two device words -> every workgroup adds the partials in the same fixed order (bitwise reproducible loss).
+// One workgroup (4 waves) per 32-graph tile; the tile's emb / z / (out - y) stay in LDS across the barrier.
+// The grid never exceeds the CU count, so all workgroups are co-resident (the barrier cannot starve).
+// Contractions on v_mfma_f32_32x32x2_f32 (exact f32): the head is latency-bound, not MFMA-bound.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RD = 64;            // hidden width
+constexpr int RK = 2 * RD;        // pooled embedding width
+constexpr int RT = 32;            // graphs per tile
+constexpr int ES = RK + 4;        // LDS stride of the emb tile
+constexpr int ZS = RD + 4;        // LDS stride of the z / dz tile
+constexpr int WS0 = RK + 1;       // LDS stride of the W0 image [64][128]
+constexpr int HW = 4;             // waves per workgroup
+constexpr int RCMAX = 8;
+// slab layout per WORKGROUP (same as readout.hip): dW0 [RD][RK] | db0 [RD] | dW1 [C][RD] | db1 [C]  (C padded to RCMAX)
+constexpr int SLAB = RD * RK + RD + RCMAX * RD + RCMAX;
+constexpr int MAXGRID = 256;
+
+__device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+struct HeadLds {
+  float w0[RD * WS0];            // W0 [d][k]
+  float e[RT * ES];              // emb tile
+  float z[RT * ZS];              // z tile, later dz
+  float part[2][RT * 33];        // K-half partial sums of the forward GEMM (per column block)
+  float diff[RT][RCMAX];         // out - y, later dout
+  float w1[RCMAX * RD];
+  float red[HW * 64];
+  float bcast[4];
+};
+
+// grid barrier: `sync[0]` = arrival counter (returns to 0), `sync[1]` = generation.  Both zero before the
+// first launch ever; every launch leaves the counter at 0 and the generation one higher.
+__device__ __forceinline__ void grid_barrier(int* sync, int nblocks) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int gen = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();                                                             // release this block's partial
+    const int prev = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == nblocks - 1) {
+      __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// stage rows [g0, g0 + n) of a [B, W] matrix into dst[row * ld + c], rows >= n zero (all 256 threads, float4)
+template <int W>
+__device__ __forceinline__ void stage_rows(float* dst, int ld, const float* __restrict__ src, int g0, int n, int B) {
+  constexpr int PER_ROW = W / 4, ITER = RT * PER_ROW / (HW * 64);
+  float4 v[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = threadIdx.x + it * HW * 64, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+    int g = g0 + row;
+    if (g > B - 1) g = B - 1;
+    v[it] = *reinterpret_cast<const float4*>(src + (size_t)g * W + 4 * c4);
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = threadIdx.x + it * HW * 64, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+    if (row >= n) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dst + row * ld + 4 * c4) = v[it];
+  }
+}
+
+__global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ emb, const float* __restrict__ y,
+                                                     const float* __restrict__ W0, const float* __restrict__ b0,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1, int B, int C,
+                                                     float slope, int rmse, float* __restrict__ z, float* __restrict__ out,
+                                                     float* __restrict__ loss, float* __restrict__ demb,
+                                                     float* __restrict__ slabs, float* __restrict__ sse_part,
+                                                     int* __restrict__ sync) {
+  __shared__ HeadLds L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles = (B + RT - 1) / RT;
+  const int nblk = gridDim.x;
+
+  // weights -> LDS once (coalesced)
+  for (int idx = threadIdx.x; idx < RD * RK; idx += HW * 64) L.w0[(idx / RK) * WS0 + (idx % RK)] = W0[idx];
+  for (int idx = threadIdx.x; idx < RCMAX * RD; idx += HW * 64) L.w1[idx] = idx < C * RD ? W1[idx] : 0.f;
+  const int nb = wave & 1, kh = wave >> 1;              // forward: output column block / K half of this wave
+  const float bz = b0[nb * 32 + r];
+
+  // ---------------------------------------------------------------- phase 1: forward + squared error
+  float sse = 0.f;                                      // thread-private partial, fixed tile order
+  int staged = -1;
+  for (int t = blockIdx.x; t < tiles; t += nblk) {
+    const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
+    __syncthreads();                                    // previous tile's readers are done (also orders the weight staging)
+    stage_rows<RK>(L.e, ES, emb, g0, n, B);
+    __syncthreads();
+    staged = t;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int t8 = 0; t8 < RK / 16; ++t8) {              // this wave's K half: k = 64 kh + 8 t8 + 4h + u
+      const int k0 = 64 * kh + 8 * t8 + 4 * h;
+      const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + k0);
+      const float* wrow = L.w0 + (nb * 32 + r) * WS0 + k0;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wrow[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wrow[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wrow[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L.part[nb][krow(i, h) * 33 + r] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = krow(i, h);
+        const float v = hcg_leaky((acc[i] + L.part[nb][row * 33 + r]) + bz, slope);
+        L.z[row * ZS + nb * 32 + r] = v;
+        if (row < n) z[(size_t)(g0 + row) * RD + nb * 32 + r] = v;
+      }
+    }
+    __syncthreads();
+    {   // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y      (thread = (row, c))
+      const int row = threadIdx.x >> 3, c = threadIdx.x & 7;
+      float d = 0.f;
+      if (c < C && row < n) {
+        float s = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < RD; ++j) s += L.z[row * ZS + j] * L.w1[c * RD + j];
+        s += b1[c];
+        out[(size_t)(g0 + row) * C + c] = s;
+        d = s - y[(size_t)(g0 + row) * C + c];
+        sse += d * d;
+      }
+      L.diff[row][c] = d;
+    }
+  }
+  // block partial of the squared error: lanes -> wave (fixed xor tree) -> block (fixed order)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sse += __shfl_xor(sse, off, 64);
+  if (lane == 0) L.red[wave] = sse;
+  __syncthreads();
+  if (threadIdx.x == 0) sse_part[blockIdx.x] = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
+
+  grid_barrier(sync, nblk);
+
+  // ---------------------------------------------------------------- phase 2: loss, dout, backward
+  if (wave == 0) {                                     // every workgroup adds the same partials in the same order
+    float s = 0.f;
+    for (int b = lane; b < nblk; b += 64) s += __hip_atomic_load(&sse_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      const float mse = s / ((float)B * (float)C);
+      const float lv = rmse ? sqrtf(mse) : mse;
+      L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
+      if (blockIdx.x == 0) { loss[0] = lv; loss[1] = mse; }
+    }
+  }
+  __syncthreads();
+  const float gscale = L.bcast[0];
+
+  const int q = lane & 15, r4 = lane >> 4;
+  const int cb = wave;                                 // backward: this wave's 32-column block of the 128-wide embedding
+  f32x16 dw0[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dw0[mb][i] = 0.f;
+  float4 db0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dw1[RCMAX];
+  float db1[RCMAX];
+#pragma unroll
+  for (int c = 0; c < RCMAX; ++c) { dw1[c] = make_float4(0.f, 0.f, 0.f, 0.f); db1[c] = 0.f; }
+
+  for (int t = blockIdx.x; t < tiles; t += nblk) {
+    const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
+    if (t != staged) {                                 // more tiles than workgroups: bring the tile back (block-uniform)
+      __syncthreads();
+      stage_rows<RK>(L.e, ES, emb, g0, n, B);
+      stage_rows<RD>(L.z, ZS, z, g0, n, B);
+      {
+        const int row = threadIdx.x >> 3, c = threadIdx.x & 7;
+        float d = 0.f;
+        if (c < C && row < n) d = out[(size_t)(g0 + row) * C + c] - y[(size_t)(g0 + row) * C + c];
+        L.diff[row][c] = d;
+      }
+      __syncthreads();
+      staged = t;
+    }
+    // 1. dz = (dout W1) * leaky'(z) -> L.z ; db0, dW1, db1 partial sums.  Two (row, 4-column) slots per thread.
+    float4 dzv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + (threadIdx.x >> 4);
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n) {
+        const float4 zz = *reinterpret_cast<const float4*>(L.z + row * ZS + 4 * q);
+#pragma unroll
+        for (int c = 0; c < RCMAX; ++c) {
+          if (c < C) {
+            const float go = gscale * L.diff[row][c];
+            const float4 w = *reinterpret_cast<const float4*>(L.w1 + c * RD + 4 * q);
+            d.x += go * w.x; d.y += go * w.y; d.z += go * w.z; d.w += go * w.w;
+            dw1[c].x += go * zz.x; dw1[c].y += go * zz.y; dw1[c].z += go * zz.z; dw1[c].w += go * zz.w;
+            if (q == 0) db1[c] += go;
+          }
+        }
+        d.x *= hcg_leaky_grad(zz.x, slope); d.y *= hcg_leaky_grad(zz.y, slope);
+        d.z *= hcg_leaky_grad(zz.z, slope); d.w *= hcg_leaky_grad(zz.w, slope);
+        db0.x += d.x; db0.y += d.y; db0.z += d.z; db0.w += d.w;
+      }
+      dzv[it] = d;
+    }
+    __syncthreads();                                   // every read of z is done
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + (threadIdx.x >> 4);
+      *reinterpret_cast<float4*>(L.z + row * ZS + 4 * q) = dzv[it];
+    }
+    __syncthreads();
+    // 2. dW0[:, cb] += dz^T emb[:, cb]   (K = graph rows)
+#pragma unroll
+    for (int s = 0; s < RT / 2; ++s) {
+      const int row = 2 * s + h;
+      const float bv = L.e[row * ES + cb * 32 + r];
+      dw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + r], bv, dw0[0], 0, 0, 0);
+      dw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + 32 + r], bv, dw0[1], 0, 0, 0);
+    }
+    // 3. demb[:, cb] = dz W0[:, cb]
+    f32x16 de;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) de[i] = 0.f;
+#pragma unroll
+    for (int t8 = 0; t8 < RD / 8; ++t8) {
+      const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * t8 + 4 * h);
+      const int d0 = 8 * t8 + 4 * h;
+      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, L.w0[(d0 + 0) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, L.w0[(d0 + 1) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, L.w0[(d0 + 2) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = krow(i, h);
+      if (row < n) demb[(size_t)(g0 + row) * RK + cb * 32 + r] = de[i];
+    }
+  }
+
+  // ---------------------------------------------------------------- one slab per workgroup
+  float* slab = slabs + (size_t)blockIdx.x * SLAB;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) slab[(mb * 32 + krow(i, h)) * RK + cb * 32 + r] = dw0[mb][i];
+  // db0 / dW1 / db1: thread (rowgroup = threadIdx >> 4, q) holds partial sums for columns 4q..4q+3; combine the four
+  // row groups of a wave by shuffles, the four waves through LDS -- all in a fixed order
+  auto fold = [](float4 v) {
+    v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+    return v;
+  };
+  __syncthreads();
+  constexpr int SMALL = RD + RCMAX * RD + RCMAX;       // db0 | dW1 | db1
+  float* scratch = L.e;                                // [HW][SMALL + 8]: the emb tile is dead
+  {
+    float* mine = scratch + wave * (SMALL + 8);
+    db0 = fold(db0);
+    if (r4 == 0) *reinterpret_cast<float4*>(mine + 4 * q) = db0;
+#pragma unroll
+    for (int c = 0; c < RCMAX; ++c) {
+      const float4 v = fold(dw1[c]);
+      if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
+      float sc = db1[c];                               // lanes with q == 0 hold the partial sums (4 of them)
+      sc += __shfl_xor(sc, 16, 64);
+      sc += __shfl_xor(sc, 32, 64);
+      if (lane == 0) mine[RD + RCMAX * RD + c] = sc;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < SMALL; idx += HW * 64)
+    slab[RD * RK + idx] = ((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx];
+}
+
+int head_grid(int64_t B) {
+  int dev = 0, cus = MAXGRID;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  if (cus > MAXGRID) cus = MAXGRID;
+  int grid = (int)((B + RT - 1) / RT);
+  if (grid > cus) grid = cus;
+  return grid < 1 ? 1 : grid;
+}
+
+}  // namespace
+
+extern "C" int hcg_head_supported(int64_t D, int64_t C) { return (D == RD && C >= 1 && C <= RCMAX) ? 1 : 0; }
+
+// workspace: [grid][SLAB] gradient slabs, then [MAXGRID] squared-error partials
+extern "C" size_t hcg_head_workspace_bytes(int64_t B) {
+  return hcg_align_up((size_t)head_grid(B) * SLAB * sizeof(float), 256) + MAXGRID * sizeof(float) + 256;
+}
+
+extern "C" int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
+                                const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse, float* z,
+                                float* out, float* loss, float* demb, void* workspace, size_t workspace_bytes,
+                                int32_t* sync, hcg_stream_t stream) {
+  if (!hcg_head_supported(D, C)) return HCG_ERR_UNSUPPORTED;
+  if (B <= 0 || !emb || !y || !W0 || !b0 || !W1 || !b1 || !z || !out || !loss || !demb || !workspace || !sync)
+    return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
+  const int grid = head_grid(B);
+  float* slabs = (float*)workspace;
+  float* part = (float*)((char*)workspace + hcg_align_up((size_t)grid * SLAB * sizeof(float), 256));
+  hipLaunchKernelGGL(k_head, dim3(grid), dim3(HW * 64), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C, slope,
+                     rmse, z, out, loss, demb, slabs, part, (int*)sync);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+extern "C" int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, float* dW0,
+                                   float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
+  if (B <= 0 || C < 1 || C > RCMAX || !dW0 || !db0 || !dW1 || !db1 || !job || !workspace) return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
+  job->slabs = (const float*)workspace;
+  job->nslabs = head_grid(B);
+  job->slab_floats = SLAB;
+  job->nseg = 4;
+  job->reserved = 0;
+  job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
+  job->seg[1] = hcg_reduce_seg{RD * RK, RD, 1, 1, db0};
+  job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};
+  job->seg[3] = hcg_reduce_seg{RD * RK + RD + RCMAX * RD, (int32_t)C, 1, 1, db1};
+  return HCG_OK;
+}

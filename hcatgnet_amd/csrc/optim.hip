@@ -37,3 +37,46 @@ extern "C" int hcg_adam_step(float* param, const float* grad, float* exp_avg, fl
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
+
+namespace {
+
+// step count and learning rate read from device memory (hipGraph-capturable).  Bias corrections in double
+// like torch's host computation.  The last workgroup to take a ticket publishes step + 1.
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float b1,
+                                                  float b2, float eps, int* __restrict__ step_dev) {
+  const int t = step_dev[0] + 1;
+  const float lr = lr_dev[0];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)t));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+  __syncthreads();                                     // every thread of this block has read the step word
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(&step_dev[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (int)gridDim.x - 1) {
+      __hip_atomic_store(&step_dev[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&step_dev[0], t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev,
+                                 hcg_stream_t stream) {
+  if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, lr_dev, beta1, beta2, eps, (int*)step_dev);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}

@@ -95,6 +95,20 @@ class DataParallelGCN(nn.Module):
         self._flat = self._own_flat
         return self._flat
 
+    def reduce_flat(self, flat: torch.Tensor, average: bool = True) -> torch.Tensor:
+        """All-reduce a flat gradient buffer in place (the `grad_sync` hook of `train.FusedTrainStep`: the fused
+        backward wrote every gradient into `flat`, the parameters' `.grad` are views of it)."""
+        ws = self.world_size()
+        if ws > 1 or self.force_collective:
+            if average and self._avg_ok:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+                if average and ws > 1:
+                    flat.div_(ws)
+        self._flat, self._inplace = flat, True
+        return flat
+
     def reduce_gradients(self, average: bool = True, grads=None) -> torch.Tensor:
         """All-reduce(sum) the flat gradient, divide by world size, re-attach the views as .grad."""
         flat = self.flat_gradient(grads)

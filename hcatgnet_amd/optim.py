@@ -21,6 +21,52 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._flat = {}      # group index -> dict(param, exp_avg, exp_avg_sq flat tensors)
+        self.capturable = False
+
+    # ------------------------------------------------------------------ hipGraph-capturable mode
+    def enable_capturable(self):
+        """Keep the step count and the learning rate in device memory (hcg_adam_step_dev), so that `step()` can be
+        captured into a hipGraph and replayed: from here on the device counter is the authority (`steps_done()`),
+        `sync_lr()` pushes a learning rate a scheduler changed.  Needs flat gradients (the fused backward's)."""
+        self.capturable = True
+        for gi, group in enumerate(self.param_groups):
+            fl = self._flat.get(gi)
+            if fl is not None:
+                self._make_dev_state(fl, group)
+
+    def _make_dev_state(self, fl, group):
+        if "step_dev" not in fl:
+            dev = fl["p"].device
+            fl["step_dev"] = torch.tensor([fl["step"], 0], dtype=torch.int32, device=dev)
+            fl["lr_dev"] = torch.tensor([float(group["lr"])], dtype=torch.float32, device=dev)
+            fl["lr_host"] = float(group["lr"])
+
+    def sync_lr(self):
+        """Push param_groups' learning rates to the device words the captured update reads (host compare only
+        when nothing changed)."""
+        for gi, group in enumerate(self.param_groups):
+            fl = self._flat.get(gi)
+            if fl is not None and "lr_dev" in fl and fl["lr_host"] != float(group["lr"]):
+                fl["lr_host"] = float(group["lr"])
+                fl["lr_dev"].fill_(fl["lr_host"])
+
+    def steps_done(self, gi: int = 0) -> int:
+        fl = self._flat.get(gi)
+        if fl is None:
+            return 0
+        if self.capturable and "step_dev" in fl:
+            return int(fl["step_dev"][0].item())     # synchronises
+        return fl["step"]
+
+    def state_dict(self):
+        for gi, group in enumerate(self.param_groups):
+            fl = self._flat.get(gi)
+            if fl is not None and self.capturable:
+                n = self.steps_done(gi)
+                fl["step"] = n
+                for p in fl["params"]:
+                    self.state[p]["step"] = torch.tensor(float(n))
+        return super().state_dict()
 
     def _rebase(self, gi, group):
         """Move the group's parameters and moments onto flat buffers (in parameter order)."""
@@ -49,6 +95,18 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat[gi] = dict(params=ps, p=flat_p, m=flat_m, v=flat_v, n=n, step=int(ps and self.state[ps[0]]["step"]) if ps else 0)
         return self._flat[gi]
 
+    @staticmethod
+    def _grads_flat(grads) -> bool:
+        g0, off = grads[0], 0
+        if not (g0.is_contiguous() and g0.dtype == torch.float32):
+            return False
+        base = g0.data_ptr()
+        for g in grads:
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
+                return False
+            off += g.numel()
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -67,18 +125,24 @@ class FusedAdam(torch.optim.Optimizer):
             grads = [p.grad for p in ps]
             if any(g is None for g in grads):
                 raise _lib.HcgError("FusedAdam.step(): a parameter has no gradient")
-            fl["step"] += 1
-            step, lr, (b1, b2), eps = fl["step"], float(group["lr"]), group["betas"], float(group["eps"])
+            (b1, b2), eps, lr = group["betas"], float(group["eps"]), float(group["lr"])
             stream = _lib.stream_ptr()
+            if self.capturable:
+                self._make_dev_state(fl, group)
+                if not self._grads_flat(grads):
+                    raise _lib.HcgError("FusedAdam(capturable) needs the gradients in one flat buffer (fused backward)")
+                if fl["lr_host"] != lr:
+                    fl["lr_host"] = lr
+                    fl["lr_dev"].fill_(lr)
+                _lib.check(lib.hcg_adam_step_dev(fl["p"].data_ptr(), grads[0].data_ptr(), fl["m"].data_ptr(),
+                                                 fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
+                                                 fl["step_dev"].data_ptr(), stream), "hcg_adam_step_dev")
+                continue
+            fl["step"] += 1
+            step = fl["step"]
             # one launch when the gradients are one flat buffer in parameter order (fused backward / DP wrapper)
-            g0, off, flat_ok = grads[0], 0, grads[0].is_contiguous() and grads[0].dtype == torch.float32
-            if flat_ok:
-                base = g0.data_ptr()
-                for g in grads:
-                    if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
-                        flat_ok = False
-                        break
-                    off += g.numel()
+            g0 = grads[0]
+            flat_ok = self._grads_flat(grads)
             if flat_ok:
                 _lib.check(lib.hcg_adam_step(fl["p"].data_ptr(), g0.data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(),
                                              fl["n"], lr, b1, b2, eps, step, stream), "hcg_adam_step")

@@ -85,6 +85,24 @@ class SynthBatch:
                   max_edges=self.max_edges, edges_grouped=True)
         return b.to(device) if device is not None else b
 
+    def as_graph_list(self):
+        """The batch split back into per-graph `Data` objects (local node ids, y, idx = position): the form a
+        dataset holds them in (reference data/rhcaa.py:78-92), e.g. to fill a `DeviceGraphStore`."""
+        from .batch import Data
+        counts = torch.bincount(self.batch, minlength=self.num_graphs)
+        ptr = torch.zeros(self.num_graphs + 1, dtype=torch.int64)
+        ptr[1:] = counts.cumsum(0)
+        eg = self.batch[self.edge_index[0]]
+        ecount = torch.bincount(eg, minlength=self.num_graphs)
+        eptr = torch.zeros(self.num_graphs + 1, dtype=torch.int64)
+        eptr[1:] = ecount.cumsum(0)
+        out = []
+        for g in range(self.num_graphs):
+            a, b, ea, eb = int(ptr[g]), int(ptr[g + 1]), int(eptr[g]), int(eptr[g + 1])
+            out.append(Data(x=self.x[a:b].clone(), edge_index=(self.edge_index[:, ea:eb] - a).clone(),
+                            y=self.y[g:g + 1].clone(), idx=g))
+        return out
+
 
 def make_batch(num_graphs: int, nodes: int, extra_bonds: int, max_degree: int, feat: int, seed: int = BASE_SEED,
                rank: int = 0, nodes_jitter: int = 0, **_unused) -> SynthBatch:

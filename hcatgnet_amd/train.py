@@ -1,0 +1,341 @@
+"""The reference's per-batch loops on MI355X (reference utils/utils_model.py:55-111).
+
+`train_network` / `eval_network` / `predict_network` keep the reference's names, arguments and return
+values; what changes is how a step is issued:
+
+  reference step (utils/utils_model.py:60-68)          here (`FusedTrainStep`)
+  -------------------------------------------          ---------------------------------------------------
+  optimizer.zero_grad()                                 -- (every gradient is overwritten, never accumulated)
+  out = model(batch)                                    hcg_fused_stack2_fwd            1 launch (+ plan: 1)
+  loss = sqrt(MSELoss(out, y.unsqueeze(1)))             hcg_head_fwd_bwd                1 launch: readout fwd,
+  loss.backward()                                           loss, readout bwd (grid barrier inside)
+                                                        hcg_fused_layer_bwd x n_conv    n_conv launches
+                                                        hcg_reduce_slabs                1 launch -> ONE flat gradient
+  [data parallel]                                       RCCL all-reduce of that buffer, in place
+  optimizer.step()                                      hcg_adam_step(_dev)             1 launch
+  loss.item()                                           -- (the loss stays on the device; ONE sync per epoch)
+
+No autograd graph is built: the step is a fixed sequence of C-ABI calls, which is also what makes it capturable
+into a hipGraph (`FusedTrainStep.capture`).  Models / batches the fused kernels do not cover (graphs above 32
+nodes, widths other than 64, explicit edge weights) take the autograd path with the same arithmetic contract.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from . import functional as HF
+
+_SYNC_WORDS = {}
+
+
+def _sync_words(dev: torch.device) -> torch.Tensor:
+    """The two grid-barrier words of hcg_head_fwd_bwd: one once-zeroed pair per device (launches on one device are
+    stream-ordered in this package)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _SYNC_WORDS.get(key)
+    if t is None:
+        t = torch.zeros(2, dtype=torch.int32, device=dev)
+        _SYNC_WORDS[key] = t
+    return t
+
+
+class FusedTrainStep:
+    """One training step of the reference's loop as <= 8 enqueued launches, no autograd, no host sync.
+
+        step = FusedTrainStep(model)            # model: hcatgnet_amd.GCN on the GPU
+        loss = step(batch)                      # 0-d device tensor: sqrt(MSE) of this batch, weights already updated
+
+    `rmse=True` is the reference's `torch.sqrt(model.loss(...))`; `optimizer_step=False` stops after the backward
+    (gradients in `model.parameters()[i].grad`, views of one flat buffer); `grad_sync` is called with the flat gradient
+    between backward and optimiser (data parallel: `DataParallelGCN.reduce_flat`).
+    """
+
+    def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None):
+        self.model, self.rmse, self.optimizer_step, self.grad_sync = model, rmse, optimizer_step, grad_sync
+        self._bufs = {}
+        self._graph = None
+        self._graph_key = None
+
+    # ------------------------------------------------------------------ support check (host only)
+    @staticmethod
+    def unsupported_reason(model, batch=None) -> Optional[str]:
+        if getattr(model, "readout_layers", None) != 2:
+            return "readout depth other than 2"
+        if not bool(getattr(model, "use_fused", True)):
+            return "fused kernels disabled on the model"
+        if model.n_convolutions + 1 > 4:
+            return "more than 3 conv layers"
+        lib = _lib.load()
+        if not lib.hcg_head_supported(model.embedding_dim, model._n_classes):
+            return "head shape (embedding_dim must be 64, n_classes <= 8)"
+        if type(model.loss).__name__ != "MSELoss":
+            return "loss other than MSE"
+        if batch is not None:
+            if getattr(batch, "y", None) is None:
+                return "batch has no targets"
+            mx = getattr(batch, "max_nodes", None)
+            if mx is None or not getattr(batch, "edges_grouped", False):
+                return "batch lacks collate metadata (max_nodes / grouped edges)"
+            convs = [model.conv1] + list(model.conv_layers)
+            for c in convs:
+                if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, mx) <= 0:
+                    return "graph / layer shape outside the fused small-graph kernels"
+        return None
+
+    # ------------------------------------------------------------------ the step
+    def _buffers(self, key, N, B, F, D, C, n_conv, dev):
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        b = {"acts": [torch.empty(N, D, **f32) for _ in range(n_conv)],
+             "dacts": [torch.empty(N, D, **f32) for _ in range(n_conv - 1)],
+             "emb": torch.empty(B, 2 * D, **f32), "demb": torch.empty(B, 2 * D, **f32),
+             "z": torch.empty(B, D, **f32), "out": torch.empty(B, C, **f32), "loss": torch.empty(2, **f32)}
+        hb = lib.hcg_head_workspace_bytes(B)
+        b["ws_head"], b["ws_head_bytes"] = torch.empty(hb, dtype=torch.uint8, device=dev), hb
+        self._bufs = {key: b}          # one live shape at a time (a new shape replaces the old buffers)
+        return b
+
+    def _flat_grads(self, params, dev):
+        n = sum(p.numel() for p in params)
+        flat = getattr(self, "_flat", None)
+        if flat is None or flat.numel() != n or flat.device != dev:
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            self._flat = flat
+            off = 0
+            for p in params:                      # .grad = view of the flat buffer, parameter order
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        else:
+            off = 0
+            for p in params:
+                g = p.grad
+                if g is None or g.data_ptr() != flat.data_ptr() + 4 * off:
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        return flat
+
+    def __call__(self, batch):
+        model = self.model
+        why = self.unsupported_reason(model, batch)
+        if why is not None:
+            raise _lib.HcgError(f"FusedTrainStep does not cover this model/batch: {why}")
+        lib = _lib.load()
+        x, y = batch.x, batch.y
+        _lib.require_gpu(x, y, batch.edge_index)
+        x = HF._f32c(x)
+        plan = model._plan_for(batch, x, batch.edge_index, batch.batch, None)
+        convs = [model.conv1] + list(model.conv_layers)
+        l0, l1 = model.readout[0][0], model.readout[1]
+        N, F, B, D, C = x.shape[0], x.shape[1], plan.B, model.embedding_dim, model._n_classes
+        n_conv, dev, stream, slope = len(convs), x.device, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        y2 = HF._f32c(y).reshape(B, -1)
+        if y2.shape[1] != C:
+            raise ValueError(f"targets have {y2.shape[1]} columns, the model predicts {C}")
+        gpts = [HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) for c in convs]
+        if not all(g > 0 for g in gpts):
+            raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused small-graph kernels")
+        bufs = self._buffers((N, B, F, plan.E), N, B, F, D, C, n_conv, dev)
+        acts, emb = bufs["acts"], bufs["emb"]
+        p = _lib.ptr
+        W = [HF._f32c(c.lin.weight) for c in convs]
+        bs = [HF._f32c(c.bias) for c in convs]
+        # ---- forward (conv stack + pooling)
+        if n_conv == 2 and gpts[0] == gpts[1]:
+            rc = lib.hcg_fused_stack2_fwd(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
+                                          p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1, p(acts[0]),
+                                          p(acts[1]), p(emb), p(plan.status), stream)
+            _lib.check(rc, "hcg_fused_stack2_fwd")
+        else:
+            h = x
+            for l in range(n_conv):
+                rc = lib.hcg_fused_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                             p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]),
+                                             p(emb) if l == n_conv - 1 else None, p(plan.status), stream)
+                _lib.check(rc, "hcg_fused_layer_fwd")
+                h = acts[l]
+        # ---- head: readout forward, loss, readout backward
+        params = [q for q in model.parameters() if q.requires_grad]
+        flat = self._flat_grads(params, dev)
+        views, off = {}, 0
+        for q in params:
+            views[id(q)] = flat[off:off + q.numel()]
+            off += q.numel()
+        g = lambda prm: p(views[id(prm)])
+        rc = lib.hcg_head_fwd_bwd(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
+                                  p(HF._f32c(l1.bias)), B, D, C, slope, int(self.rmse), p(bufs["z"]), p(bufs["out"]),
+                                  p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
+                                  p(_sync_words(dev)), stream)
+        _lib.check(rc, "hcg_head_fwd_bwd")
+        jb = lib.hcg_reduce_job_bytes()
+        jobs = ctypes.create_string_buffer(jb * 4)
+        jaddr = ctypes.addressof(jobs)
+        _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
+                                           g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
+        # ---- conv stack backward, last layer first
+        njobs, dh = 1, None
+        for l in reversed(range(n_conv)):
+            inp = x if l == 0 else acts[l - 1]
+            Fl = inp.shape[1]
+            dx = bufs["dacts"][l - 1] if l > 0 else None
+            wsb = lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l])
+            ws = bufs.get(("ws", l))
+            if ws is None or ws.numel() < wsb:
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                bufs[("ws", l)] = ws
+            last = l == n_conv - 1
+            rc = lib.hcg_fused_layer_bwd(None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None,
+                                         p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                         p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope, 1, p(dx), p(plan.status), p(ws), wsb,
+                                         stream)
+            _lib.check(rc, "hcg_fused_layer_bwd")
+            _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight), g(convs[l].bias),
+                                                jaddr + njobs * jb), "hcg_fused_reduce_job")
+            njobs += 1
+            dh = dx
+        _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+        # ---- exchange + update
+        if self.grad_sync is not None:
+            self.grad_sync(flat)
+        if self.optimizer_step:
+            model.optimizer.step()
+        self.last_out = bufs["out"]
+        return bufs["loss"][0]
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture(self, batch):
+        """Capture the step on `batch`'s tensors into a hipGraph; `replay()` re-runs it on whatever those tensors
+        hold then (copy the next batch into them, or re-collate in place).  `batch` may be a callable returning the
+        batch: whatever it enqueues (a device collate, the plan build of a fresh `Batch`) is captured too.  The optimiser switches to its
+        device-side step counter / learning rate (`FusedAdam.enable_capturable`); the gradient exchange
+        (`grad_sync`) is NOT captured: it runs eagerly between the captured backward and a captured update."""
+        opt = self.model.optimizer
+        if self.optimizer_step:
+            if not hasattr(opt, "enable_capturable"):
+                raise _lib.HcgError("capture() with optimizer_step needs hcatgnet_amd.optim.FusedAdam")
+            opt.enable_capturable()
+        sync, do_opt = self.grad_sync, self.optimizer_step
+        get = batch if callable(batch) else (lambda: batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # warm-up: every buffer allocated, optimiser state re-based
+                self(get())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            self.grad_sync = None
+            self.optimizer_step = do_opt and sync is None
+            g_main = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_main):
+                loss = self(get())
+            g_opt = None
+            if do_opt and sync is not None:          # exchange in the middle: the update gets a graph of its own
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_opt):
+                    self.model.optimizer.step()
+        finally:
+            self.grad_sync, self.optimizer_step = sync, do_opt
+        self._graph = (g_main, g_opt, loss)
+        return self
+
+    def replay(self):
+        g_main, g_opt, loss = self._graph
+        if self.optimizer_step:
+            self.model.optimizer.sync_lr()
+        g_main.replay()
+        if self.grad_sync is not None:
+            self.grad_sync(self._flat)
+        if g_opt is not None:
+            g_opt.replay()
+        return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's loops (same names / arguments / return values)
+# ---------------------------------------------------------------------------------------------------------------
+def _rmse_autograd(model, batch):
+    out = model(batch)
+    return torch.sqrt(model.loss(out, batch.y.unsqueeze(1)))
+
+
+def train_network(model, train_loader, device):
+    """reference utils/utils_model.py:55-70: one epoch; returns sum(loss * num_graphs) / len(dataset).
+    The per-batch `loss.item()` of the reference is replaced by a device-side accumulation and ONE sync."""
+    model.train()
+    fused = getattr(model, "_hcg_train_step", None)
+    if fused is None:
+        fused = FusedTrainStep(model)
+        try:
+            model._hcg_train_step = fused
+        except Exception:
+            pass
+    total = None
+    for batch in train_loader:
+        batch = batch.to(device)
+        if FusedTrainStep.unsupported_reason(model, batch) is None:
+            loss = fused(batch)
+        else:
+            model.optimizer.zero_grad()
+            loss = _rmse_autograd(model, batch)
+            loss.backward()
+            model.optimizer.step()
+            loss = loss.detach()
+        contrib = loss * float(batch.num_graphs)
+        total = contrib.clone() if total is None else total + contrib
+    if total is None:
+        return 0.0
+    return float(total.item()) / len(train_loader.dataset)
+
+
+def eval_network(model, loader, device):
+    """reference utils/utils_model.py:72-79 (forward + sqrt(MSE) per batch; no parameter update)."""
+    model.eval()
+    total = None
+    with torch.no_grad():
+        for batch in loader:
+            batch = batch.to(device)
+            loss = _rmse_autograd(model, batch)
+            contrib = loss * float(batch.num_graphs)
+            total = contrib.clone() if total is None else total + contrib
+    if total is None:
+        return 0.0
+    return float(total.item()) / len(loader.dataset)
+
+
+def predict_network(model, loader, return_emb: bool = False, device=None):
+    """reference utils/utils_model.py:82-111: -> (y_pred, y_true, idx[, embeddings DataFrame]).
+    The reference moves the model to the CPU for this; here it stays on the GPU (`device` defaults to the
+    model's) and only the results come back.  The embeddings frame has the reference's columns: `0..2D-1`
+    (graph_emb = [max, mean]), `ddG_exp`, `ddG_pred`, `index`."""
+    import numpy as np
+    model.eval()
+    if device is None:
+        device = next(model.parameters()).device
+    y_pred, y_true, idx, embs = [], [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            batch = batch.to(device)
+            out, emb = model(batch, True)
+            y_pred.append(out.reshape(-1))
+            y_true.append(batch.y.reshape(-1))
+            idx.append(batch.idx.reshape(-1) if batch.idx is not None else torch.full((batch.num_graphs,), -1, device=out.device))
+            if return_emb:
+                embs.append(emb)
+    y_pred = torch.cat(y_pred).cpu().numpy().ravel()
+    y_true = torch.cat(y_true).cpu().numpy().ravel()
+    idx = torch.cat(idx).cpu().numpy().ravel()
+    if not return_emb:
+        return y_pred, y_true, idx
+    import pandas as pd
+    frame = pd.DataFrame(torch.cat(embs).cpu().numpy())
+    frame["ddG_exp"] = y_true
+    frame["ddG_pred"] = y_pred
+    frame["index"] = idx
+    return y_pred, y_true, idx, frame

@@ -191,6 +191,22 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
                      float* demb, float* dW0, float* db0, float* dW1, float* db1,
                      void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
+/* ---- regression head, forward + loss + backward in ONE launch (a10 + a12 + their backward; f2) -------------
+ * The reference's step runs  out = readout(emb); loss = torch.sqrt(MSELoss()(out, y.unsqueeze(1)));
+ * loss.backward()  (model/gcn.py:70-71, utils/utils_model.py:64-65): here one kernel with a grid barrier.
+ *   z [B,D], out [B,C] : forward results;  loss[0] = rmse ? sqrt(mse) : mse, loss[1] = mse
+ *   demb [B,2D]        : d loss / d emb (upstream gradient 1)
+ *   workspace          : gradient slabs (describe them with hcg_head_reduce_job, sum with hcg_reduce_slabs)
+ *   sync               : TWO int32 device words, zero before the first launch ever and owned by this entry
+ *                        point afterwards (grid-barrier state; launches sharing it must be stream-ordered)
+ * y is [B,C] like out.  D = 64, C <= 8 (hcg_head_supported). */
+int hcg_head_supported(int64_t D, int64_t C);
+size_t hcg_head_workspace_bytes(int64_t B);
+int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
+                     const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
+                     float* z, float* out, float* loss, float* demb,
+                     void* workspace, size_t workspace_bytes, int32_t* sync, hcg_stream_t stream);
+
 /* ---- MSE loss (a12 / f2): loss[0] = mean((a - b)^2) over n elements, fixed-order reduction;
  *      backward: da = grad_loss[0] * 2 (a - b) / n, db = -da (either may be NULL). */
 int hcg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, hcg_stream_t stream);
@@ -221,12 +237,21 @@ int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z
                              void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                             float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+                        float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
 
 /* ---- Adam update (f2) over one contiguous fp32 segment: torch.optim.Adam's rule (amsgrad / weight_decay /
  *      maximize off).  `step` = 1-based count of this update.  One launch. */
 int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int64_t step, hcg_stream_t stream);
+
+/* Same update with the step count and the learning rate in DEVICE memory, so that the launch can sit inside a
+ * captured hipGraph: `step_dev[0]` = number of updates done so far (the kernel uses step_dev[0] + 1 and the last
+ * workgroup to finish stores the incremented count; `step_dev[1]` is its ticket word, zero between launches),
+ * `lr_dev[0]` = learning rate (the host rewrites it when a scheduler changes it). */
+int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, hcg_stream_t stream);
 
 /* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),

@@ -169,3 +169,22 @@ def train_step_grads(params: Dict[str, torch.Tensor], x, edge_index, batch, y, n
     if x_requires_grad:
         return loss.detach(), out.detach(), emb.detach(), grads, xx.grad
     return loss.detach(), out.detach(), emb.detach(), grads
+
+
+def make_train_state(params: Dict[str, torch.Tensor], lr: float = 0.01, eps: float = 1e-9, dtype=torch.float32):
+    """Leaf parameters + the reference's optimiser: `torch.optim.Adam(self.parameters(), lr=lr, eps=1e-9)`
+    (model/networks.py:38).  Returns (p, opt)."""
+    p = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=lr, eps=eps)
+    return p, opt
+
+
+def train_step(p: Dict[str, torch.Tensor], opt, x, edge_index, batch, y, num_graphs=None):
+    """One full step of the reference's loop (utils/utils_model.py:62-66): zero_grad -> forward -> sqrt(MSE) ->
+    backward -> Adam step, in place on `p`.  Returns the loss (detached)."""
+    opt.zero_grad()
+    out, _ = gcn_forward(p, x, edge_index, batch, num_graphs)
+    loss = rmse_loss(out, y.to(out.dtype))
+    loss.backward()
+    opt.step()
+    return loss.detach()

@@ -1,0 +1,172 @@
+"""GPU parity of the fused training step: csrc/head.hip (readout forward + sqrt(MSE) + readout
+backward in one launch) and `hcatgnet_amd.train.FusedTrainStep` (the reference's per-batch step,
+utils/utils_model.py:60-68, without autograd) against the CPU oracle's autograd + torch.optim.Adam.
+Nothing in the reference pins gradients or optimiser trajectories: the oracle is the checker."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_inf
+from tests.test_gpu_parity import H, oracle, _model_from_params, _rand_params  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("B,C,rmse", [(1, 1, 1), (31, 1, 1), (32, 3, 1), (4096, 1, 1), (4096, 8, 0), (9000, 2, 1)])
+def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
+    """out / loss / demb / weight gradients of hcg_head_fwd_bwd vs torch fp64 autograd of
+    sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes workgroups loop over several tiles."""
+    from hcatgnet_amd import _lib
+    from hcatgnet_amd.train import _sync_words
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 * B + C)
+    emb = torch.randn(B, 128, generator=g); W0 = torch.randn(64, 128, generator=g) * 0.1; b0 = torch.randn(64, generator=g) * 0.1
+    W1 = torch.randn(C, 64, generator=g) * 0.1; b1 = torch.randn(C, generator=g) * 0.1; y = torch.randn(B, C, generator=g) * 3
+    d = [t.cuda().contiguous() for t in (emb, y, W0, b0, W1, b1)]
+    z = torch.empty(B, 64, device="cuda"); out = torch.empty(B, C, device="cuda"); loss = torch.empty(2, device="cuda")
+    demb = torch.empty(B, 128, device="cuda")
+    wsb = lib.hcg_head_workspace_bytes(B)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    sync = _sync_words(torch.device("cuda", torch.cuda.current_device()))
+    grads = [torch.empty_like(t) for t in d[2:]]
+    p = _lib.ptr
+    for rep in range(2):        # twice: the barrier words must come back to a reusable state
+        rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, 64, C, 0.01, rmse, p(z), p(out),
+                                  p(loss), p(demb), p(ws), wsb, p(sync), _lib.stream_ptr())
+        _lib.check(rc, "hcg_head_fwd_bwd")
+        job = ctypes.create_string_buffer(lib.hcg_reduce_job_bytes())
+        _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
+                                           ctypes.addressof(job)), "hcg_head_reduce_job")
+        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(job), 1, _lib.stream_ptr()), "hcg_reduce_slabs")
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0 and int(sync[1]) >= rep + 1
+    ref = [t.double().requires_grad_(True) for t in (emb, W0, b0, W1, b1)]
+    zr = F.leaky_relu(F.linear(ref[0], ref[1], ref[2]), 0.01)
+    r = F.linear(zr, ref[3], ref[4])
+    mse = F.mse_loss(r, y.double())
+    lref = torch.sqrt(mse) if rmse else mse
+    lref.backward()
+    assert rel_inf(out, r) <= TOL and rel_inf(z, zr) <= TOL
+    assert abs(float(loss[0]) - float(lref)) <= TOL * float(lref) and abs(float(loss[1]) - float(mse)) <= TOL * float(mse)
+    assert rel_inf(demb, ref[0].grad) <= TOL
+    for a, b in zip(grads, ref[1:]):
+        assert rel_inf(a, b.grad) <= TOL
+
+
+def _oracle_grads(oracle, m, sb):
+    params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    return oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+
+
+@pytest.mark.parametrize("cfg,ng,feat", [("C2", 96, 64), ("C2", 4096, 64), ("C2", 50, 25)])
+def test_fused_train_step_gradients_match_oracle(H, oracle, cfg, ng, feat):
+    """FusedTrainStep(optimizer_step=False): loss and every weight gradient vs oracle autograd; the gradients sit
+    in ONE flat buffer in parameter order."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config(cfg, num_graphs=ng)
+    if feat != 64:
+        sb.x = sb.x[:, :feat].contiguous()
+    m = H.make_network("GCN", H.default_options(), feat).cuda()
+    with torch.no_grad():
+        for prm in m.parameters():          # non-zero biases so that every gradient path matters
+            if prm.dim() == 1:
+                prm.add_(0.05)
+    step = FusedTrainStep(m, optimizer_step=False)
+    loss = step(sb.as_batch("cuda"))
+    l_ref, out_ref, _, g_ref = _oracle_grads(oracle, m, sb)
+    assert abs(float(loss) - float(l_ref)) <= TOL * abs(float(l_ref))
+    assert rel_inf(step.last_out, out_ref) <= TOL
+    base, off = None, 0
+    for name, prm in m.named_parameters():
+        tol = 1e-4 if (ng >= 4096 and "conv" in name) else TOL     # sums of > 1e5 terms
+        assert rel_inf(prm.grad, g_ref[name]) <= tol, name
+        base = prm.grad.data_ptr() if base is None else base
+        assert prm.grad.data_ptr() == base + 4 * off, name
+        off += prm.numel()
+
+
+def test_fused_train_step_with_adam_follows_the_reference_loop(H, oracle):
+    """Full step incl. the Adam update: (1) each update equals torch.optim.Adam(lr=.01, eps=1e-9) applied to OUR
+    gradients (tight), (2) the 6-step loss trajectory follows the oracle's full loop (loose: Adam with eps = 1e-9
+    turns rounding-level gradient differences into lr-sized parameter differences), (3) the loss decreases."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=128)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    batch = sb.as_batch("cuda")
+    p_or, opt_or = oracle.make_train_state({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    ref_params = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=0.01, eps=1e-9)
+    step = FusedTrainStep(m)
+    losses, losses_or = [], []
+    for it in range(6):
+        losses.append(float(step(batch)))
+        for rp, prm in zip(ref_params, m.parameters()):
+            rp.grad = prm.grad.detach().clone()
+        ref_opt.step()
+        for prm, rp in zip(m.parameters(), ref_params):
+            assert rel_inf(prm, rp) <= 2e-6, it
+        losses_or.append(float(oracle.train_step(p_or, opt_or, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)))
+    assert abs(losses[0] - losses_or[0]) <= TOL * abs(losses_or[0])
+    for a, b in zip(losses, losses_or):
+        assert abs(a - b) <= 2e-2 * abs(b)
+    assert losses[-1] < losses[0]
+
+
+def test_captured_step_replays_like_eager_steps(H):
+    """hipGraph capture of the whole step (plan build, forward, head, backward, reduction, Adam with device-side
+    step count): 2 warm-up + 4 replays == 6 eager steps, and a learning-rate change reaches the captured update."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=256)
+    mk = lambda: H.Batch(sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.num_graphs, y=sb.y.cuda(),
+                         max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+    torch.manual_seed(0)
+    a = H.make_network("GCN", H.default_options(), 64).cuda()
+    b = H.make_network("GCN", H.default_options(), 64).cuda()
+    b.load_state_dict(a.state_dict())
+    ea, eb = FusedTrainStep(a), FusedTrainStep(b)
+    x, ei, bv, y = sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.y.cuda()
+    fresh = lambda: H.Batch(x, ei, bv, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+    la = [float(ea(fresh())) for _ in range(6)]
+    eb.capture(fresh)                       # runs 2 eager warm-up steps
+    lb = [float(eb.replay()) for _ in range(4)]
+    assert b.optimizer.steps_done() == 6
+    for u, v in zip(la[2:], lb):
+        assert abs(u - v) <= 1e-6 * abs(u)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel_inf(pb, pa) <= 1e-6
+    # learning rate: set by a scheduler on the host -> sync_lr() inside replay()
+    for opt in (a.optimizer, b.optimizer):
+        opt.param_groups[0]["lr"] = 0.001
+    l7a, l7b = float(ea(fresh())), float(eb.replay())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel_inf(pb, pa) <= 1e-6
+    assert abs(l7a - l7b) <= 1e-6 * abs(l7a)
+    assert b.optimizer.state_dict()["state"][0]["step"].item() == 7
+
+
+def test_train_network_mirror_runs_an_epoch_and_learns(H):
+    """hcatgnet_amd.train.train_network / eval_network / predict_network: the reference's loop signatures
+    (utils/utils_model.py:55-111) over a DeviceLoader; fused step for 30-atom graphs, autograd fallback for graphs
+    the fused kernels do not cover; one host sync per epoch."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import eval_network, predict_network, train_network
+    for nodes in (30, 60):
+        sb = synth.make_config("C2", num_graphs=160, nodes=nodes)
+        store = H.DeviceGraphStore(sb.as_graph_list(), device="cuda")
+        loader = H.DeviceLoader(store, batch_size=40, shuffle=True, seed=1)
+        m = H.make_network("GCN", H.default_options(), 64).cuda()
+        first = train_network(m, loader, "cuda")
+        for _ in range(4):
+            last = train_network(m, loader, "cuda")
+        assert last < first
+        ev = eval_network(m, loader, "cuda")
+        assert ev > 0 and abs(ev - last) < 0.5 * first
+        yp, yt, idx, frame = predict_network(m, H.DeviceLoader(store, batch_size=64), True)
+        assert yp.shape == (160,) and yt.shape == (160,) and list(frame.columns[-3:]) == ["ddG_exp", "ddG_pred", "index"]
+        assert frame.shape == (160, 128 + 3)
