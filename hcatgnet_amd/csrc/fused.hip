@@ -121,6 +121,22 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 
 #define HCG_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
+// Distance between the LAST MFMA of a chain and the first VALU read of its result registers.
+// Observed on MI355X (tools/dbg_determinism.py, 80 launches of the stacked forward on 4096 tiles, two waves per SIMD):
+// with the compiler's own padding (s_nop to 12 wait states for this 8-pass instruction) and -O3's SLP-packed f32
+// epilogue (v_pk_fma_f32 / v_pk_mul_f32 on accumulator pairs), 11..31 of 80 launches came back with ONE wrong 1x16
+// block -- lanes 48-63 of one accumulator register of the second layer: the value before the chain's last MFMAs
+// landed.  Silent, timing dependent, different tile every time.  0 of 80 with (a) this file built with
+// -fno-slp-vectorize (see Makefile; packed f32 VALU next to MFMAs is slower on CDNA4 anyway) and (b) 64 idle
+// cycles here before the first read.  Both are kept; tests/test_gpu_train_step.py::test_forty_launches_are_bitwise_
+// identical is the regression test.
+__device__ __forceinline__ void mfma_results_fence(f32x16& a, f32x16& b) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void mfma_results_fence(f32x16& a) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a));
+}
+
 // acc += a * b with both operands split: the six cross terms >= 2^-24, smallest first
 __device__ __forceinline__ void mfma_split(f32x16& acc, const Split3& a, const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) {
   acc = HCG_MFMA(a.p3, b1, acc);
@@ -474,7 +490,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     Stager<KPAD, VEC> sxn;
     const TileRaw raw_cur = raw_next;                                    // loaded one tile ago
     raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // consumed one tile from now
-    if (VEC && have_next) {   // (the scalar-staging variants are short of registers: they load after the compute)
+#ifndef HCG_DBG_NOPF
+#define HCG_DBG_NOPF 0
+#endif
+    if (VEC && have_next && !HCG_DBG_NOPF) {   // (the scalar-staging variants are short of registers: they load after the compute)
       tin = tile_finish(raw_cur, gpt, lane, status);
       sxn.load(x, F, N, tin.nbase, tin.n, lane);
       ten.load(tin, graph_ptr, ei, E, lane);
@@ -495,6 +514,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         tile_gemm_split<KPAD>(L.buf, w1l, acc0, acc1, lane);
       }
       if (layer == 0) STAMP(3 + 8 * stamp_it);
+      mfma_results_fence(acc0, acc1);
 
       // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H': B operand = the H' accumulators, split in
       //      registers; slot j of k-step s <-> accumulator register 8s + j
@@ -516,6 +536,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         mfma_exact_a(y1, adj.f[s], split3(h1));
       }
       if (layer == 0) STAMP(6 + 8 * stamp_it);
+      mfma_results_fence(y0, y1);
 
       // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers.
       //      The values go back through the (now dead) input tile so that the HBM stores are 8 row-contiguous
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 
     have = have_next;
     if (have_next) {
-      if (!VEC) {
+      if (!VEC || HCG_DBG_NOPF) {
         tin = tile_finish(raw_cur, gpt, lane, status);
         sxn.load(x, F, N, tin.nbase, tin.n, lane);
         ten.load(tin, graph_ptr, ei, E, lane);
@@ -744,6 +765,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       mfma_exact_a(dh0, adj.f[s], split3(g0));
       mfma_exact_a(dh1, adj.f[s], split3(g1));
     }
+    mfma_results_fence(dh0, dh1);
     {
       float dvr[16];
 #pragma unroll
@@ -803,6 +825,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
                      *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
         }
       }
+#pragma unroll
+      for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
       if (VEC) {   // F == KPAD: rows are whole float4 groups -> transpose through LDS, dwordx4 stores
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -857,6 +881,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   constexpr int PER_T = (SLABF + WAVES * 64 - 1) / (WAVES * 64);
   static_assert(sizeof(WaveLdsB) * WAVES >= 4 * SLABF * sizeof(float), "wave-combine scratch must fit in the tile buffers");
   float* flat = reinterpret_cast<float*>(&lds[0]);
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dw[mb][nb]);
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 16));
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 32));
   float tot[PER_T];

@@ -16,6 +16,9 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// see fused.hip (mfma_results_fence): keep VALU reads of an accumulator a whole foreign MFMA away from the chain's
+// last MFMA when several waves share the SIMD's matrix pipe (f32 32x32x2: 16 passes = 64 cycles)
+__device__ __forceinline__ void mfma_results_fence(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a)); }
 
 constexpr int RD = 64;            // hidden width
 constexpr int RK = 2 * RD;        // pooled embedding width
@@ -28,6 +31,7 @@ constexpr int RCMAX = 8;
 // slab layout per WORKGROUP (same as readout.hip): dW0 [RD][RK] | db0 [RD] | dW1 [C][RD] | db1 [C]  (C padded to RCMAX)
 constexpr int SLAB = RD * RK + RD + RCMAX * RD + RCMAX;
 constexpr int MAXGRID = 256;
+static_assert(2 + 2 * MAXGRID <= HCG_HEAD_SYNC_WORDS, "sync words");
 
 __device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -42,23 +46,48 @@ struct HeadLds {
   float bcast[4];
 };
 
-// grid barrier: `sync[0]` = arrival counter (returns to 0), `sync[1]` = generation.  Both zero before the
-// first launch ever; every launch leaves the counter at 0 and the generation one higher.
-__device__ __forceinline__ void grid_barrier(int* sync, int nblocks) {
-  __syncthreads();
+// Grid-wide exchange of the per-workgroup squared-error partials WITHOUT read-modify-write atomics (128 workgroups
+// taking turns on one counter word cost ~10 us on this 8-XCD part: device-scope atomics are resolved at the memory
+// side).  `sync` = HCG_HEAD_SYNC_WORDS int32 words, all zero before the first launch ever:
+//   sync[0]              generation = number of launches completed so far (every workgroup reads it on entry)
+//   sync[2 + 2b .. +1]   slot of workgroup b: {partial sum bits, stamp}, written as ONE 8-byte store, stamp = generation + 1
+// A workgroup publishes its slot, then wave 0 polls all slots until every stamp is current -- nobody can get past that
+// before every workgroup has read the generation, so workgroup 0 may advance it right afterwards.  Every workgroup
+// adds the same partials in the same lane order: the loss is bitwise reproducible.
+__device__ __forceinline__ float exchange_partials(int* sync, int nblk, int gen, float my_partial, float* bcast) {
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(sync + 2);
+  const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) {
-    const int gen = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();                                                             // release this block's partial
-    const int prev = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == nblocks - 1) {
-      __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (__hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long v = ((unsigned long long)(unsigned)(gen + 1) << 32) | (unsigned long long)__float_as_uint(my_partial);
+    __hip_atomic_store(&slots[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    bool done;
+    do {
+      done = true;
+      s = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXGRID / 64; ++k) {
+        const int b = lane + 64 * k;
+        const unsigned long long v = __hip_atomic_load(&slots[b < nblk ? b : nblk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b < nblk) {
+          done = done && (int)(v >> 32) == gen + 1;
+          s += __uint_as_float((unsigned)v);
+        }
+      }
+      done = __all(done);
+      if (!done) __builtin_amdgcn_s_sleep(2);
+    } while (!done);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      bcast[1] = s;
+      if (blockIdx.x == 0) __hip_atomic_store(&sync[0], gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
   }
   __syncthreads();
+  return bcast[1];
 }
 
 // stage rows [g0, g0 + n) of a [B, W] matrix into dst[row * ld + c], rows >= n zero (all 256 threads, float4)
@@ -86,19 +115,46 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
                                                      const float* __restrict__ W1, const float* __restrict__ b1, int B, int C,
                                                      float slope, int rmse, float* __restrict__ z, float* __restrict__ out,
                                                      float* __restrict__ loss, float* __restrict__ demb,
-                                                     float* __restrict__ slabs, float* __restrict__ sse_part,
-                                                     int* __restrict__ sync) {
+                                                     float* __restrict__ slabs, int* __restrict__ sync,
+                                                     int* __restrict__ step_counter) {
   __shared__ HeadLds L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int tiles = (B + RT - 1) / RT;
   const int nblk = gridDim.x;
+  const int gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // launches completed so far
 
-  // weights -> LDS once (coalesced)
-  for (int idx = threadIdx.x; idx < RD * RK; idx += HW * 64) L.w0[(idx / RK) * WS0 + (idx % RK)] = W0[idx];
-  for (int idx = threadIdx.x; idx < RCMAX * RD; idx += HW * 64) L.w1[idx] = idx < C * RD ? W1[idx] : 0.f;
+  // weights -> LDS once.  Every global load of the prologue is issued before the first LDS write (a load-store
+  // loop would serialise 32 HBM round trips per thread: that alone cost ~15 us of this launch-latency-bound kernel)
+  {
+    constexpr int W4 = RD * RK / 4 / (HW * 64);          // 8 float4 of W0 per thread
+    float4 wv[W4];
+#pragma unroll
+    for (int it = 0; it < W4; ++it) wv[it] = *reinterpret_cast<const float4*>(W0 + 4 * (threadIdx.x + it * HW * 64));
+    float w1v[RCMAX * RD / (HW * 64)];
+#pragma unroll
+    for (int it = 0; it < RCMAX * RD / (HW * 64); ++it) {
+      const int idx = threadIdx.x + it * HW * 64;
+      w1v[it] = W1[idx < C * RD ? idx : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < W4; ++it) {
+      const int f4 = threadIdx.x + it * HW * 64, row = f4 / (RK / 4), c4 = f4 - row * (RK / 4);
+      float* dst = L.w0 + row * WS0 + 4 * c4;
+      dst[0] = wv[it].x; dst[1] = wv[it].y; dst[2] = wv[it].z; dst[3] = wv[it].w;
+    }
+#pragma unroll
+    for (int it = 0; it < RCMAX * RD / (HW * 64); ++it) {
+      const int idx = threadIdx.x + it * HW * 64;
+      L.w1[idx] = idx < C * RD ? w1v[it] : 0.f;
+    }
+  }
   const int nb = wave & 1, kh = wave >> 1;              // forward: output column block / K half of this wave
   const float bz = b0[nb * 32 + r];
+  const int orow = threadIdx.x >> 3, oj = threadIdx.x & 7;   // out projection: 8 threads per graph row, 8 hidden units each
+  float b1v[RCMAX];
+#pragma unroll
+  for (int c = 0; c < RCMAX; ++c) b1v[c] = b1[c < C ? c : 0];
 
   // ---------------------------------------------------------------- phase 1: forward + squared error
   float sse = 0.f;                                      // thread-private partial, fixed tile order
@@ -122,6 +178,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wrow[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
     }
+    mfma_results_fence(acc);
     if (kh == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) L.part[nb][krow(i, h) * 33 + r] = acc[i];
@@ -137,19 +194,37 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       }
     }
     __syncthreads();
-    {   // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y      (thread = (row, c))
-      const int row = threadIdx.x >> 3, c = threadIdx.x & 7;
-      float d = 0.f;
-      if (c < C && row < n) {
-        float s = 0.f;
-#pragma unroll 16
-        for (int j = 0; j < RD; ++j) s += L.z[row * ZS + j] * L.w1[c * RD + j];
-        s += b1[c];
-        out[(size_t)(g0 + row) * C + c] = s;
-        d = s - y[(size_t)(g0 + row) * C + c];
-        sse += d * d;
+    {   // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y.  Thread (row, j): hidden units 8j..8j+7 of every class,
+        // the 8 partial sums of a row meet by xor-shuffles (fixed order); the target is loaded ahead of the arithmetic
+      float yv[RCMAX];
+#pragma unroll
+      for (int c = 0; c < RCMAX; ++c)   // unconditional, clamped (a guarded load would sit behind its own wait)
+        yv[c] = y[(size_t)(g0 + orow < B ? g0 + orow : B - 1) * C + (c < C ? c : C - 1)];
+      const float4 za = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj);
+      const float4 zb = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj + 4);
+#pragma unroll
+      for (int c = 0; c < RCMAX; ++c) {
+        if (c < C) {                                     // block-uniform
+          const float4 wa = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj);
+          const float4 wb = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj + 4);
+          float s = ((za.x * wa.x + za.y * wa.y) + (za.z * wa.z + za.w * wa.w)) + ((zb.x * wb.x + zb.y * wb.y) + (zb.z * wb.z + zb.w * wb.w));
+          s += __shfl_xor(s, 1, 64);
+          s += __shfl_xor(s, 2, 64);
+          s += __shfl_xor(s, 4, 64);
+          if (oj == 0) {
+            float d = 0.f;
+            if (orow < n) {
+              s += b1v[c];
+              out[(size_t)(g0 + orow) * C + c] = s;
+              d = s - yv[c];
+              sse += d * d;
+            }
+            L.diff[orow][c] = d;
+          }
+        } else if (oj == 0) {
+          L.diff[orow][c] = 0.f;
+        }
       }
-      L.diff[row][c] = d;
     }
   }
   // block partial of the squared error: lanes -> wave (fixed xor tree) -> block (fixed order)
@@ -157,21 +232,20 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   for (int off = 32; off > 0; off >>= 1) sse += __shfl_xor(sse, off, 64);
   if (lane == 0) L.red[wave] = sse;
   __syncthreads();
-  if (threadIdx.x == 0) sse_part[blockIdx.x] = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
+  const float block_sse = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
 
-  grid_barrier(sync, nblk);
+  // ---------------------------------------------------------------- grid-wide: every workgroup gets the batch's squared error
+  const float total_sse = exchange_partials(sync, nblk, gen, block_sse, L.bcast);
 
   // ---------------------------------------------------------------- phase 2: loss, dout, backward
-  if (wave == 0) {                                     // every workgroup adds the same partials in the same order
-    float s = 0.f;
-    for (int b = lane; b < nblk; b += 64) s += __hip_atomic_load(&sse_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) {
-      const float mse = s / ((float)B * (float)C);
-      const float lv = rmse ? sqrtf(mse) : mse;
-      L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
-      if (blockIdx.x == 0) { loss[0] = lv; loss[1] = mse; }
+  if (threadIdx.x == 0) {
+    const float mse = total_sse / ((float)B * (float)C);
+    const float lv = rmse ? sqrtf(mse) : mse;
+    L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
+    if (blockIdx.x == 0) {
+      loss[0] = lv;
+      loss[1] = mse;
+      if (step_counter) step_counter[0] += 1;          // this training step's number, for the update launched later
     }
   }
   __syncthreads();
@@ -257,6 +331,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, L.w0[(d0 + 2) * WS0 + cb * 32 + r], de, 0, 0, 0);
       de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
     }
+    mfma_results_fence(de);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = krow(i, h);
@@ -266,6 +341,8 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
 
   // ---------------------------------------------------------------- one slab per workgroup
   float* slab = slabs + (size_t)blockIdx.x * SLAB;
+  mfma_results_fence(dw0[0]);
+  mfma_results_fence(dw0[1]);
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -315,24 +392,21 @@ int head_grid(int64_t B) {
 
 extern "C" int hcg_head_supported(int64_t D, int64_t C) { return (D == RD && C >= 1 && C <= RCMAX) ? 1 : 0; }
 
-// workspace: [grid][SLAB] gradient slabs, then [MAXGRID] squared-error partials
-extern "C" size_t hcg_head_workspace_bytes(int64_t B) {
-  return hcg_align_up((size_t)head_grid(B) * SLAB * sizeof(float), 256) + MAXGRID * sizeof(float) + 256;
-}
+// workspace: [grid][SLAB] gradient slabs
+extern "C" size_t hcg_head_workspace_bytes(int64_t B) { return hcg_align_up((size_t)head_grid(B) * SLAB * sizeof(float), 256) + 256; }
 
 extern "C" int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
                                 const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse, float* z,
                                 float* out, float* loss, float* demb, void* workspace, size_t workspace_bytes,
-                                int32_t* sync, hcg_stream_t stream) {
+                                int32_t* sync, int32_t* step_counter, hcg_stream_t stream) {
   if (!hcg_head_supported(D, C)) return HCG_ERR_UNSUPPORTED;
   if (B <= 0 || !emb || !y || !W0 || !b0 || !W1 || !b1 || !z || !out || !loss || !demb || !workspace || !sync)
     return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
   const int grid = head_grid(B);
   float* slabs = (float*)workspace;
-  float* part = (float*)((char*)workspace + hcg_align_up((size_t)grid * SLAB * sizeof(float), 256));
   hipLaunchKernelGGL(k_head, dim3(grid), dim3(HW * 64), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C, slope,
-                     rmse, z, out, loss, demb, slabs, part, (int*)sync);
+                     rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }

@@ -7,6 +7,18 @@
 
 namespace {
 
+// b^t for an integer t >= 0 by squaring, in double: a few ulp of double, far inside the float the caller rounds to
+// (torch computes `1 - beta ** step` in Python doubles); ~20 multiplications instead of a library pow().
+__device__ __forceinline__ double hcg_powi(double b, int t) {
+  double r = 1.0;
+  while (t > 0) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 struct Jobs {
   int njobs;
   hcg_reduce_job job[HCG_REDUCE_MAX_JOBS];
@@ -14,12 +26,32 @@ struct Jobs {
 
 constexpr int RS = 16;  // slab slices per output element
 
-__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs) {
+// Adam state for the fused "reduce, then update" variant: every reduced gradient element is written to its place in
+// the flat gradient buffer AND immediately used for torch.optim.Adam's update of the parameter at the same offset
+// (one launch fewer per step; the reference's optimiser: model/networks.py:38).
+struct AdamArgs {
+  const float* grad_flat;   // base of the flat gradient buffer every segment's dst points into
+  float* p;
+  float* m;
+  float* v;
+  const float* lr_dev;
+  const int* step_dev;      // [0] = 1-based number of this update
+  float b1, b2, eps;
+};
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
   __shared__ float part[RS][16];
   const hcg_reduce_job& J = jobs.job[blockIdx.y];
   const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + o;
   if (blockIdx.x * 16 >= J.slab_floats) return;   // block-uniform
+  __shared__ float adam_c[3];                        // lr / bias-correction-1, sqrt(bias-correction-2)
+  if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation
+    const int t = A.step_dev[0];                     // number of THIS update (advanced earlier in the step)
+    adam_c[0] = A.lr_dev[0] / (float)(1.0 - hcg_powi((double)A.b1, t));
+    adam_c[1] = (float)sqrt(1.0 - hcg_powi((double)A.b2, t));
+  }
   float s = 0.f;
   if (idx < J.slab_floats) {
 #pragma unroll 8
@@ -36,7 +68,18 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs) {
       const int rel = idx - S.begin;
       if (rel >= 0 && rel < S.count) {
         const int rr = rel / S.row_in, cc = rel - rr * S.row_in;
-        if (cc < S.row_out) S.dst[(size_t)rr * S.row_out + cc] = tot;
+        if (cc < S.row_out) {
+          float* gdst = S.dst + (size_t)rr * S.row_out + cc;
+          *gdst = tot;
+          if (ADAM) {
+            const size_t off = (size_t)(gdst - A.grad_flat);
+            const float mi = A.b1 * A.m[off] + (1.0f - A.b1) * tot;
+            const float vi = A.b2 * A.v[off] + (1.0f - A.b2) * tot * tot;
+            A.m[off] = mi;
+            A.v[off] = vi;
+            A.p[off] -= adam_c[0] * (mi / (sqrtf(vi) / adam_c[1] + A.eps));
+          }
+        }
       }
     }
   }
@@ -44,25 +87,44 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs) {
 
 }  // namespace
 
-extern "C" int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream) {
+static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamArgs* adam, int64_t n_flat, hipStream_t stream) {
   if (njobs < 0 || njobs > HCG_REDUCE_MAX_JOBS || (njobs > 0 && !jobs_host)) return HCG_ERR_INVALID_ARG;
-  if (njobs == 0) return HCG_OK;
+  if (njobs == 0) return adam ? HCG_ERR_INVALID_ARG : HCG_OK;
   Jobs jobs;
   jobs.njobs = njobs;
   int max_floats = 0;
   for (int j = 0; j < njobs; ++j) {
     const hcg_reduce_job& J = jobs_host[j];
     if (!J.slabs || J.nslabs < 0 || J.slab_floats <= 0 || J.nseg < 0 || J.nseg > HCG_REDUCE_MAX_SEGS) return HCG_ERR_INVALID_ARG;
-    for (int g = 0; g < J.nseg; ++g)
-      if (!J.seg[g].dst || J.seg[g].row_in <= 0 || J.seg[g].row_out <= 0 || J.seg[g].row_out > J.seg[g].row_in)
-        return HCG_ERR_INVALID_ARG;
+    for (int g = 0; g < J.nseg; ++g) {
+      const hcg_reduce_seg& S = J.seg[g];
+      if (!S.dst || S.row_in <= 0 || S.row_out <= 0 || S.row_out > S.row_in || S.count < 0) return HCG_ERR_INVALID_ARG;
+      if (adam) {   // the update addresses param / moments by the gradient's offset: every dst must lie in the flat buffer
+        const int64_t rows = (S.count + S.row_in - 1) / S.row_in;
+        if (S.dst < adam->grad_flat || S.dst + rows * S.row_out > adam->grad_flat + n_flat) return HCG_ERR_INVALID_ARG;
+      }
+    }
     jobs.job[j] = J;
     if (J.slab_floats > max_floats) max_floats = J.slab_floats;
   }
   for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
-  hipLaunchKernelGGL(k_reduce_jobs, dim3((max_floats + 15) / 16, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  const dim3 grid((max_floats + 15) / 16, njobs);
+  if (adam) hipLaunchKernelGGL(k_reduce_jobs<true>, grid, dim3(256), 0, stream, jobs, *adam);
+  else hipLaunchKernelGGL(k_reduce_jobs<false>, grid, dim3(256), 0, stream, jobs, AdamArgs{});
   HCG_CHECK_LAUNCH();
   return HCG_OK;
+}
+
+extern "C" int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream) {
+  return launch_reduce(jobs_host, njobs, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
+                                     float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
+                                     float beta2, float eps, const int32_t* step_dev, hcg_stream_t stream) {
+  if (n <= 0 || !grad_flat || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
+  AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
+  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream);
 }
 
 extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }

@@ -95,6 +95,59 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat[gi] = dict(params=ps, p=flat_p, m=flat_m, v=flat_v, n=n, step=int(ps and self.state[ps[0]]["step"]) if ps else 0)
         return self._flat[gi]
 
+    def fused_update_ready(self, flat_grad: torch.Tensor):
+        """Device word the head kernel must advance (hcg_head_fwd_bwd `step_counter`) if the NEXT update can be fused
+        into the slab reduction (`step_with_reduction`), else None -- nothing is launched or changed here."""
+        if not self.capturable or len(self.param_groups) != 1:
+            return None
+        group = self.param_groups[0]
+        ps = [p for p in group["params"] if p.requires_grad]
+        if not ps or not all(p.is_cuda for p in ps):
+            return None
+        fl = self._flat.get(0)
+        if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
+            with torch.no_grad():
+                fl = self._rebase(0, group)
+        grads = [p.grad for p in ps]
+        if any(g is None for g in grads) or not self._grads_flat(grads):
+            return None
+        if grads[0].data_ptr() != flat_grad.data_ptr() or flat_grad.numel() != fl["n"]:
+            return None
+        self._make_dev_state(fl, group)
+        return fl["step_dev"]
+
+    def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor) -> bool:
+        """The backward's slab reduction and this optimiser's update as ONE launch (hcg_reduce_slabs_adam): `jobs_addr`
+        = host address of the hcg_reduce_job array whose segments write `flat_grad` (the buffer the parameters'
+        `.grad` are views of, in parameter order).  The step word returned by `fused_update_ready` must have been
+        advanced earlier in this step (the head kernel does).  Returns False -- nothing launched -- when the
+        preconditions do not hold; the caller then issues the two launches."""
+        if not self.capturable or len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        ps = [p for p in group["params"] if p.requires_grad]
+        if not ps or not all(p.is_cuda for p in ps):
+            return False
+        fl = self._flat.get(0)
+        if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
+            with torch.no_grad():
+                fl = self._rebase(0, group)
+        grads = [p.grad for p in ps]
+        if any(g is None for g in grads) or not self._grads_flat(grads):
+            return False
+        if grads[0].data_ptr() != flat_grad.data_ptr() or flat_grad.numel() != fl["n"]:
+            return False
+        self._make_dev_state(fl, group)
+        (b1, b2), eps, lr = group["betas"], float(group["eps"]), float(group["lr"])
+        if fl["lr_host"] != lr:
+            fl["lr_host"] = lr
+            fl["lr_dev"].fill_(lr)
+        lib = _lib.load()
+        _lib.check(lib.hcg_reduce_slabs_adam(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
+                                             fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
+                                             fl["step_dev"].data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam")
+        return True
+
     @staticmethod
     def _grads_flat(grads) -> bool:
         g0, off = grads[0], 0
@@ -129,12 +182,15 @@ class FusedAdam(torch.optim.Optimizer):
             stream = _lib.stream_ptr()
             if self.capturable:
                 self._make_dev_state(fl, group)
-                if not self._grads_flat(grads):
-                    raise _lib.HcgError("FusedAdam(capturable) needs the gradients in one flat buffer (fused backward)")
+                gflat = grads[0]
+                if not self._grads_flat(grads):      # e.g. the autograd path's per-tensor gradients: one gather first
+                    if any(g.dtype != torch.float32 for g in grads):
+                        raise _lib.HcgError("FusedAdam handles float32 gradients only")
+                    gflat = torch.cat([g.reshape(-1) for g in grads])
                 if fl["lr_host"] != lr:
                     fl["lr_host"] = lr
                     fl["lr_dev"].fill_(lr)
-                _lib.check(lib.hcg_adam_step_dev(fl["p"].data_ptr(), grads[0].data_ptr(), fl["m"].data_ptr(),
+                _lib.check(lib.hcg_adam_step_dev(fl["p"].data_ptr(), gflat.data_ptr(), fl["m"].data_ptr(),
                                                  fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
                                                  fl["step_dev"].data_ptr(), stream), "hcg_adam_step_dev")
                 continue

@@ -33,12 +33,12 @@ _SYNC_WORDS = {}
 
 
 def _sync_words(dev: torch.device) -> torch.Tensor:
-    """The two grid-barrier words of hcg_head_fwd_bwd: one once-zeroed pair per device (launches on one device are
-    stream-ordered in this package)."""
+    """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: one once-zeroed set per device (launches on one
+    device are stream-ordered in this package)."""
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     t = _SYNC_WORDS.get(key)
     if t is None:
-        t = torch.zeros(2, dtype=torch.int32, device=dev)
+        t = torch.zeros(520, dtype=torch.int32, device=dev)
         _SYNC_WORDS[key] = t
     return t
 
@@ -56,6 +56,8 @@ class FusedTrainStep:
 
     def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None):
         self.model, self.rmse, self.optimizer_step, self.grad_sync = model, rmse, optimizer_step, grad_sync
+        if optimizer_step and hasattr(model.optimizer, "enable_capturable"):
+            model.optimizer.enable_capturable()     # step count / lr in device memory: same launches eager and captured
         self._bufs = {}
         self._graph = None
         self._graph_key = None
@@ -168,10 +170,16 @@ class FusedTrainStep:
             views[id(q)] = flat[off:off + q.numel()]
             off += q.numel()
         g = lambda prm: p(views[id(prm)])
+        # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
+        # advances the step number that launch reads
+        opt = model.optimizer
+        step_word = None
+        if self.optimizer_step and self.grad_sync is None and hasattr(opt, "fused_update_ready"):
+            step_word = opt.fused_update_ready(flat)
         rc = lib.hcg_head_fwd_bwd(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
                                   p(HF._f32c(l1.bias)), B, D, C, slope, int(self.rmse), p(bufs["z"]), p(bufs["out"]),
                                   p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
-                                  p(_sync_words(dev)), stream)
+                                  p(_sync_words(dev)), p(step_word), stream)
         _lib.check(rc, "hcg_head_fwd_bwd")
         jb = lib.hcg_reduce_job_bytes()
         jobs = ctypes.create_string_buffer(jb * 4)
@@ -199,12 +207,17 @@ class FusedTrainStep:
                                                 jaddr + njobs * jb), "hcg_fused_reduce_job")
             njobs += 1
             dh = dx
-        _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
-        # ---- exchange + update
-        if self.grad_sync is not None:
-            self.grad_sync(flat)
-        if self.optimizer_step:
-            model.optimizer.step()
+        # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
+        #      are one launch (the update reads each gradient element as it is produced)
+        if step_word is not None:
+            if not opt.step_with_reduction(jaddr, njobs, flat):    # (same preconditions as fused_update_ready)
+                raise _lib.HcgError("optimizer state changed between head launch and update")
+        else:
+            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+            if self.grad_sync is not None:
+                self.grad_sync(flat)
+            if self.optimizer_step:
+                opt.step()
         self.last_out = bufs["out"]
         return bufs["loss"][0]
 

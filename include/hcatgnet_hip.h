@@ -197,15 +197,20 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
  *   z [B,D], out [B,C] : forward results;  loss[0] = rmse ? sqrt(mse) : mse, loss[1] = mse
  *   demb [B,2D]        : d loss / d emb (upstream gradient 1)
  *   workspace          : gradient slabs (describe them with hcg_head_reduce_job, sum with hcg_reduce_slabs)
- *   sync               : TWO int32 device words, zero before the first launch ever and owned by this entry
- *                        point afterwards (grid-barrier state; launches sharing it must be stream-ordered)
+ *   sync               : HCG_HEAD_SYNC_WORDS int32 device words, all zero before the first launch ever and owned
+ *                        by this entry point afterwards (state of the grid-wide exchange of the squared-error
+ *                        partials; launches sharing it must be stream-ordered)
+ *   step_counter       : nullable; one int32 device word incremented by 1 per launch -- the number of the training
+ *                        step, read later in the same step by hcg_reduce_slabs_adam
  * y is [B,C] like out.  D = 64, C <= 8 (hcg_head_supported). */
+#define HCG_HEAD_SYNC_WORDS 520
 int hcg_head_supported(int64_t D, int64_t C);
 size_t hcg_head_workspace_bytes(int64_t B);
 int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
                      const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
                      float* z, float* out, float* loss, float* demb,
-                     void* workspace, size_t workspace_bytes, int32_t* sync, hcg_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int32_t* sync, int32_t* step_counter /*nullable*/,
+                     hcg_stream_t stream);
 
 /* ---- MSE loss (a12 / f2): loss[0] = mean((a - b)^2) over n elements, fixed-order reduction;
  *      backward: da = grad_loss[0] * 2 (a - b) / n, db = -da (either may be NULL). */
@@ -252,6 +257,16 @@ int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * `lr_dev[0]` = learning rate (the host rewrites it when a scheduler changes it). */
 int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, hcg_stream_t stream);
+
+/* hcg_reduce_slabs with the Adam update fused in: every reduced gradient element is stored at its place in the flat
+ * gradient buffer [grad_flat, grad_flat + n) -- each segment's dst must point into it -- and the parameter / moments
+ * at the same offset are updated at once (one launch instead of two; same rule as hcg_adam_step_dev).
+ * `step_dev[0]` = 1-based number of THIS update, already advanced when the kernel runs (hcg_head_fwd_bwd's
+ * step_counter does that earlier in the step; this launch only reads it).  Every element of the flat buffer must be
+ * covered by exactly one segment. */
+int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
+                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
+                          float eps, const int32_t* step_dev, hcg_stream_t stream);
 
 /* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),

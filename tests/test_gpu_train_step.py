@@ -33,16 +33,16 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
     sync = _sync_words(torch.device("cuda", torch.cuda.current_device()))
     grads = [torch.empty_like(t) for t in d[2:]]
     p = _lib.ptr
-    for rep in range(2):        # twice: the barrier words must come back to a reusable state
+    for rep in range(2):        # twice: the exchange words must be reusable launch after launch
         rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, 64, C, 0.01, rmse, p(z), p(out),
-                                  p(loss), p(demb), p(ws), wsb, p(sync), _lib.stream_ptr())
+                                  p(loss), p(demb), p(ws), wsb, p(sync), None, _lib.stream_ptr())
         _lib.check(rc, "hcg_head_fwd_bwd")
         job = ctypes.create_string_buffer(lib.hcg_reduce_job_bytes())
         _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
                                            ctypes.addressof(job)), "hcg_head_reduce_job")
         _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(job), 1, _lib.stream_ptr()), "hcg_reduce_slabs")
         torch.cuda.synchronize()
-        assert int(sync[0]) == 0 and int(sync[1]) >= rep + 1
+        assert int(sync[0]) >= rep + 1        # generation advanced once per launch
     ref = [t.double().requires_grad_(True) for t in (emb, W0, b0, W1, b1)]
     zr = F.leaky_relu(F.linear(ref[0], ref[1], ref[2]), 0.01)
     r = F.linear(zr, ref[3], ref[4])
@@ -170,3 +170,27 @@ def test_train_network_mirror_runs_an_epoch_and_learns(H):
         yp, yt, idx, frame = predict_network(m, H.DeviceLoader(store, batch_size=64), True)
         assert yp.shape == (160,) and yt.shape == (160,) and list(frame.columns[-3:]) == ["ddG_exp", "ddG_pred", "index"]
         assert frame.shape == (160, 128 + 3)
+
+
+def test_forty_launches_are_bitwise_identical(H):
+    """Run-to-run determinism under load: the fused forward / backward on the full C2 batch (4096 tiles over 256 CUs,
+    two waves per SIMD) 40 times -- every activation, the loss and every gradient bit-identical.  This is the test
+    that caught VALU reads of MFMA accumulators placed at the compiler's minimum distance (a wrong 1x16 block in
+    ~25 % of launches; csrc/fused.hip `mfma_results_fence`)."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=4096)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    batch = sb.as_batch("cuda")
+    step = FusedTrainStep(m, optimizer_step=False)
+    ref = None
+    for rep in range(40):
+        loss = step(batch)
+        bufs = next(iter(step._bufs.values()))
+        cur = [loss.clone(), step._flat.clone(), bufs["acts"][0].clone(), bufs["acts"][1].clone(), bufs["emb"].clone(),
+               bufs["demb"].clone(), bufs["dacts"][0].clone(), bufs["out"].clone()]
+        if ref is None:
+            ref = cur
+            continue
+        for k, (a, b) in enumerate(zip(ref, cur)):
+            assert torch.equal(a, b), (rep, k)
