@@ -35,6 +35,7 @@ SIGNATURES = {
     "hcg_gcn_layer_fwd": (INT, [P, P, P, P, P, P, P, F32, F32, INT, P, P, I64, I64, I64, I64, P]),
     "hcg_gcn_layer_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "hcg_gcn_layer_bwd": (INT, [P, P, P, P, P, P, P, P, F32, F32, INT, P, P, P, P, I64, I64, I64, I64, P, SZ, P]),
+    "hcg_gcn_edge_weight_grad": (INT, [P, P, P, P, P, P, F32, INT, P, I64, I64, I64, P]),
     "hcg_pool_fwd": (INT, [P, P, P, I64, I64, I64, P]),
     "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
     "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),

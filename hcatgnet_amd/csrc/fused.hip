@@ -466,6 +466,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
   __syncthreads();
+#ifndef HCG_STAGGER
+#define HCG_STAGGER 0
+#endif
+  if (HCG_STAGGER > 0 && wave >= 4) {   // second wave of each SIMD: start out of phase with the first one
+#pragma unroll
+    for (int k = 0; k < HCG_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   STAMP(0);
   int stamp_it = 0;
   // adjacency fragments + dinv of this lane's 16 accumulator rows: read ONCE per tile into registers, shared by
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         tile_gemm_split<KPAD>(L.buf, w1l, acc0, acc1, lane);
       }
       if (layer == 0) STAMP(3 + 8 * stamp_it);
+      if (layer == 1 && stamp_it == 0) STAMP(41);
       mfma_results_fence(acc0, acc1);
 
       // ---- H' = dinv (.) H  (in the accumulators), Y = (C + I) H': B operand = the H' accumulators, split in
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         y1[i] = 0.f;
       }
       if (layer == 0) STAMP(4 + 8 * stamp_it);
+      if (layer == 1 && stamp_it == 0) STAMP(42);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float h0[8] = {acc0[8 * s], acc0[8 * s + 1], acc0[8 * s + 2], acc0[8 * s + 3],
@@ -536,6 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         mfma_exact_a(y1, adj.f[s], split3(h1));
       }
       if (layer == 0) STAMP(6 + 8 * stamp_it);
+      if (layer == 1 && stamp_it == 0) STAMP(43);
       mfma_results_fence(y0, y1);
 
       // ---- out = LeakyReLU(dinv (.) Y + b): accumulator layout, column = lane (feature), rows in registers.
@@ -555,6 +565,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         L.buf[row * HS + 32 + r] = v1;
       }
       if (layer == 0) STAMP(7 + 8 * stamp_it);
+      if (layer == 1 && stamp_it == 0) STAMP(44);
       if (ti.n > 0) {   // wave-uniform
         // rows >= n are redirected to row n-1 (read AND write): duplicate identical stores instead of a
         // per-lane branch around every store -> all 8 LDS reads and 8 stores stay in one basic block
@@ -572,6 +583,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
           *reinterpret_cast<float4*>(dst + (size_t)(ti.nbase + row) * DD + 4 * q) = ov[it];
         }
       }
+      if (stamp_it == 0) STAMP(layer == 0 ? 40 : 45);
     }
     if (POOL) {
       for (int g = ti.g0; g < ti.g1; ++g) {

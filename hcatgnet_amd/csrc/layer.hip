@@ -107,6 +107,38 @@ int launch_aggregate(const float* src, const float* mask_src, const int32_t* row
   return HCG_OK;
 }
 
+// Gradient of a layer's output w.r.t. the per-edge multipliers `ew` of k_aggregate (explain mode):
+//   dew[k] = dinv_i * dinv_{col k} * < dY_i , h_{col k} >,   dY = dout * leaky'(out),   i = row of entry k.
+// 16 lanes per destination row walk its entries; each entry's D-term dot product is reduced inside the 16-lane
+// group in a fixed order.
+__global__ __launch_bounds__(256) void k_edge_weight_grad(const float* __restrict__ dout, const float* __restrict__ out,
+                                                          const float* __restrict__ h, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col, const float* __restrict__ dinv,
+                                                          float slope, int apply_act, float* __restrict__ dew, int64_t N,
+                                                          int D) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= N) return;                       // whole 16-lane groups leave together
+  const int lr = threadIdx.x & 15;
+  const int32_t kb = rowptr[i], ke = rowptr[i + 1];
+  const float di = dinv[i];
+  for (int32_t k = kb; k < ke; ++k) {
+    const int32_t c = col[k];
+    float s = 0.f;
+    if (c >= 0) {
+      for (int f = lr; f < D; f += 16) {
+        float g = dout[(size_t)i * D + f];
+        if (apply_act) g *= hcg_leaky_grad(out[(size_t)i * D + f], slope);
+        s += g * h[(size_t)c * D + f];
+      }
+    }
+    s += __shfl_xor(s, 1, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 8, 16);
+    if (lr == 0) dew[k] = c >= 0 ? di * dinv[c] * s : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  float* __restrict__ dz, int64_t n, int act, float slope) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,5 +229,19 @@ extern "C" int hcg_gcn_layer_bwd(const float* dout, const float* out, const floa
   HCG_TRY(hcg_gemm(dh_ws, 1, D, x, F, 1, dW, D, F, N, nullptr, 0, 0.f, partials, pf, stream));
   // dx[i, f] = sum_d dH[i, d] W[d, f]
   if (dx && N > 0) HCG_TRY(hcg_gemm(dh_ws, D, 1, W, F, 1, dx, N, F, D, nullptr, 0, 0.f, nullptr, 0, stream));
+  return HCG_OK;
+}
+
+// d loss / d ew_csr of hcg_gcn_layer_fwd (explain mode): `h` = x W^T (recompute it with hcg_linear_fwd), `out` = the
+// layer's saved output, `dout` the upstream gradient; entries of explicit self-loop edges (col < 0) get 0.
+extern "C" int hcg_gcn_edge_weight_grad(const float* dout, const float* out, const float* h, const int32_t* rowptr,
+                                        const int32_t* col, const float* dinv, float slope, int apply_act, float* dew_csr,
+                                        int64_t N, int64_t E, int64_t D, hcg_stream_t stream) {
+  if (N < 0 || E < 0 || D <= 0) return HCG_ERR_INVALID_ARG;
+  if (N == 0 || E == 0) return HCG_OK;
+  if (!dout || !out || !h || !rowptr || !col || !dinv || !dew_csr) return HCG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_edge_weight_grad, dim3((unsigned)hcg_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dout, out, h,
+                     rowptr, col, dinv, slope, apply_act, dew_csr, N, (int)D);
+  HCG_CHECK_LAUNCH();
   return HCG_OK;
 }

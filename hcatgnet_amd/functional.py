@@ -23,35 +23,49 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 class _GCNLayerFn(torch.autograd.Function):
-    """out = leaky_relu( Ahat (x W^T) + b ), Ahat = D^-1/2 (A + fill I) D^-1/2 from the plan."""
+    """out = leaky_relu( Ahat (x W^T) + b ), Ahat = D^-1/2 (A + fill I) D^-1/2 from the plan.
+    `edge_mult` (optional, [E] in the caller's edge order, may require grad): explain-mode multiplier of every
+    message, applied AFTER the normalisation like PyG's Explainer edge mask (self loops keep 1)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, plan: BatchPlan, use_edge_weight: bool, apply_act: bool, slope: float):
+    def forward(ctx, x, weight, bias, plan: BatchPlan, use_edge_weight: bool, apply_act: bool, slope: float, edge_mult=None):
         lib = _lib.load()
-        _lib.require_gpu(x, weight, bias)
+        _lib.require_gpu(x, weight, bias, edge_mult)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         N, F = x.shape
         D = weight.shape[0]
         if weight.shape[1] != F or N != plan.N:
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(weight.shape)}, plan N {plan.N}")
-        plan.ensure_csr()
+        mult_csr = mult_csc = None
+        if edge_mult is not None:
+            if use_edge_weight or plan.ew_csr is not None:
+                raise _lib.HcgError("an edge mask cannot be combined with explicit edge weights")
+            if edge_mult.numel() != plan.E:
+                raise ValueError(f"edge mask has {edge_mult.numel()} entries, the batch has {plan.E} edges")
+            plan.ensure_eid()
+            em = _f32c(edge_mult.detach()).reshape(-1)
+            mult_csr = em[plan.eid.long()[:plan.E]].contiguous() if plan.E else em
+            mult_csc = em[plan.eid_t.long()[:plan.E]].contiguous() if plan.E else em
+        else:
+            plan.ensure_csr()
         out = torch.empty(N, D, dtype=torch.float32, device=x.device)
         h_ws = torch.empty(N, D, dtype=torch.float32, device=x.device)
-        ew = plan.ew_csr if use_edge_weight else None
+        ew = plan.ew_csr if use_edge_weight else mult_csr
         fill = plan.fill if use_edge_weight else 1.0
         rc = lib.hcg_gcn_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.rowptr),
                                    _lib.ptr(plan.col), _lib.ptr(ew), _lib.ptr(ctx_dinv(plan, use_edge_weight)),
                                    fill, slope, int(apply_act), _lib.ptr(h_ws), _lib.ptr(out), N, plan.E, F, D,
                                    _lib.stream_ptr())
         _lib.check(rc, "hcg_gcn_layer_fwd")
-        ctx.save_for_backward(x, weight, out)
-        ctx.plan, ctx.use_ew, ctx.apply_act, ctx.slope = plan, use_edge_weight, apply_act, slope
+        ctx.save_for_backward(x, weight, out, *([mult_csc, h_ws] if edge_mult is not None else []))
+        ctx.plan, ctx.use_ew, ctx.apply_act, ctx.slope, ctx.masked = plan, use_edge_weight, apply_act, slope, edge_mult is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        x, weight, out = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, weight, out = saved[:3]
         plan = ctx.plan
         dout = _f32c(dout)
         N, F = x.shape
@@ -63,15 +77,27 @@ class _GCNLayerFn(torch.autograd.Function):
         dh_ws = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
         wsb = lib.hcg_gcn_layer_bwd_workspace_bytes(N, F, D)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        ew = plan.ew_csc if ctx.use_ew else None
+        ew = plan.ew_csc if ctx.use_ew else (saved[3] if ctx.masked else None)
         fill = plan.fill if ctx.use_ew else 1.0
+        dinv = ctx_dinv(plan, ctx.use_ew)
         rc = lib.hcg_gcn_layer_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(x), _lib.ptr(weight),
                                    _lib.ptr(plan.rowptr_t), _lib.ptr(plan.col_t), _lib.ptr(ew),
-                                   _lib.ptr(ctx_dinv(plan, ctx.use_ew)), fill, ctx.slope, int(ctx.apply_act),
+                                   _lib.ptr(dinv), fill, ctx.slope, int(ctx.apply_act),
                                    _lib.ptr(dh_ws), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), N, plan.E, F, D,
                                    _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "hcg_gcn_layer_bwd")
-        return dx, dW, db, None, None, None, None
+        dmult = None
+        if ctx.masked and ctx.needs_input_grad[7]:
+            h = saved[4]                                     # x W^T of the forward
+            dew = torch.zeros(max(plan.E, 1), dtype=torch.float32, device=dev)
+            rc = lib.hcg_gcn_edge_weight_grad(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(h), _lib.ptr(plan.rowptr),
+                                              _lib.ptr(plan.col), _lib.ptr(dinv), ctx.slope, int(ctx.apply_act),
+                                              _lib.ptr(dew), N, plan.E, D, _lib.stream_ptr())
+            _lib.check(rc, "hcg_gcn_edge_weight_grad")
+            dmult = torch.zeros(plan.E, dtype=torch.float32, device=dev)
+            if plan.E:
+                dmult[plan.eid.long()[:plan.E]] = dew[:plan.E]    # CSR order -> the caller's edge order (a permutation)
+        return dx, dW, db, None, None, None, None, dmult
 
 
 def ctx_dinv(plan: BatchPlan, use_edge_weight: bool):
@@ -449,8 +475,8 @@ def fused_gcn_layer(x, weight, bias, plan: BatchPlan, gpt: int, apply_act=True, 
     return _FusedLayerFn.apply(x, weight, bias, plan, gpt, apply_act, slope, pool)
 
 
-def gcn_layer(x, weight, bias, plan: BatchPlan, use_edge_weight=False, apply_act=True, slope=LEAKY_SLOPE):
-    return _GCNLayerFn.apply(x, weight, bias, plan, use_edge_weight, apply_act, slope)
+def gcn_layer(x, weight, bias, plan: BatchPlan, use_edge_weight=False, apply_act=True, slope=LEAKY_SLOPE, edge_mult=None):
+    return _GCNLayerFn.apply(x, weight, bias, plan, use_edge_weight, apply_act, slope, edge_mult)
 
 
 def graph_pool(a, plan: BatchPlan):

@@ -36,6 +36,9 @@ class GCNConv(nn.Module):
         self.in_channels, self.out_channels, self.improved = in_channels, out_channels, improved
         self.lin = nn.Linear(in_channels, out_channels, bias=False)
         self.bias = nn.Parameter(torch.empty(out_channels))
+        # explain-mode hooks with PyG MessagePassing's attribute names (set by hcatgnet_amd.explain.set_masks):
+        # when `explain` is on, every message is multiplied by `_edge_mask` (after a sigmoid if `_apply_sigmoid`)
+        self.explain, self._edge_mask, self._apply_sigmoid = False, None, True
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -49,6 +52,10 @@ class GCNConv(nn.Module):
         """`pool=True` (last conv): returns the pooled graph embedding [B, 2*out] instead of the
         node embeddings.  `fused=True` uses the one-launch-per-layer small-graph kernels when the
         plan / shapes allow, else the any-shape kernels."""
+        if self.explain and self._edge_mask is not None:
+            m = self._edge_mask.sigmoid() if self._apply_sigmoid else self._edge_mask
+            h = HF.gcn_layer(x, self.lin.weight, self.bias, plan, use_edge_weight, apply_act, edge_mult=m)
+            return HF.graph_pool(h, plan) if pool else h
         gpt = 0 if (use_edge_weight or not fused) else HF.fused_graphs_per_tile(plan, self.in_channels, self.out_channels)
         if gpt > 0:
             return HF.fused_gcn_layer(x, self.lin.weight, self.bias, plan, gpt, apply_act, pool=pool)
@@ -110,7 +117,8 @@ class GCN(BaseNetwork):
     def _run(self, x, plan: BatchPlan, use_edge_weight: bool, return_graph_embedding: bool):
         last = self.n_convolutions - 1
         fused = self.use_fused
-        if fused and not use_edge_weight and self.single_node:
+        masked = any(getattr(c, "explain", False) and c._edge_mask is not None for c in [self.conv1] + list(self.conv_layers))
+        if fused and not use_edge_weight and self.single_node and not masked:
             # whole model as one autograd node when every piece has a fused kernel (small graphs, D = 64)
             convs = [self.conv1] + list(self.conv_layers)
             gpts = [HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) for c in convs]

@@ -35,7 +35,7 @@ def _shared_status(dev: torch.device) -> torch.Tensor:
 class BatchPlan:
     __slots__ = ("N", "E", "B", "mode", "fill", "edge_index", "batch", "edge_weight", "graph_ptr", "edge_ptr",
                  "rowptr", "col", "eid", "rowptr_t", "col_t", "eid_t", "dinv", "ew_csr", "ew_csc", "dinv_unw",
-                 "status", "max_nodes", "max_edges", "validated", "has_csr", "shared_status")
+                 "status", "max_nodes", "max_edges", "validated", "has_csr", "shared_status", "want_eid")
 
     def check_status(self):
         """Synchronising read of the device-side status word; raises on any violation.  (For plans built
@@ -60,9 +60,10 @@ class BatchPlan:
             self.col = torch.empty(max(E, 1), **i32)
             self.col_t = torch.empty(max(E, 1), **i32)
             self.dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-            if self.edge_weight is not None:
+            if self.edge_weight is not None or getattr(self, "want_eid", False):
                 self.eid = torch.empty(max(E, 1), **i32)
                 self.eid_t = torch.empty(max(E, 1), **i32)
+            if self.edge_weight is not None:
                 self.ew_csr = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
                 self.ew_csc = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
                 self.dinv_unw = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
@@ -81,6 +82,18 @@ class BatchPlan:
         _lib.check(rc, "hcg_plan_build")
         self.mode = which
         self.has_csr = csr
+
+    def ensure_eid(self):
+        """CSR / CSC plus `eid` / `eid_t` (position of every CSR / CSC entry in the caller's edge_index): what the
+        explain path needs to carry a per-edge mask into CSR order and its gradient back."""
+        if self.eid is None:
+            self.want_eid = True
+            if self.status is None:
+                self.status = _shared_status(self.edge_index.device)
+            self.rowptr = None          # re-run the CSR build with the id arrays attached
+            self.has_csr = False
+            self._run(self.mode, csr=True)
+        return self
 
     def ensure_csr(self):
         """Build rowptr/col/dinv (and the transpose) if this plan so far only holds the pointers."""
@@ -133,6 +146,7 @@ class BatchPlan:
         p.N, p.E, p.B, p.fill = N, E, B, fill
         p.edge_index, p.batch, p.edge_weight = edge_index, batch, edge_weight
         p.max_nodes, p.max_edges, p.validated, p.has_csr = max_nodes, max_edges, False, False
+        p.want_eid = False
         i32 = dict(dtype=torch.int32, device=dev)
         p.graph_ptr = torch.empty(B + 1, **i32)
         p.edge_ptr = torch.empty(B + 1, **i32)

@@ -82,7 +82,7 @@ class DeviceGraphStore:
         plan.edge_index, plan.batch, plan.edge_weight = ei, bvec, None
         plan.graph_ptr, plan.edge_ptr = gp_d, ep_d
         plan.max_nodes, plan.max_edges, plan.validated, plan.has_csr = batch.max_nodes, batch.max_edges, True, False
-        plan.shared_status, plan.status = True, _shared_status(dev)
+        plan.shared_status, plan.status, plan.want_eid = True, _shared_status(dev), False
         plan.rowptr = plan.col = plan.eid = plan.rowptr_t = plan.col_t = plan.eid_t = None
         plan.dinv = plan.ew_csr = plan.ew_csc = plan.dinv_unw = None
         batch._hcg_plan = plan

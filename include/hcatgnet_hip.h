@@ -126,6 +126,15 @@ int hcg_gcn_layer_bwd(const float* dout, const float* out, const float* x, const
                       int64_t N, int64_t E, int64_t F, int64_t D,
                       void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
+/* explain mode (f4): gradient of the layer w.r.t. the per-edge multipliers ew_csr handed to hcg_gcn_layer_fwd --
+ * PyG's Explainer multiplies every message by an edge mask inside each MessagePassing layer (reference
+ * scripts_experiments/explain_gnn.py:39-50: edge_mask_type='object').  dew_csr[k] = dinv_i dinv_{col k} <dY_i, h_{col k}>
+ * with dY = dout * act'(out) and h = x W^T (recompute with hcg_linear_fwd); 0 for explicit self-loop entries. */
+int hcg_gcn_edge_weight_grad(const float* dout, const float* out, const float* h,
+                             const int32_t* rowptr, const int32_t* col, const float* dinv,
+                             float slope, int apply_act, float* dew_csr,
+                             int64_t N, int64_t E, int64_t D, hcg_stream_t stream);
+
 /* ---- graph pooling (a9): emb[g] = [ max_i a_i , mean_i a_i ]  (max FIRST, model/gcn.py:65-66) */
 int hcg_pool_fwd(const float* a, const int32_t* graph_ptr, float* emb /*[B,2D]*/,
                  int64_t N, int64_t B, int64_t D, hcg_stream_t stream);

@@ -72,10 +72,19 @@ def gcn_norm(edge_index: torch.Tensor, num_nodes: int, edge_weight: Optional[tor
 
 
 def gcn_conv(x: torch.Tensor, edge_index: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
-             edge_weight: Optional[torch.Tensor] = None, improved: bool = False) -> torch.Tensor:
-    """One GCNConv: ``scatter_add(norm * (x W^T)[src] -> dst) + bias``."""
+             edge_weight: Optional[torch.Tensor] = None, improved: bool = False,
+             edge_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One GCNConv: ``scatter_add(norm * (x W^T)[src] -> dst) + bias``.
+
+    `edge_mask` ([E], already passed through its sigmoid): explain mode.  PyG's Explainer multiplies every MESSAGE
+    by the mask inside `MessagePassing.propagate` -- after gcn_norm, the self loops gcn_norm appended get mask 1
+    (published torch_geometric behaviour; the reference uses it through `Explainer(..., edge_mask_type='object')`,
+    scripts_experiments/explain_gnn.py:39-50).  No reference artefact pins this branch: parity unpinned."""
     n = x.shape[0]
     ei, norm = gcn_norm(edge_index, n, edge_weight, improved, x.dtype)
+    if edge_mask is not None:
+        keep = edge_index[0] != edge_index[1]             # same edges gcn_norm kept, then one loop per node
+        norm = norm * torch.cat([edge_mask[keep].to(norm.dtype), torch.ones(n, dtype=norm.dtype, device=norm.device)])
     h = F.linear(x, weight)                               # a4: Linear(bias=False)
     hj = h.index_select(0, ei[0])                         # a5: gather of source rows
     m = norm.unsqueeze(1) * hj                            # a6: message
@@ -123,9 +132,10 @@ def infer_depths(params: Dict[str, torch.Tensor]) -> Tuple[int, int]:
 def gcn_forward(params: Dict[str, torch.Tensor], x: torch.Tensor, edge_index: torch.Tensor,
                 batch: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None,
                 edge_weight: Optional[torch.Tensor] = None, improved: bool = False,
-                return_intermediates: bool = False):
+                return_intermediates: bool = False, edge_mask: Optional[torch.Tensor] = None):
     """`GCN.forward` (model/gcn.py:54-76).  Returns ``(out[B,n_classes], graph_emb[B,2D])``
-    (+ list of post-activation node embeddings per conv when asked)."""
+    (+ list of post-activation node embeddings per conv when asked).  `edge_mask`: explain mode, applied in EVERY
+    conv layer (see gcn_conv)."""
     if batch is None:
         batch = torch.zeros(x.shape[0], dtype=torch.long, device=x.device)
     if num_graphs is None:
@@ -136,7 +146,7 @@ def gcn_forward(params: Dict[str, torch.Tensor], x: torch.Tensor, edge_index: to
     for li, (wk, bk) in enumerate(conv_param_names(n_conv)):
         # reference passes edge_weight to conv1 only (model/gcn.py:58 vs :62, and :127 vs :131)
         ew = edge_weight if li == 0 else None
-        h = gcn_conv(h, edge_index, params[wk], params[bk], ew, improved)
+        h = gcn_conv(h, edge_index, params[wk], params[bk], ew, improved, edge_mask)
         h = F.leaky_relu(h, LEAKY_SLOPE)
         acts.append(h)
     emb = torch.cat([global_max_pool(h, batch, num_graphs), global_mean_pool(h, batch, num_graphs)], dim=1)

@@ -50,6 +50,7 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
     lref = torch.sqrt(mse) if rmse else mse
     lref.backward()
     assert rel_inf(out, r) <= TOL and rel_inf(z, zr) <= TOL
+    lref, mse = lref.detach(), mse.detach()
     assert abs(float(loss[0]) - float(lref)) <= TOL * float(lref) and abs(float(loss[1]) - float(mse)) <= TOL * float(mse)
     assert rel_inf(demb, ref[0].grad) <= TOL
     for a, b in zip(grads, ref[1:]):

@@ -1,0 +1,94 @@
+"""the reference's on-disk formats either side of the path -- `reaction_N.pt` graphs in (read WITHOUT
+unpickling), `embeddings.csv` out.  CPU tests cover the reader; the GPU test runs the golden fixtures end to end
+through `predict_network` on the MI355X and compares with the reference's own embeddings / predictions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import golden_files, load_golden, rel_inf
+
+REF = "/root/reference"
+
+
+def _save_like_reference(path, x, ei, ea, y):
+    # same container layout: storages pickled in the order x, edge_index, edge_attr, y -> members data/0..3
+    torch.save({"x": x, "edge_index": ei, "edge_attr": ea, "y": y}, path)
+
+
+def test_reader_takes_raw_storages_and_checks_them(tmp_path):
+    from hcatgnet_amd.io import read_reaction_graph, load_processed_dir
+    g = torch.Generator().manual_seed(3)
+    for i, (n, e, F) in enumerate([(57, 118, 25), (184, 390, 32), (1, 0, 25)]):
+        x = torch.randn(n, F, generator=g)
+        ei = torch.randint(0, n, (2, e), generator=g, dtype=torch.int64)
+        ea = torch.randn(e, 7, generator=g)
+        y = torch.randn(1, generator=g)
+        p = tmp_path / f"reaction_{10 + i}.pt"
+        _save_like_reference(str(p), x, ei, ea, y)
+        d = read_reaction_graph(str(p), F)
+        assert torch.equal(d.x, x) and torch.equal(d.edge_index, ei) and torch.equal(d.edge_attr, ea) and torch.equal(d.y, y)
+        assert d.idx == 10 + i
+        if e:
+            with pytest.raises(ValueError):          # wrong feature width is caught by the byte-size cross-checks
+                read_reaction_graph(str(p), F + 1 if (n * F) % (F + 1) else F + 2)
+    ds = load_processed_dir(str(tmp_path), 25, indices=[10, 12])
+    assert [d.idx for d in ds] == [10, 12]
+    bad = tmp_path / "reaction_99.pt"
+    torch.save({"x": torch.randn(4, 25)}, str(bad))
+    with pytest.raises(ValueError, match="missing storage"):
+        read_reaction_graph(str(bad), 25)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("path", golden_files())
+def test_reader_on_the_reference_files_matches_the_committed_fixtures(path):
+    """The reader applied to the reference's real `reaction_N.pt` files reproduces the graphs the golden fixtures
+    were cut from (x, edge_index, y), for every fixture whose dataset directory can be identified by its name."""
+    from hcatgnet_amd.io import read_reaction_graph
+    name = os.path.basename(path)
+    ds = {"all_data": "all_data", "biaryl": "biAryl", "half_data": "half_data", "learning": "rhcaa_learning"}
+    key = next((k for k in ds if name.startswith("golden_" + k)), None)
+    if key is None:
+        pytest.skip("final-test fixture mixes two dataset directories")
+    z = np.load(path)
+    F = z["x"].shape[1]
+    for g, idx in enumerate(z["reaction_index"]):
+        f = os.path.join(REF, "data", "datasets", ds[key], "processed", f"reaction_{int(idx)}.pt")
+        if not os.path.isfile(f):
+            pytest.skip("reference graph file not present")
+        d = read_reaction_graph(f, F)
+        a, b = z["node_ptr"][g], z["node_ptr"][g + 1]
+        ea, eb = z["edge_ptr"][g], z["edge_ptr"][g + 1]
+        assert np.array_equal(d.x.numpy(), z["x"][a:b])
+        assert np.array_equal(d.edge_index.numpy(), z["edge_index_local"][:, ea:eb].astype(np.int64))
+        assert abs(float(d.y) - float(z["y"][g])) <= 1e-6 * max(1.0, abs(float(z["y"][g])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", golden_files())
+def test_predict_network_on_gpu_reproduces_reference_embeddings_csv(path, tmp_path):
+    """End to end (f3): golden graphs -> DeviceGraphStore -> DeviceLoader -> predict_network on the MI355X ->
+    embeddings.csv -> read back; embeddings <= 1e-5 relative, predictions <= 5e-5 absolute vs the numbers the
+    REFERENCE wrote (its own embeddings.csv, utils/utils_model.py:82-111)."""
+    import hcatgnet_amd as H
+    from hcatgnet_amd.io import read_embeddings_csv, write_embeddings_csv
+    from tests.test_gpu_parity import _model_from_params
+    gd = load_golden(path)
+    z = np.load(path)
+    graphs = []
+    for g in range(gd["num_graphs"]):
+        a, b = gd["node_ptr"][g], gd["node_ptr"][g + 1]
+        ea, eb = gd["edge_ptr"][g], gd["edge_ptr"][g + 1]
+        graphs.append(H.Data(x=gd["x"][a:b].clone(), edge_index=torch.from_numpy(z["edge_index_local"][:, ea:eb].astype(np.int64)),
+                             y=gd["y"][g:g + 1].clone(), idx=int(z["reaction_index"][g])))
+    m = _model_from_params(H, gd["params"])
+    store = H.DeviceGraphStore(graphs, device="cuda")
+    out_csv = str(tmp_path / "embeddings.csv")
+    write_embeddings_csv(m, {"test": H.DeviceLoader(store, batch_size=3)}, out_csv)
+    got = read_embeddings_csv(out_csv)
+    assert list(got["index"]) == [int(v) for v in z["reaction_index"]] and set(got["set"]) == {"test"}
+    assert rel_inf(torch.from_numpy(got["emb"]), gd["ref_emb"]) <= 1e-5
+    assert float(np.abs(got["pred"] - gd["ref_pred"].numpy()).max()) <= 5e-5
+    assert np.allclose(got["exp"], gd["y"].numpy(), rtol=0, atol=1e-6)

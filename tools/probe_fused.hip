@@ -69,6 +69,18 @@ int main() {
       printf("bwd %s: %.2f us per launch\n", variant == 0 ? "layer2 (pooled grad + dx)" : "layer1 (dout, no dx)", ms * 1000.f / 50);
     }
   }
+  {  // stacked two-layer forward (the product's forward launch); its stamps are the ones printed below
+    float *dW2, *dout2;
+    CK(hipMalloc(&dW2, W.size() * 4)); CK(hipMalloc(&dout2, (size_t)N * D * 4));
+    CK(hipMemcpy(dW2, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    for (int it = 0; it < 55; ++it) {
+      if (it == 5) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
+      hcg_fused_stack2_fwd(dx, dW, db, dW2, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 1, dout, dout2, demb, dstatus, 0);
+    }
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("stack2 fwd: %.2f us per launch\n", ms * 1000.f / 50);
+  }
 #ifndef HCG_STAMP
   return 0;
 #endif
@@ -90,6 +102,8 @@ int main() {
       if (s[1 + 8 * (it + 1)]) printf(" stage-next %llu", s[1 + 8 * (it + 1)] - s[5 + 8 * it]);
       printf(" | ");
     }
+    printf("\n   tile0 L1-stores %llu | L2: gemm %llu scale %llu agg %llu epiLDS %llu stores %llu | pool %llu\n   ", s[40] - s[7], s[41] - s[40], s[42] - s[41],
+           s[43] - s[42], s[44] - s[43], s[45] - s[44], s[5] - s[45]);
     printf("total %llu cyc | last stage-next: wait+xwrite %llu build %llu (of it: before %llu)\n", s[63] - s[0], s[57] - s[56], s[58] - s[57], s[56] - s[5]);
   }
   return 0;
