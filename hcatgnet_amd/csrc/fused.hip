@@ -35,6 +35,7 @@
 //     through LDS, workgroups through a [grid][D*KPAD+D] slab reduced in a fixed order by a second
 //     kernel -> bitwise reproducible gradients.
 #include "common.h"
+#include "split_mfma.h"
 
 // Diagnostic builds only (tools/probe_fused.hip defines HCG_STAMP): s_memtime stamps of a few waves go to
 // a buffer of their own; the product build compiles STAMP() to nothing and executes no stamp.
@@ -64,94 +65,13 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));   // one MFMA A/B fragment: 8 bf16 in 4 VGPRs
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int TM = 32;          // node rows per wave tile
-constexpr int DD = 64;          // layer width handled by this file (embedding_dim = 64)
-constexpr int HS = DD + 4;      // LDS row stride (floats) of the [TM][DD] tile buffer
 constexpr int CS = TM + 1;      // row stride of the adjacency-count matrix (conflict-free rows AND columns)
 constexpr int CNT_WORDS = 1280; // >= TM * CS, multiple of 256 (zero-filled with 5 int4 stores per lane)
 constexpr int WAVES = 8;        // waves per workgroup
 constexpr int BUF_FLOATS = TM * HS;
-constexpr int WPAD = 8;         // bf16 padding of a pre-split weight row: rows of (K + 8) * 2 bytes are 16-byte
-                                // aligned and 16 consecutive rows cover all 64 LDS banks (ds_read_b128, conflict-free)
 constexpr int CNT_EXACT = 256;  // adjacency counts up to here are exact in one bf16 piece
 static_assert(CNT_WORDS * 4 <= BUF_FLOATS * 4, "the count matrix must fit inside the tile buffer it aliases");
-
-// rows of a 32x32 MFMA accumulator: register i of lane-half h holds row krow(i, h)
-__device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-
-// ---- split-bf16 arithmetic ------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32 (round to nearest even)
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-struct Split3 { bf16x8 p1, p2, p3; };
-// 8 f32 -> three bf16 fragments with x = p1 + p2 + p3 (each residual is exact in f32)
-__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
-  u32x4 a, b, c;
-  float r[8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned u = pk_bf16(x[2 * j], x[2 * j + 1]);
-    a[j] = u;
-    r[2 * j] = x[2 * j] - __uint_as_float(u << 16);
-    r[2 * j + 1] = x[2 * j + 1] - __uint_as_float(u & 0xffff0000u);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned u = pk_bf16(r[2 * j], r[2 * j + 1]);
-    b[j] = u;
-    r[2 * j] -= __uint_as_float(u << 16);
-    r[2 * j + 1] -= __uint_as_float(u & 0xffff0000u);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c[j] = pk_bf16(r[2 * j], r[2 * j + 1]);
-  Split3 s;
-  s.p1 = __builtin_bit_cast(bf16x8, a);
-  s.p2 = __builtin_bit_cast(bf16x8, b);
-  s.p3 = __builtin_bit_cast(bf16x8, c);
-  return s;
-}
-
-#define HCG_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
-
-// Distance between the LAST MFMA of a chain and the first VALU read of its result registers.
-// Observed on MI355X (tools/dbg_determinism.py, 80 launches of the stacked forward on 4096 tiles, two waves per SIMD):
-// with the compiler's own padding (s_nop to 12 wait states for this 8-pass instruction) and -O3's SLP-packed f32
-// epilogue (v_pk_fma_f32 / v_pk_mul_f32 on accumulator pairs), 11..31 of 80 launches came back with ONE wrong 1x16
-// block -- lanes 48-63 of one accumulator register of the second layer: the value before the chain's last MFMAs
-// landed.  Silent, timing dependent, different tile every time.  0 of 80 with (a) this file built with
-// -fno-slp-vectorize (see Makefile; packed f32 VALU next to MFMAs is slower on CDNA4 anyway) and (b) 64 idle
-// cycles here before the first read.  Both are kept; tests/test_gpu_train_step.py::test_forty_launches_are_bitwise_
-// identical is the regression test.
-__device__ __forceinline__ void mfma_results_fence(f32x16& a, f32x16& b) {
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void mfma_results_fence(f32x16& a) {
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a));
-}
-
-// acc += a * b with both operands split: the six cross terms >= 2^-24, smallest first
-__device__ __forceinline__ void mfma_split(f32x16& acc, const Split3& a, const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) {
-  acc = HCG_MFMA(a.p3, b1, acc);
-  acc = HCG_MFMA(a.p1, b3, acc);
-  acc = HCG_MFMA(a.p2, b2, acc);
-  acc = HCG_MFMA(a.p2, b1, acc);
-  acc = HCG_MFMA(a.p1, b2, acc);
-  acc = HCG_MFMA(a.p1, b1, acc);
-}
-// acc += a * b with an EXACT one-piece a (small integers) and a split b
-__device__ __forceinline__ void mfma_exact_a(f32x16& acc, const bf16x8& a, const Split3& b) {
-  acc = HCG_MFMA(a, b.p3, acc);
-  acc = HCG_MFMA(a, b.p2, acc);
-  acc = HCG_MFMA(a, b.p1, acc);
-}
 
 // per-wave LDS.  Forward: the count matrix occupies the first CNT_WORDS words of `buf` while the tile's
 // adjacency fragments are being built, then the x tile is staged over it.  Backward: `cnt` is separate.
@@ -359,63 +279,6 @@ struct Stager {
     }
   }
 };
-
-// Pre-split weight image in LDS: three bf16 planes [rows][K + WPAD]; plane p at wl + p * rows * (K + WPAD).
-// Block-cooperative (every thread of the 512-thread workgroup takes part), coalesced global reads.
-//   TRANS = false: image row n, column k  <-  g[n * cols + k]   (B[k][n] = W[n][k]: the H = X W^T operand)
-//   TRANS = true : image row f, column d  <-  g[d * cols + f]   (B[d][f] = W[d][f]: the dX = dH W operand)
-// `rows_img` x `K` is the image extent (zero padded past the matrix), `g` is [grows][cols] row-major.
-template <bool TRANS>
-__device__ __forceinline__ void stage_weight_split(short* wl, int rows_img, int K, const float* __restrict__ g, int grows,
-                                                   int cols) {
-  const int ld = K + WPAD, plane = rows_img * ld;
-  const int total = TRANS ? grows * rows_img : rows_img * K;    // iterate in global-memory order where possible
-  for (int idx = threadIdx.x; idx < total; idx += WAVES * 64) {
-    int ir, ic;       // image row / column
-    float v;
-    if (TRANS) {      // idx = d * rows_img + f
-      const int d = idx / rows_img, f = idx - d * rows_img;
-      v = g[(size_t)d * cols + (f < cols ? f : cols - 1)];
-      if (f >= cols) v = 0.f;
-      ir = f;
-      ic = d;
-    } else {          // idx = n * K + k
-      const int n = idx / K, k = idx - n * K;
-      v = g[(size_t)(n < grows ? n : grows - 1) * cols + (k < cols ? k : cols - 1)];
-      if (k >= cols || n >= grows) v = 0.f;
-      ir = n;
-      ic = k;
-    }
-    const unsigned u1 = pk_bf16(v, 0.f) & 0xffffu;
-    const float r1 = v - __uint_as_float(u1 << 16);
-    const unsigned u2 = pk_bf16(r1, 0.f) & 0xffffu;
-    const float r2 = r1 - __uint_as_float(u2 << 16);
-    const unsigned u3 = pk_bf16(r2, 0.f) & 0xffffu;
-    wl[ir * ld + ic] = (short)u1;
-    wl[plane + ir * ld + ic] = (short)u2;
-    wl[2 * plane + ir * ld + ic] = (short)u3;
-  }
-}
-
-// acc{0,1}[TM x 64] += buf[TM x K] * (weight image: 64 rows n, K columns k)
-template <int K>
-__device__ __forceinline__ void tile_gemm_split(const float* buf, const short* wl, f32x16& acc0, f32x16& acc1, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  constexpr int ld = K + WPAD, plane = DD * ld;
-#pragma unroll
-  for (int s = 0; s < K / 16; ++s) {
-    const float4 a0 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h);
-    const float4 a1 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h + 4);
-    const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const Split3 A = split3(xa);
-    const short* w0 = wl + r * ld + 16 * s + 8 * h;
-    const short* w1 = w0 + 32 * ld;
-    mfma_split(acc0, A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
-               *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
-    mfma_split(acc1, A, *reinterpret_cast<const bf16x8*>(w1), *reinterpret_cast<const bf16x8*>(w1 + plane),
-               *reinterpret_cast<const bf16x8*>(w1 + 2 * plane));
-  }
-}
 
 // =====================================================================================================
 // forward:  out = LeakyReLU( Ahat (x W^T) + b ),  optional pooled epilogue emb[g] = [max, mean]

@@ -1,0 +1,598 @@
+// Fused per-layer kernels for batches of MID-SIZE graphs: one graph (33 .. 192 nodes) per workgroup.
+//
+// This is the reference's real regime: hcatgnet's reaction graphs have 56-184 atoms (3 molecules + explicit H),
+// F = 25 / 32 input features, embedding_dim 64 ("Real data").  The small-graph kernels (fused.hip)
+// stop at 32 nodes per tile; the any-shape kernels (layer.hip) round-trip every intermediate through HBM.  Here a
+// workgroup of 4 waves owns a whole graph:
+//   * gcn_norm on chip: the graph's raw COO edges -> in-degree + a CSR in LDS (integer atomics for the counting
+//     sort, then every row sorted by source id: the per-node sum order is fixed -> bitwise reproducible);
+//   * H' = dinv . (X W^T): the graph's X rows are staged into ONE LDS tile, each wave transforms its 32-row blocks
+//     on the matrix cores (split-bf16 MFMAs, split_mfma.h) and writes H' back over its own rows;
+//   * Y_i = H'_i + sum_{k in row i} H'_{col k}: wavefront segmented sum out of LDS (16 lanes x float4 per row,
+//     four rows per pass) -- the neighbour gather never touches HBM;
+//   * out = LeakyReLU(dinv . Y + b) stored once (row-contiguous 256 B), optional [max, mean] pooling epilogue.
+// backward mirrors it (dY' tile -> transpose segmented sum -> dH tile -> dW on the matrix cores with K = nodes,
+// dX = dH W), per-workgroup gradient slabs reduced in a fixed order by hcg_reduce_slabs.
+// LDS is sized at launch from the batch's largest graph (dynamic shared memory): 2 workgroups per CU up to 96 nodes.
+#include "common.h"
+#include "split_mfma.h"
+
+namespace {
+
+constexpr int MW = 4;                 // waves per workgroup
+constexpr int MT = MW * 64;           // threads
+constexpr int MID_MAX_NODES = 192;    // 6 row blocks of 32
+constexpr int MID_MAX_EDGES = 2048;   // directed edges of one graph (LDS col array, 16-bit ids)
+
+struct MidLds {   // carved out of dynamic shared memory by carve()
+  float* t0;              // [npad][HS]   forward: X -> H';   backward: dY' -> X
+  float* t1;              // [npad][HS]   backward only: dH
+  short* wl;              // 3 planes of the pre-split weight image
+  int* rowptr;            // [npad + 1]
+  int* cursor;            // [npad]   degree counter, then fill cursor
+  float* dinv;            // [npad]
+  unsigned short* col;    // [emax]
+  float* red;             // [MW * 2 * DD]   pooling / bias-gradient combine
+};
+
+__host__ __device__ inline size_t mid_lds_bytes(int npad, int emax, int wl_rows, int wl_k, bool two_tiles) {
+  size_t b = (size_t)npad * HS * 4 * (two_tiles ? 2 : 1);
+  b += (size_t)3 * wl_rows * (wl_k + WPAD) * 2;
+  b = (b + 15) / 16 * 16;
+  b += (size_t)(npad + 1 + 3) / 4 * 16;       // rowptr
+  b += (size_t)(npad + 3) / 4 * 16 * 2;       // cursor, dinv
+  b += (size_t)(emax + 7) / 8 * 16;           // col (u16)
+  b += (size_t)MW * 2 * DD * 4;
+  return b + 64;
+}
+
+__device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_rows, int wl_k, bool two_tiles) {
+  MidLds L;
+  L.t0 = reinterpret_cast<float*>(base);
+  base += (size_t)npad * HS * 4;
+  L.t1 = two_tiles ? reinterpret_cast<float*>(base) : nullptr;
+  if (two_tiles) base += (size_t)npad * HS * 4;
+  L.wl = reinterpret_cast<short*>(base);
+  base += (size_t)3 * wl_rows * (wl_k + WPAD) * 2;
+  base = reinterpret_cast<char*>(((uintptr_t)base + 15) / 16 * 16);
+  L.rowptr = reinterpret_cast<int*>(base);
+  base += (size_t)(npad + 1 + 3) / 4 * 16;
+  L.cursor = reinterpret_cast<int*>(base);
+  base += (size_t)(npad + 3) / 4 * 16;
+  L.dinv = reinterpret_cast<float*>(base);
+  base += (size_t)(npad + 3) / 4 * 16;
+  L.col = reinterpret_cast<unsigned short*>(base);
+  base += (size_t)(emax + 7) / 8 * 16;
+  L.red = reinterpret_cast<float*>(base);
+  return L;
+}
+
+struct GraphInfo { int nbase, n, ebase, ne, nblk; };
+
+__device__ __forceinline__ GraphInfo graph_info(int g, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
+                                                int npad, int emax, int32_t* status) {
+  GraphInfo gi;
+  gi.nbase = graph_ptr[g];
+  gi.n = graph_ptr[g + 1] - gi.nbase;
+  gi.ebase = edge_ptr[g];
+  gi.ne = edge_ptr[g + 1] - gi.ebase;
+  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax) {     // host metadata was wrong: refuse the graph
+    if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
+    gi.n = 0;
+    gi.ne = 0;
+  }
+  gi.nblk = (gi.n + 31) / 32;
+  return gi;
+}
+
+// In-degree -> dinv, and a CSR of the graph in LDS.  BY_SRC = false: rows = targets, col = sources (forward
+// aggregation); BY_SRC = true: rows = sources, col = targets (the transpose, for the backward).  dinv is always
+// (1 + in-degree)^-1/2.  Explicit (i, i) edges collapse into the unit self loop (PyG add_remaining_self_loops).
+// Every row ends up sorted by id, whatever order the LDS atomics ran in.  All MT threads; ends with a barrier.
+template <bool BY_SRC>
+__device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, const int64_t* __restrict__ ei, int64_t E,
+                                          int32_t* status, int* degin_scratch) {
+  const int tid = threadIdx.x;
+  const int nrows = gi.nblk * 32;
+  for (int i = tid; i < nrows; i += MT) { L.cursor[i] = 0; if (BY_SRC) degin_scratch[i] = 0; }
+  __syncthreads();
+  bool bad = false;
+  for (int e = tid; e < gi.ne; e += MT) {
+    int64_t k = (int64_t)gi.ebase + e;
+    if (k > E - 1) k = E - 1;
+    const long long s = ei[k], d = ei[E + k];
+    const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
+    const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
+    bad |= !ok;
+    if (ok && sl != dl) {
+      atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
+      if (BY_SRC) atomicAdd(&degin_scratch[dl], 1);
+    }
+  }
+  if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
+  __syncthreads();
+  // exclusive scan of the row sizes by wave 0 (<= 192 rows: 3 per lane), dinv for every row
+  if (tid < 64) {
+    int v[MID_MAX_NODES / 64], tot = 0;
+#pragma unroll
+    for (int j = 0; j < MID_MAX_NODES / 64; ++j) {
+      const int i = tid * (MID_MAX_NODES / 64) + j;
+      v[j] = i < nrows ? L.cursor[i] : 0;
+      tot += v[j];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (tid >= off) incl += t;
+    }
+    int run = incl - tot;
+#pragma unroll
+    for (int j = 0; j < MID_MAX_NODES / 64; ++j) {
+      const int i = tid * (MID_MAX_NODES / 64) + j;
+      if (i < nrows) L.rowptr[i] = run;
+      run += v[j];
+    }
+    if (tid == 63) L.rowptr[nrows] = incl;
+  }
+  __syncthreads();
+  for (int i = tid; i < nrows; i += MT) {
+    const int degin = BY_SRC ? degin_scratch[i] : L.cursor[i];
+    L.dinv[i] = i < gi.n ? 1.0f / sqrtf(1.0f + (float)degin) : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < nrows; i += MT) L.cursor[i] = L.rowptr[i];
+  __syncthreads();
+  for (int e = tid; e < gi.ne; e += MT) {
+    int64_t k = (int64_t)gi.ebase + e;
+    if (k > E - 1) k = E - 1;
+    const long long s = ei[k], d = ei[E + k];
+    const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
+    const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
+    if (ok && sl != dl) {
+      const int p = atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
+      L.col[p] = (unsigned short)(BY_SRC ? dl : sl);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < gi.n; i += MT) {          // insertion sort of each (short) row: fixed summation order
+    const int kb = L.rowptr[i], ke = L.rowptr[i + 1];
+    for (int a = kb + 1; a < ke; ++a) {
+      const unsigned short key = L.col[a];
+      int b = a - 1;
+      while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
+      L.col[b + 1] = key;
+    }
+  }
+  __syncthreads();
+}
+
+// Stage rows [nbase, nbase + n) of a row-major [Nrows, F] matrix into t[row][0..KPAD) (zero padded to KPAD columns and
+// to whole 32-row blocks).  All MT threads; no trailing barrier.
+template <int KPAD>
+__device__ __forceinline__ void stage_graph_rows(float* t, const float* __restrict__ g, int F, int nbase, int n, int nblk) {
+  const int tid = threadIdx.x;
+  const int rows = nblk * 32;
+  if (F == KPAD && ((uintptr_t)g % 16 == 0)) {
+    constexpr int PER_ROW = KPAD / 4;
+    for (int idx = tid; idx < rows * PER_ROW; idx += MT) {
+      const int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n) v = *reinterpret_cast<const float4*>(g + (size_t)(nbase + row) * F + 4 * c4);
+      *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = v;
+    }
+  } else {
+    for (int idx = tid; idx < rows * KPAD; idx += MT) {
+      const int row = idx / KPAD, c = idx - row * KPAD;
+      t[row * HS + c] = (row < n && c < F) ? g[(size_t)(nbase + row) * F + c] : 0.f;
+    }
+  }
+}
+
+// =====================================================================================================
+// forward of one layer, one graph per workgroup iteration
+// =====================================================================================================
+template <int KPAD, bool POOL>
+__global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const int64_t* __restrict__ ei,
+                                                         int64_t E, const int32_t* __restrict__ graph_ptr,
+                                                         const int32_t* __restrict__ edge_ptr, int B, int npad, int emax,
+                                                         float slope, int apply_act, float* __restrict__ out,
+                                                         float* __restrict__ emb, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const MidLds L = carve(smem, npad, emax, DD, KPAD, false);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
+
+  stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F);
+  const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+  __syncthreads();
+
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
+    stage_graph_rows<KPAD>(L.t0, x, F, gi.nbase, gi.n, gi.nblk);
+    build_csr<false>(L, gi, ei, E, status, nullptr);                // (ends with a barrier: the x tile is complete too)
+
+    // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
+    for (int mb = wave; mb < gi.nblk; mb += MW) {
+      float* blk = L.t0 + mb * 32 * HS;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
+      mfma_results_fence(acc0, acc1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = krow(i, h);
+        const float dv = L.dinv[mb * 32 + row];
+        blk[row * HS + r] = acc0[i] * dv;
+        blk[row * HS + 32 + r] = acc1[i] * dv;
+      }
+    }
+    __syncthreads();
+
+    // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
+    float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int mb = wave; mb < gi.nblk; mb += MW) {
+#pragma unroll 2
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = mb * 32 + pass * 4 + r4;
+        const bool valid = row < gi.n;
+        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
+        float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
+        for (int k = kb; __any(k < ke); ++k) {
+          if (k < ke) {
+            const int c = L.col[k];
+            const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+        }
+        const float di = L.dinv[row];
+        float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
+        if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
+        if (valid) {
+          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * DD + 4 * q) = y;
+          if (POOL) {
+            pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
+            psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
+          }
+        }
+      }
+    }
+    if (POOL) {   // rows of this lane's (r4, q) slot -> wave (xor 16, 32) -> workgroup (LDS, fixed order)
+      pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 16, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 16, 64)),
+                         fmaxf(pmax.z, __shfl_xor(pmax.z, 16, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 16, 64)));
+      pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 32, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 32, 64)),
+                         fmaxf(pmax.z, __shfl_xor(pmax.z, 32, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 32, 64)));
+      psum.x += __shfl_xor(psum.x, 16, 64); psum.y += __shfl_xor(psum.y, 16, 64); psum.z += __shfl_xor(psum.z, 16, 64); psum.w += __shfl_xor(psum.w, 16, 64);
+      psum.x += __shfl_xor(psum.x, 32, 64); psum.y += __shfl_xor(psum.y, 32, 64); psum.z += __shfl_xor(psum.z, 32, 64); psum.w += __shfl_xor(psum.w, 32, 64);
+      if (r4 == 0) {
+        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + 4 * q) = pmax;
+        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + DD + 4 * q) = psum;
+      }
+      __syncthreads();
+      if (tid < DD) {
+        float m = fmaxf(fmaxf(L.red[tid], L.red[2 * DD + tid]), fmaxf(L.red[4 * DD + tid], L.red[6 * DD + tid]));
+        float s = ((L.red[DD + tid] + L.red[3 * DD + tid]) + L.red[5 * DD + tid]) + L.red[7 * DD + tid];
+        if (gi.n <= 0) m = 0.f;
+        emb[(size_t)g * 2 * DD + tid] = m;
+        emb[(size_t)g * 2 * DD + DD + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
+      }
+    }
+    __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
+  }
+}
+
+// =====================================================================================================
+// backward of one layer, one graph per workgroup iteration
+//   dY = dA (.) leaky'(A)            dA = dout, or (POOLG) the pooled-gradient expansion (ties of the max split evenly)
+//   db += colsum dY ;  dH = Ahat^T dY ;  dW += dH^T x ;  dx = dH W  (NEEDS_DX)
+// per-workgroup partial sums go to `partials[blockIdx][64*KPAD + 64]` (same slab layout as fused.hip).
+// =====================================================================================================
+template <int KPAD, bool NEEDS_DX, bool POOLG>
+__global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
+    const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb,
+    const float* __restrict__ a_out, const float* __restrict__ x, int F, const float* __restrict__ W,
+    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
+    int B, int npad, int emax, float slope, int apply_act, float* __restrict__ dx, float* __restrict__ partials,
+    int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const MidLds L = carve(smem, npad, emax, NEEDS_DX ? KPAD : 0, DD, true);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
+  constexpr int NBF = KPAD / 32;
+  constexpr int ld = DD + WPAD, plane = KPAD * ld;
+  const int c4 = tid & 15, rg = tid >> 4;             // step 1: this thread's float4 column group / row group (16 of them)
+
+  if (NEEDS_DX) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
+  __syncthreads();
+
+  // dW block of this wave: d-block mbw x f-block nbw (KPAD = 32: waves 2, 3 have no block)
+  const int mbw = NBF == 2 ? (wave >> 1) : wave, nbw = NBF == 2 ? (wave & 1) : 0;
+  const bool has_dw = NBF == 2 || wave < 2;
+  f32x16 dw;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dw[i] = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
+    build_csr<true>(L, gi, ei, E, status, reinterpret_cast<int*>(L.red));
+    const int rows = gi.nblk * 32;
+
+    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
+    float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
+    if (POOLG) {
+      gmx = *reinterpret_cast<const float4*>(emb + (size_t)g * 2 * DD + 4 * c4);
+      const float4 dmx = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + 4 * c4);
+      dmean = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + DD + 4 * c4);
+      const float cntf = (float)(gi.n > 0 ? gi.n : 1);
+      dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
+      float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int row = rg; row < gi.n; row += MT / 16) {
+        const float4 a = *reinterpret_cast<const float4*>(a_out + (size_t)(gi.nbase + row) * DD + 4 * c4);
+        ties.x += (a.x == gmx.x); ties.y += (a.y == gmx.y); ties.z += (a.z == gmx.z); ties.w += (a.w == gmx.w);
+      }
+      float* sc = L.t1;                                  // [16 row groups][64] scratch (t1 is free here)
+      *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = ties;
+      __syncthreads();
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < MT / 16; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(sc + k * DD + 4 * c4);
+        tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+      }
+      share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
+      __syncthreads();                                   // scratch reads done before step 2 writes t1
+    }
+    for (int row = rg; row < rows; row += MT / 16) {
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < gi.n) {
+        const float4 a = *reinterpret_cast<const float4*>(a_out + (size_t)(gi.nbase + row) * DD + 4 * c4);
+        if (POOLG) {
+          d = make_float4(dmean.x + (a.x == gmx.x ? share.x : 0.f), dmean.y + (a.y == gmx.y ? share.y : 0.f),
+                          dmean.z + (a.z == gmx.z ? share.z : 0.f), dmean.w + (a.w == gmx.w ? share.w : 0.f));
+        } else {
+          d = *reinterpret_cast<const float4*>(dout + (size_t)(gi.nbase + row) * DD + 4 * c4);
+        }
+        if (apply_act) {
+          d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
+          d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
+        }
+        dbacc.x += d.x; dbacc.y += d.y; dbacc.z += d.z; dbacc.w += d.w;
+        const float di = L.dinv[row];
+        d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
+      }
+      *reinterpret_cast<float4*>(L.t0 + row * HS + 4 * c4) = d;
+    }
+    __syncthreads();
+
+    // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1
+    for (int mb = wave; mb < gi.nblk; mb += MW) {
+#pragma unroll 2
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = mb * 32 + pass * 4 + r4;
+        const bool valid = row < gi.n;
+        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
+        float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
+        for (int k = kb; __any(k < ke); ++k) {
+          if (k < ke) {
+            const int c = L.col[k];
+            const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+        }
+        const float di = L.dinv[row];
+        *reinterpret_cast<float4*>(L.t1 + row * HS + 4 * q) = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
+      }
+    }
+    __syncthreads();
+
+    // ---- 3. x tile -> t0
+    stage_graph_rows<KPAD>(L.t0, x, F, gi.nbase, gi.n, gi.nblk);
+    __syncthreads();
+
+    // ---- 4. dW[mbw][nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
+    if (has_dw) {
+      for (int ks = 0; ks < gi.nblk * 2; ++ks) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int node = 16 * ks + 8 * h + j;
+          av[j] = L.t1[node * HS + mbw * 32 + r];
+          bv[j] = L.t0[node * HS + nbw * 32 + r];
+        }
+        const Split3 A = split3(av), Bx = split3(bv);
+        mfma_split(dw, A, Bx.p1, Bx.p2, Bx.p3);
+      }
+    }
+
+    // ---- 5. dx = dH W, each wave on its own row blocks
+    if (NEEDS_DX) {
+      for (int mb = wave; mb < gi.nblk; mb += MW) {
+        const float* blk = L.t1 + mb * 32 * HS;
+        f32x16 dxa[NBF];
+#pragma unroll
+        for (int nb = 0; nb < NBF; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dxa[nb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DD / 16; ++s) {
+          const float4 a0 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h);
+          const float4 a1 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h + 4);
+          const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const Split3 A = split3(xa);
+#pragma unroll
+          for (int nb = 0; nb < NBF; ++nb) {
+            const short* w0 = L.wl + (nb * 32 + r) * ld + 16 * s + 8 * h;
+            mfma_split(dxa[nb], A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
+                       *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mb * 32 + krow(i, h);
+          if (row < gi.n) {
+#pragma unroll
+            for (int nb = 0; nb < NBF; ++nb) {
+              const int f = nb * 32 + r;
+              if (f < F) dx[(size_t)(gi.nbase + row) * F + f] = dxa[nb][i];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // tiles / CSR free for the next graph
+  }
+
+  // ---- publish this workgroup's slab: dW [64][KPAD] | db [64]
+  constexpr int SLABF = DD * KPAD + DD;
+  float* slab = partials + (size_t)blockIdx.x * SLABF;
+  mfma_results_fence(dw);
+  if (has_dw) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) slab[(mbw * 32 + krow(i, h)) * KPAD + nbw * 32 + r] = dw[i];
+  }
+  float* sc = L.t1;                                      // [16 row groups][64]
+  *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = dbacc;
+  __syncthreads();
+  if (tid < DD) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MT / 16; ++k) s += sc[k * DD + tid];
+    slab[DD * KPAD + tid] = s;
+  }
+}
+
+int mid_grid(int64_t B, int wgs_per_cu) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int64_t grid = (int64_t)cus * wgs_per_cu;
+  if (grid > B) grid = B;
+  return grid < 1 ? 1 : (int)grid;
+}
+
+int pad32(int64_t v) { return (int)((v + 31) / 32 * 32); }
+int pad8(int64_t v) { return (int)((v + 7) / 8 * 8 > 8 ? (v + 7) / 8 * 8 : 8); }
+
+// dynamic LDS above 64 KB has to be allowed per kernel: once per process (not per launch: the step may be under capture)
+template <auto KFN>
+hipError_t allow_big_lds() {   // (the kernel is a template VALUE parameter: one static per instantiation, not per signature)
+  static hipError_t st = hipFuncSetAttribute((const void*)KFN, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return st;
+}
+
+}  // namespace
+
+// 1 when the mid-size kernels apply: D = 64, F <= 64, every graph of the batch within 192 nodes / 2048 directed edges
+extern "C" int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph) {
+  return (D == DD && F >= 1 && F <= 64 && max_nodes_per_graph >= 1 && max_nodes_per_graph <= MID_MAX_NODES &&
+          max_edges_per_graph >= 0 && max_edges_per_graph <= MID_MAX_EDGES) ? 1 : 0;
+}
+
+extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
+                                 const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
+                                 int64_t max_nodes, int64_t max_edges, float slope, int apply_act, float* out, float* emb,
+                                 int32_t* status, hcg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
+  if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
+  if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
+  if (B == 0 || N == 0) return HCG_OK;
+  if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no graph has edges
+  const int npad = pad32(max_nodes), emax = pad8(max_edges);
+  const int kpad = F <= 32 ? 32 : 64;
+  const size_t lds = mid_lds_bytes(npad, emax, DD, kpad, false);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  const dim3 grid(mid_grid(B, per_cu)), blk(MT);
+#define LAUNCH_MID_FWD(KP, PL)                                                                                             \
+  do {                                                                                                                     \
+    auto kfn = k_mid_layer_fwd<KP, PL>;                                                                                    \
+    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL>>();                                                                                     \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
+    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, W, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad, emax, \
+                       slope, apply_act, out, emb, status);                                                                \
+  } while (0)
+  if (kpad == 32) { if (emb) LAUNCH_MID_FWD(32, true); else LAUNCH_MID_FWD(32, false); }
+  else            { if (emb) LAUNCH_MID_FWD(64, true); else LAUNCH_MID_FWD(64, false); }
+#undef LAUNCH_MID_FWD
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+static int mid_bwd_grid(int64_t B, int64_t F, int64_t max_nodes, int64_t max_edges, size_t* lds_out, bool needs_dx) {
+  const int kpad = F <= 32 ? 32 : 64;
+  const size_t lds = mid_lds_bytes(pad32(max_nodes), pad8(max_edges), needs_dx ? kpad : 0, DD, true);
+  if (lds_out) *lds_out = lds;
+  // one grid size for both variants of a step (with / without dx) keeps the slab count a function of the batch only
+  const size_t lds_worst = mid_lds_bytes(pad32(max_nodes), pad8(max_edges), kpad, DD, true);
+  return mid_grid(B, lds_worst <= 80 * 1024 ? 2 : 1);
+}
+
+extern "C" size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges) {
+  if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return 0;
+  const int kpad = F <= 32 ? 32 : 64;
+  return (size_t)mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true) * (DD * kpad + DD) * sizeof(float) + 256;
+}
+
+// backward, stage 1 (ONE launch).  dout == NULL selects the pooled form (upstream gradient = demb [B, 2D], expanded on
+// chip with `emb`).  dx nullable (first layer).  Leaves one slab per workgroup in `workspace`; describe it with
+// hcg_mid_reduce_job and sum with hcg_reduce_slabs.
+extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
+                                 const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
+                                 const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
+                                 int64_t max_edges, float slope, int apply_act, float* dx, int32_t* status, void* workspace,
+                                 size_t workspace_bytes, hcg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
+  if (N <= 0 || B <= 0 || E < 0 || !W || !workspace || !out || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index))
+    return HCG_ERR_INVALID_ARG;
+  const bool poolg = (dout == nullptr);
+  if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
+  if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
+  const int npad = pad32(max_nodes), emax = pad8(max_edges), kpad = F <= 32 ? 32 : 64;
+  const bool ndx = dx != nullptr;
+  size_t lds = 0;
+  const dim3 grid(mid_bwd_grid(B, F, max_nodes, max_edges, &lds, ndx)), blk(MT);
+  float* partials = (float*)workspace;
+#define LAUNCH_MID_BWD(KP, DX, PG)                                                                                          \
+  do {                                                                                                                      \
+    auto kfn = k_mid_layer_bwd<KP, DX, PG>;                                                                                 \
+    hipError_t e = allow_big_lds<k_mid_layer_bwd<KP, DX, PG>>();                                                                                      \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                             \
+    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, dout, demb, emb, out, x, (int)F, W, edge_index, E, graph_ptr, edge_ptr, \
+                       (int)B, npad, emax, slope, apply_act, dx, partials, status);                                         \
+  } while (0)
+#define DISPATCH_MID_BWD(KP)                                                                          \
+  do {                                                                                                \
+    if (ndx) { if (poolg) LAUNCH_MID_BWD(KP, true, true); else LAUNCH_MID_BWD(KP, true, false); }     \
+    else     { if (poolg) LAUNCH_MID_BWD(KP, false, true); else LAUNCH_MID_BWD(KP, false, false); }   \
+  } while (0)
+  if (kpad == 32) DISPATCH_MID_BWD(32); else DISPATCH_MID_BWD(64);
+#undef DISPATCH_MID_BWD
+#undef LAUNCH_MID_BWD
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+extern "C" int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int64_t D,
+                                  int64_t max_nodes, int64_t max_edges, float* dW, float* db, hcg_reduce_job* job) {
+  if (!hcg_mid_supported(F, D, max_nodes, max_edges) || !dW || !db || !job || !workspace || B <= 0) return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
+  const int kpad = F <= 32 ? 32 : 64;
+  job->slabs = (const float*)workspace;
+  job->nslabs = mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true);
+  job->slab_floats = DD * kpad + DD;
+  job->nseg = 2;
+  job->reserved = 0;
+  job->seg[0] = hcg_reduce_seg{0, DD * kpad, kpad, (int32_t)F, dW};
+  job->seg[1] = hcg_reduce_seg{DD * kpad, DD, 1, 1, db};
+  return HCG_OK;
+}

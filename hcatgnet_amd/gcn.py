@@ -59,6 +59,8 @@ class GCNConv(nn.Module):
         gpt = 0 if (use_edge_weight or not fused) else HF.fused_graphs_per_tile(plan, self.in_channels, self.out_channels)
         if gpt > 0:
             return HF.fused_gcn_layer(x, self.lin.weight, self.bias, plan, gpt, apply_act, pool=pool)
+        if fused and not use_edge_weight and HF.mid_supported(plan, self.in_channels, self.out_channels):
+            return HF.mid_gcn_layer(x, self.lin.weight, self.bias, plan, apply_act, pool=pool)   # one graph per workgroup
         h = HF.gcn_layer(x, self.lin.weight, self.bias, plan, use_edge_weight, apply_act)
         return HF.graph_pool(h, plan) if pool else h
 

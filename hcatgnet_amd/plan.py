@@ -171,4 +171,6 @@ class BatchPlan:
                 raise ValueError("hcatgnet_amd: invalid batch: " + _lib.describe_status(word))
             if p.max_nodes is None and B > 0:   # index bookkeeping for kernel selection (we are synchronising anyway)
                 p.max_nodes = int((p.graph_ptr[1:] - p.graph_ptr[:-1]).max().item())
+            if p.max_edges is None and B > 0 and p.mode == "blocked":
+                p.max_edges = int((p.edge_ptr[1:] - p.edge_ptr[:-1]).max().item())
         return p

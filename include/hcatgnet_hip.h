@@ -187,6 +187,27 @@ int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_
                            int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
                            hcg_stream_t stream);
 
+/* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 192 nodes and <= 2048
+ * directed edges per graph, D = 64, F <= 64 -- the size range of the reference's own reaction graphs (56-184 atoms,
+ * F = 25 / 32).  Same contract as hcg_fused_layer_*: raw int64 edge_index grouped by graph + graph_ptr / edge_ptr of
+ * a BLOCKED plan, gcn_norm and the CSR rebuilt on chip per graph, unweighted edges, optional pooled epilogue /
+ * pooled-gradient prologue, per-workgroup gradient slabs (hcg_mid_reduce_job + hcg_reduce_slabs).
+ * `max_nodes` / `max_edges` = largest graph of the batch (host metadata; sizes the dynamic LDS); a graph that exceeds
+ * them is skipped and flagged HCG_STATUS_SHAPE_LIMIT. */
+int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph);
+size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges);
+int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
+                      const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                      int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
+                      float slope, int apply_act, float* out, float* emb /*nullable*/, int32_t* status,
+                      hcg_stream_t stream);
+int hcg_mid_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
+                      const float* out, const float* x, const float* W,
+                      const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                      int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
+                      float slope, int apply_act, float* dx /*nullable*/, int32_t* status,
+                      void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
 /* ---- fused readout head (a10 + its backward) for the reference's default shape:
  *      z = LeakyReLU(emb W0^T + b0) [B,2D]->[B,D];  out = z W1^T + b1 [B,D]->[B,C];  D = 64, C <= 8.
  * forward: one launch (z is kept for the backward).  backward: one launch + fixed-order slab reduce;
@@ -251,6 +272,8 @@ int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z
                              void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                             float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int64_t D,
+                       int64_t max_nodes, int64_t max_edges, float* dW, float* db, hcg_reduce_job* job_host);
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
