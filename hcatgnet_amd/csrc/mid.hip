@@ -3,7 +3,7 @@
 // This is the reference's real regime: hcatgnet's reaction graphs have 56-184 atoms (3 molecules + explicit H),
 // F = 25 / 32 input features, embedding_dim 64 ("Real data").  The small-graph kernels (fused.hip)
 // stop at 32 nodes per tile; the any-shape kernels (layer.hip) round-trip every intermediate through HBM.  Here a
-// workgroup of 4 waves owns a whole graph:
+// workgroup of 8 waves owns a whole graph:
 //   * gcn_norm on chip: the graph's raw COO edges -> in-degree + a CSR in LDS (integer atomics for the counting
 //     sort, then every row sorted by source id: the per-node sum order is fixed -> bitwise reproducible);
 //   * H' = dinv . (X W^T): the graph's X rows are staged into ONE LDS tile, each wave transforms its 32-row blocks
@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int MW = 4;                 // waves per workgroup
+constexpr int MW = 8;                 // waves per workgroup (two per SIMD: the per-graph phases are latency chains)
 constexpr int MT = MW * 64;           // threads
 constexpr int MID_MAX_NODES = 192;    // 6 row blocks of 32
 constexpr int MID_MAX_EDGES = 2048;   // directed edges of one graph (LDS col array, 16-bit ids)
@@ -96,17 +96,28 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
   const int nrows = gi.nblk * 32;
   for (int i = tid; i < nrows; i += MT) { L.cursor[i] = 0; if (BY_SRC) degin_scratch[i] = 0; }
   __syncthreads();
+  // this thread's edges stay in registers from the counting pass to the fill pass (one global read per edge)
+  constexpr int EPT = MID_MAX_EDGES / MT;
+  unsigned short es[EPT], ed[EPT];
   bool bad = false;
-  for (int e = tid; e < gi.ne; e += MT) {
-    int64_t k = (int64_t)gi.ebase + e;
-    if (k > E - 1) k = E - 1;
-    const long long s = ei[k], d = ei[E + k];
-    const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
-    const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
-    bad |= !ok;
-    if (ok && sl != dl) {
-      atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
-      if (BY_SRC) atomicAdd(&degin_scratch[dl], 1);
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = tid + j * MT;
+    es[j] = 0xffff;
+    ed[j] = 0xffff;
+    if (e < gi.ne) {
+      int64_t k = (int64_t)gi.ebase + e;
+      if (k > E - 1) k = E - 1;
+      const long long s = ei[k], d = ei[E + k];
+      const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
+      const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
+      bad |= !ok;
+      if (ok && sl != dl) {
+        es[j] = (unsigned short)sl;
+        ed[j] = (unsigned short)dl;
+        atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
+        if (BY_SRC) atomicAdd(&degin_scratch[dl], 1);
+      }
     }
   }
   if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
@@ -143,15 +154,11 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
   __syncthreads();
   for (int i = tid; i < nrows; i += MT) L.cursor[i] = L.rowptr[i];
   __syncthreads();
-  for (int e = tid; e < gi.ne; e += MT) {
-    int64_t k = (int64_t)gi.ebase + e;
-    if (k > E - 1) k = E - 1;
-    const long long s = ei[k], d = ei[E + k];
-    const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
-    const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
-    if (ok && sl != dl) {
-      const int p = atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
-      L.col[p] = (unsigned short)(BY_SRC ? dl : sl);
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    if (es[j] != 0xffff) {
+      const int p = atomicAdd(&L.cursor[BY_SRC ? es[j] : ed[j]], 1);
+      L.col[p] = BY_SRC ? ed[j] : es[j];
     }
   }
   __syncthreads();
@@ -233,10 +240,10 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
 
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int mb = wave; mb < gi.nblk; mb += MW) {
+    for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
 #pragma unroll 2
-      for (int pass = 0; pass < 8; ++pass) {
-        const int row = mb * 32 + pass * 4 + r4;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = u * 16 + pass * 4 + r4;
         const bool valid = row < gi.n;
         const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
         float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
@@ -272,8 +279,12 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
       }
       __syncthreads();
       if (tid < DD) {
-        float m = fmaxf(fmaxf(L.red[tid], L.red[2 * DD + tid]), fmaxf(L.red[4 * DD + tid], L.red[6 * DD + tid]));
-        float s = ((L.red[DD + tid] + L.red[3 * DD + tid]) + L.red[5 * DD + tid]) + L.red[7 * DD + tid];
+        float m = -INFINITY, s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {                    // fixed order over the waves
+          m = fmaxf(m, L.red[w * 2 * DD + tid]);
+          s += L.red[w * 2 * DD + DD + tid];
+        }
         if (gi.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * DD + tid] = m;
         emb[(size_t)g * 2 * DD + DD + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
@@ -307,9 +318,10 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   if (NEEDS_DX) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
   __syncthreads();
 
-  // dW block of this wave: d-block mbw x f-block nbw (KPAD = 32: waves 2, 3 have no block)
-  const int mbw = NBF == 2 ? (wave >> 1) : wave, nbw = NBF == 2 ? (wave & 1) : 0;
-  const bool has_dw = NBF == 2 || wave < 2;
+  // dW: 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every NPART-th k-step
+  constexpr int NBLOCKS = 2 * NBF, NPART = MW / NBLOCKS;
+  const int blk_id = wave % NBLOCKS, part = wave / NBLOCKS;
+  const int mbw = blk_id / NBF, nbw = blk_id % NBF;
   f32x16 dw;
 #pragma unroll
   for (int i = 0; i < 16; ++i) dw[i] = 0.f;
@@ -368,10 +380,10 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     __syncthreads();
 
     // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1
-    for (int mb = wave; mb < gi.nblk; mb += MW) {
+    for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
 #pragma unroll 2
-      for (int pass = 0; pass < 8; ++pass) {
-        const int row = mb * 32 + pass * 4 + r4;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = u * 16 + pass * 4 + r4;
         const bool valid = row < gi.n;
         const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
         float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
@@ -393,8 +405,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     __syncthreads();
 
     // ---- 4. dW[mbw][nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
-    if (has_dw) {
-      for (int ks = 0; ks < gi.nblk * 2; ++ks) {
+    {
+      for (int ks = part; ks < gi.nblk * 2; ks += NPART) {
         float av[8], bv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -451,11 +463,24 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   constexpr int SLABF = DD * KPAD + DD;
   float* slab = partials + (size_t)blockIdx.x * SLABF;
   mfma_results_fence(dw);
-  if (has_dw) {
+  float* comb = L.t0;                                    // [NBLOCKS][32 * 32]: the K parts of a block meet here, fixed order
+  static_assert(NBLOCKS * 1024 * 4 <= 2 * 32 * HS * 4, "combine scratch must fit in the two smallest tiles");
+  for (int round = 0; round < NPART; ++round) {
+    if (part == round) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) slab[(mbw * 32 + krow(i, h)) * KPAD + nbw * 32 + r] = dw[i];
+      for (int i = 0; i < 16; ++i) {
+        float* c = comb + blk_id * 1024 + krow(i, h) * 32 + r;
+        *c = round == 0 ? dw[i] : *c + dw[i];
+      }
+    }
+    __syncthreads();
   }
-  float* sc = L.t1;                                      // [16 row groups][64]
+  for (int idx = tid; idx < NBLOCKS * 1024; idx += MT) {
+    const int b = idx >> 10, rr = (idx >> 5) & 31, cc = idx & 31;
+    slab[((b / NBF) * 32 + rr) * KPAD + (b % NBF) * 32 + cc] = comb[idx];
+  }
+  __syncthreads();
+  float* sc = L.t0;                                      // [MT / 16 row groups][64]
   *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = dbacc;
   __syncthreads();
   if (tid < DD) {
@@ -476,6 +501,9 @@ int mid_grid(int64_t B, int wgs_per_cu) {
   if (grid > B) grid = B;
   return grid < 1 ? 1 : (int)grid;
 }
+
+// workgroups of 8 waves that fit a CU: 160 KB of LDS, at most 2 (16 waves: the kernels use up to 256 VGPRs per lane)
+int wgs_per_cu(size_t lds) { return lds * 2 <= 160 * 1024 ? 2 : 1; }
 
 int pad32(int64_t v) { return (int)((v + 31) / 32 * 32); }
 int pad8(int64_t v) { return (int)((v + 7) / 8 * 8 > 8 ? (v + 7) / 8 * 8 : 8); }
@@ -509,8 +537,7 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   const int npad = pad32(max_nodes), emax = pad8(max_edges);
   const int kpad = F <= 32 ? 32 : 64;
   const size_t lds = mid_lds_bytes(npad, emax, DD, kpad, false);
-  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-  const dim3 grid(mid_grid(B, per_cu)), blk(MT);
+  const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
 #define LAUNCH_MID_FWD(KP, PL)                                                                                             \
   do {                                                                                                                     \
     auto kfn = k_mid_layer_fwd<KP, PL>;                                                                                    \
@@ -532,7 +559,7 @@ static int mid_bwd_grid(int64_t B, int64_t F, int64_t max_nodes, int64_t max_edg
   if (lds_out) *lds_out = lds;
   // one grid size for both variants of a step (with / without dx) keeps the slab count a function of the batch only
   const size_t lds_worst = mid_lds_bytes(pad32(max_nodes), pad8(max_edges), kpad, DD, true);
-  return mid_grid(B, lds_worst <= 80 * 1024 ? 2 : 1);
+  return mid_grid(B, wgs_per_cu(lds_worst));
 }
 
 extern "C" size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges) {
