@@ -6,18 +6,20 @@ values; what changes is how a step is issued:
   reference step (utils/utils_model.py:60-68)          here (`FusedTrainStep`)
   -------------------------------------------          ---------------------------------------------------
   optimizer.zero_grad()                                 -- (every gradient is overwritten, never accumulated)
-  out = model(batch)                                    hcg_fused_stack2_fwd            1 launch (+ plan: 1)
+  out = model(batch)                                    hcg_fused_stack2_fwd / hcg_mid_layer_fwd x n_conv   (+ plan: 1)
   loss = sqrt(MSELoss(out, y.unsqueeze(1)))             hcg_head_fwd_bwd                1 launch: readout fwd,
   loss.backward()                                           loss, readout bwd (grid barrier inside)
-                                                        hcg_fused_layer_bwd x n_conv    n_conv launches
+                                                        hcg_fused_layer_bwd / hcg_mid_layer_bwd x n_conv
                                                         hcg_reduce_slabs                1 launch -> ONE flat gradient
   [data parallel]                                       RCCL all-reduce of that buffer, in place
   optimizer.step()                                      hcg_adam_step(_dev)             1 launch
   loss.item()                                           -- (the loss stays on the device; ONE sync per epoch)
 
 No autograd graph is built: the step is a fixed sequence of C-ABI calls, which is also what makes it capturable
-into a hipGraph (`FusedTrainStep.capture`).  Models / batches the fused kernels do not cover (graphs above 32
-nodes, widths other than 64, explicit edge weights) take the autograd path with the same arithmetic contract.
+into a hipGraph (`FusedTrainStep.capture`).  Graphs up to 32 nodes run through the small-graph tiles (csrc/fused.hip),
+graphs up to 192 nodes -- the reference's own reaction graphs -- through the one-graph-per-workgroup kernels
+(csrc/mid.hip).  Models / batches neither covers (widths other than 64, explicit edge weights, larger graphs) take
+the autograd path with the same arithmetic contract.
 """
 from __future__ import annotations
 
@@ -82,10 +84,12 @@ class FusedTrainStep:
             mx = getattr(batch, "max_nodes", None)
             if mx is None or not getattr(batch, "edges_grouped", False):
                 return "batch lacks collate metadata (max_nodes / grouped edges)"
+            me = getattr(batch, "max_edges", None)
             convs = [model.conv1] + list(model.conv_layers)
             for c in convs:
-                if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, mx) <= 0:
-                    return "graph / layer shape outside the fused small-graph kernels"
+                if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, mx) <= 0 and not (
+                        me is not None and lib.hcg_mid_supported(c.in_channels, c.out_channels, mx, me)):
+                    return "graph / layer shape outside the fused kernels (small-graph tiles and one-graph-per-workgroup)"
         return None
 
     # ------------------------------------------------------------------ the step
@@ -140,16 +144,19 @@ class FusedTrainStep:
         y2 = HF._f32c(y).reshape(B, -1)
         if y2.shape[1] != C:
             raise ValueError(f"targets have {y2.shape[1]} columns, the model predicts {C}")
+        # kernel family per layer: gpt > 0 = small-graph tiles (csrc/fused.hip), 0 = one graph per workgroup (csrc/mid.hip)
         gpts = [HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) for c in convs]
-        if not all(g > 0 for g in gpts):
-            raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused small-graph kernels")
+        for c, gpt in zip(convs, gpts):
+            if gpt <= 0 and not HF.mid_supported(plan, c.in_channels, c.out_channels):
+                raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused kernels")
+        mxn, mxe = plan.max_nodes, plan.max_edges
         bufs = self._buffers((N, B, F, plan.E), N, B, F, D, C, n_conv, dev)
         acts, emb = bufs["acts"], bufs["emb"]
         p = _lib.ptr
         W = [HF._f32c(c.lin.weight) for c in convs]
         bs = [HF._f32c(c.bias) for c in convs]
         # ---- forward (conv stack + pooling)
-        if n_conv == 2 and gpts[0] == gpts[1]:
+        if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
             rc = lib.hcg_fused_stack2_fwd(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
                                           p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1, p(acts[0]),
                                           p(acts[1]), p(emb), p(plan.status), stream)
@@ -157,10 +164,17 @@ class FusedTrainStep:
         else:
             h = x
             for l in range(n_conv):
-                rc = lib.hcg_fused_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                             p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]),
-                                             p(emb) if l == n_conv - 1 else None, p(plan.status), stream)
-                _lib.check(rc, "hcg_fused_layer_fwd")
+                pe = p(emb) if l == n_conv - 1 else None
+                if gpts[l] > 0:
+                    rc = lib.hcg_fused_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                                 p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]), pe,
+                                                 p(plan.status), stream)
+                    _lib.check(rc, "hcg_fused_layer_fwd")
+                else:
+                    rc = lib.hcg_mid_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                               p(plan.edge_ptr), N, B, h.shape[1], D, mxn, mxe, slope, 1, p(acts[l]), pe,
+                                               p(plan.status), stream)
+                    _lib.check(rc, "hcg_mid_layer_fwd")
                 h = acts[l]
         # ---- head: readout forward, loss, readout backward
         params = [q for q in model.parameters() if q.requires_grad]
@@ -192,19 +206,28 @@ class FusedTrainStep:
             inp = x if l == 0 else acts[l - 1]
             Fl = inp.shape[1]
             dx = bufs["dacts"][l - 1] if l > 0 else None
-            wsb = lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l])
+            small = gpts[l] > 0
+            wsb = lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l]) if small else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)
             ws = bufs.get(("ws", l))
             if ws is None or ws.numel() < wsb:
                 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
                 bufs[("ws", l)] = ws
             last = l == n_conv - 1
-            rc = lib.hcg_fused_layer_bwd(None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None,
-                                         p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                         p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope, 1, p(dx), p(plan.status), p(ws), wsb,
-                                         stream)
-            _lib.check(rc, "hcg_fused_layer_bwd")
-            _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight), g(convs[l].bias),
-                                                jaddr + njobs * jb), "hcg_fused_reduce_job")
+            up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
+            if small:
+                rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                             p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope, 1, p(dx), p(plan.status), p(ws),
+                                             wsb, stream)
+                _lib.check(rc, "hcg_fused_layer_bwd")
+                _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
+                                                    g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
+            else:
+                rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(dx), p(plan.status), p(ws),
+                                           wsb, stream)
+                _lib.check(rc, "hcg_mid_layer_bwd")
+                _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, g(convs[l].lin.weight), g(convs[l].bias),
+                                                  jaddr + njobs * jb), "hcg_mid_reduce_job")
             njobs += 1
             dh = dx
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam

@@ -62,13 +62,15 @@ def _oracle_grads(oracle, m, sb):
     return oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
 
 
-@pytest.mark.parametrize("cfg,ng,feat", [("C2", 96, 64), ("C2", 4096, 64), ("C2", 50, 25)])
-def test_fused_train_step_gradients_match_oracle(H, oracle, cfg, ng, feat):
+@pytest.mark.parametrize("cfg,ng,feat,nodes", [("C2", 96, 64, 30), ("C2", 4096, 64, 30), ("C2", 50, 25, 30), ("C2", 64, 25, 87),
+                                               ("C2", 40, 64, 150)])
+def test_fused_train_step_gradients_match_oracle(H, oracle, cfg, ng, feat, nodes):
     """FusedTrainStep(optimizer_step=False): loss and every weight gradient vs oracle autograd; the gradients sit
-    in ONE flat buffer in parameter order."""
+    in ONE flat buffer in parameter order.  30-atom graphs run the small-graph tiles, 87 / 150-atom graphs (the
+    reference's sizes) the one-graph-per-workgroup kernels."""
     from hcatgnet_amd import synth
     from hcatgnet_amd.train import FusedTrainStep
-    sb = synth.make_config(cfg, num_graphs=ng)
+    sb = synth.make_config(cfg, num_graphs=ng, nodes=nodes, **({} if nodes == 30 else {"seed": 12}))
     if feat != 64:
         sb.x = sb.x[:, :feat].contiguous()
     m = H.make_network("GCN", H.default_options(), feat).cuda()
