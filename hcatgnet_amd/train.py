@@ -250,7 +250,8 @@ class FusedTrainStep:
         hold then (copy the next batch into them, or re-collate in place).  `batch` may be a callable returning the
         batch: whatever it enqueues (a device collate, the plan build of a fresh `Batch`) is captured too.  The optimiser switches to its
         device-side step counter / learning rate (`FusedAdam.enable_capturable`); the gradient exchange
-        (`grad_sync`) is NOT captured: it runs eagerly between the captured backward and a captured update."""
+        (`grad_sync`) is NOT captured: with one, the graph ends after the slab reduction and `replay()` issues the
+        collective and the (single-launch) update eagerly behind it."""
         opt = self.model.optimizer
         if self.optimizer_step:
             if not hasattr(opt, "enable_capturable"):
@@ -271,25 +272,20 @@ class FusedTrainStep:
             g_main = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_main):
                 loss = self(get())
-            g_opt = None
-            if do_opt and sync is not None:          # exchange in the middle: the update gets a graph of its own
-                g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_opt):
-                    self.model.optimizer.step()
         finally:
             self.grad_sync, self.optimizer_step = sync, do_opt
-        self._graph = (g_main, g_opt, loss)
+        self._graph = (g_main, loss)
         return self
 
     def replay(self):
-        g_main, g_opt, loss = self._graph
+        g_main, loss = self._graph
         if self.optimizer_step:
             self.model.optimizer.sync_lr()
         g_main.replay()
-        if self.grad_sync is not None:
-            self.grad_sync(self._flat)
-        if g_opt is not None:
-            g_opt.replay()
+        if self.grad_sync is not None:               # exchange between the captured backward and the update:
+            self.grad_sync(self._flat)               # one collective on the flat gradient, then ONE eager launch
+            if self.optimizer_step:
+                self.model.optimizer.step()
         return loss
 
 

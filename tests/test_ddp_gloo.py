@@ -47,7 +47,11 @@ def _worker(rank, world, port, q):
             p.grad = torch.full_like(p, float(rank + 1))
         s = dp.reduce_gradients(average=False)
         ok_sum = torch.allclose(s, torch.full_like(s, 3.0))
-        q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum))
+        # the hook of the fused trainer: one flat buffer (what the fused backward writes), averaged IN PLACE
+        fb = torch.full((16641,), float(rank + 1))
+        out = dp.reduce_flat(fb)
+        ok_hook = out.data_ptr() == fb.data_ptr() and torch.allclose(fb, torch.full_like(fb, 1.5))
+        q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum, ok_hook))
     finally:
         dist.destroy_process_group()
 

@@ -197,3 +197,46 @@ def test_forty_launches_are_bitwise_identical(H):
             continue
         for k, (a, b) in enumerate(zip(ref, cur)):
             assert torch.equal(a, b), (rep, k)
+
+
+def test_fused_trainer_with_rccl_exchange_world1(H):
+    """The multi-GPU step on the one GPU we have: backend "nccl" (= RCCL), world size 1, exchange forced.  Eager
+    step = backward -> all-reduce of the flat gradient in place -> Adam; captured step = graph (plan .. slab reduction)
+    -> eager all-reduce -> eager single-launch Adam.  Both must equal the plain single-process step."""
+    import os
+    import torch.distributed as dist
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.ddp import DataParallelGCN
+    from hcatgnet_amd.train import FusedTrainStep
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        created = True
+    try:
+        sb = synth.make_config("C2", num_graphs=512)
+        x, ei, bv, y = sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.y.cuda()
+        fresh = lambda: H.Batch(x, ei, bv, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+        models = [H.make_network("GCN", H.default_options(), 64).cuda() for _ in range(3)]
+        for m in models[1:]:
+            m.load_state_dict(models[0].state_dict())
+        plain = FusedTrainStep(models[0])
+        dp1 = DataParallelGCN(models[1], force_collective=True)
+        eager = FusedTrainStep(models[1], grad_sync=dp1.reduce_flat)
+        dp2 = DataParallelGCN(models[2], force_collective=True)
+        graphed = FusedTrainStep(models[2], grad_sync=lambda flat: None)
+        graphed.capture(fresh)                     # (captured before the hook is live, like bench.py does before RCCL is up)
+        graphed.grad_sync = dp2.reduce_flat
+        for _ in range(2):
+            plain(fresh()); eager(fresh())         # the capture ran two warm-up steps
+        la = [float(plain(fresh())) for _ in range(3)]
+        lb = [float(eager(fresh())) for _ in range(3)]
+        lc = [float(graphed.replay()) for _ in range(3)]
+        for u, v, w in zip(la, lb, lc):
+            assert abs(u - v) <= 1e-6 * abs(u) and abs(u - w) <= 1e-6 * abs(u)
+        for pa, pb, pc in zip(*[m.parameters() for m in models]):
+            assert rel_inf(pb, pa) <= 1e-6 and rel_inf(pc, pa) <= 1e-6
+    finally:
+        if created:
+            dist.destroy_process_group()
