@@ -147,6 +147,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a ONE-GPU box (tools/rehearse_multi_rank.sh): every rank on device 0,
+    # gloo instead of RCCL (RCCL refuses two ranks on one device).  Never set by the driver; the numbers mean nothing.
+    rehearsal = os.environ.get("HCG_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -238,14 +243,14 @@ def main():
 
     def timed(k, fn):
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
             fn()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -274,7 +279,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         dp = DataParallelGCN(model)           # broadcasts rank-0 weights (in place: the graphs see them)
         if fused_ok:
             trainer.grad_sync = dp.reduce_flat
