@@ -329,13 +329,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
   __syncthreads();
-#ifndef HCG_STAGGER
-#define HCG_STAGGER 0
-#endif
-  if (HCG_STAGGER > 0 && wave >= 4) {   // second wave of each SIMD: start out of phase with the first one
-#pragma unroll
-    for (int k = 0; k < HCG_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-  }
   STAMP(0);
   int stamp_it = 0;
   // adjacency fragments + dinv of this lane's 16 accumulator rows: read ONCE per tile into registers, shared by
@@ -360,10 +353,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     Stager<KPAD, VEC> sxn;
     const TileRaw raw_cur = raw_next;                                    // loaded one tile ago
     raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // consumed one tile from now
-#ifndef HCG_DBG_NOPF
-#define HCG_DBG_NOPF 0
-#endif
-    if (VEC && have_next && !HCG_DBG_NOPF) {   // (the scalar-staging variants are short of registers: they load after the compute)
+    if (VEC && have_next) {   // (the scalar-staging variants are short of registers: they load after the compute)
       tin = tile_finish(raw_cur, gpt, lane, status);
       sxn.load(x, F, N, tin.nbase, tin.n, lane);
       ten.load(tin, graph_ptr, ei, E, lane);
@@ -478,7 +468,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 
     have = have_next;
     if (have_next) {
-      if (!VEC || HCG_DBG_NOPF) {
+      if (!VEC) {
         tin = tile_finish(raw_cur, gpt, lane, status);
         sxn.load(x, F, N, tin.nbase, tin.n, lane);
         ten.load(tin, graph_ptr, ei, E, lane);

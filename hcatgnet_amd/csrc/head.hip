@@ -13,6 +13,13 @@
 // Contractions on v_mfma_f32_32x32x2_f32 (exact f32): the head is latency-bound, not MFMA-bound.
 #include "common.h"
 
+#ifdef HCG_HEAD_STAMP
+__device__ unsigned long long g_head_stamp[16 * 16];
+#define HSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); g_head_stamp[blockIdx.x * 16 + (i)] = _t; } } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   const int tiles = (B + RT - 1) / RT;
   const int nblk = gridDim.x;
   const int gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // launches completed so far
+  HSTAMP(0);
 
   // weights -> LDS once.  Every global load of the prologue is issued before the first LDS write (a load-store
   // loop would serialise 32 HBM round trips per thread: that alone cost ~15 us of this launch-latency-bound kernel)
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     __syncthreads();                                    // previous tile's readers are done (also orders the weight staging)
     stage_rows<RK>(L.e, ES, emb, g0, n, B);
     __syncthreads();
+    HSTAMP(1);
     staged = t;
     f32x16 acc;
 #pragma unroll
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
     }
     mfma_results_fence(acc);
+    HSTAMP(2);
     if (kh == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) L.part[nb][krow(i, h) * 33 + r] = acc[i];
@@ -233,9 +243,11 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   if (lane == 0) L.red[wave] = sse;
   __syncthreads();
   const float block_sse = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
+  HSTAMP(3);
 
   // ---------------------------------------------------------------- grid-wide: every workgroup gets the batch's squared error
   const float total_sse = exchange_partials(sync, nblk, gen, block_sse, L.bcast);
+  HSTAMP(4);
 
   // ---------------------------------------------------------------- phase 2: loss, dout, backward
   if (threadIdx.x == 0) {
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       *reinterpret_cast<float4*>(L.z + row * ZS + 4 * q) = dzv[it];
     }
     __syncthreads();
+    HSTAMP(5);
     // 2. dW0[:, cb] += dz^T emb[:, cb]   (K = graph rows)
 #pragma unroll
     for (int s = 0; s < RT / 2; ++s) {
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
       de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
     }
     mfma_results_fence(de);
+    HSTAMP(6);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = krow(i, h);
@@ -372,6 +386,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     }
   }
   __syncthreads();
+  HSTAMP(7);
   for (int idx = threadIdx.x; idx < SMALL; idx += HW * 64)
     slab[RD * RK + idx] = ((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx];
 }
