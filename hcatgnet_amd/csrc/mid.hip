@@ -175,7 +175,8 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
 }
 
 // Stage rows [nbase, nbase + n) of a row-major [Nrows, F] matrix into t[row][0..KPAD) (zero padded to KPAD columns and
-// to whole 32-row blocks).  All MT threads; no trailing barrier.
+// to whole 32-row blocks).  All MT threads; no trailing barrier.  (Batching every load of the graph into registers first
+// was measured: it costs the forward its second workgroup per CU -- 218 VGPRs -- and ran 1.7x slower.)
 template <int KPAD>
 __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restrict__ g, int F, int nbase, int n, int nblk) {
   const int tid = threadIdx.x;
@@ -333,6 +334,18 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     const int rows = gi.nblk * 32;
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
+    //         this thread's rows (row group rg, float4 column group c4): all global loads first, used by both passes
+    constexpr int NR = MID_MAX_NODES / (MT / 16);
+    float4 av[NR], dv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int row = rg + j * (MT / 16);
+      if (j * (MT / 16) < rows) {                          // block-uniform
+        const size_t at = (size_t)(gi.nbase + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * DD + 4 * c4;
+        av[j] = *reinterpret_cast<const float4*>(a_out + at);
+        if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(dout + at);
+      }
+    }
     float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
     if (POOLG) {
       gmx = *reinterpret_cast<const float4*>(emb + (size_t)g * 2 * DD + 4 * c4);
@@ -341,11 +354,15 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       const float cntf = (float)(gi.n > 0 ? gi.n : 1);
       dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int row = rg; row < gi.n; row += MT / 16) {
-        const float4 a = *reinterpret_cast<const float4*>(a_out + (size_t)(gi.nbase + row) * DD + 4 * c4);
-        ties.x += (a.x == gmx.x); ties.y += (a.y == gmx.y); ties.z += (a.z == gmx.z); ties.w += (a.w == gmx.w);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int row = rg + j * (MT / 16);
+        if (j * (MT / 16) < rows && row < gi.n) {
+          const float4 a = av[j];
+          ties.x += (a.x == gmx.x); ties.y += (a.y == gmx.y); ties.z += (a.z == gmx.z); ties.w += (a.w == gmx.w);
+        }
       }
-      float* sc = L.t1;                                  // [16 row groups][64] scratch (t1 is free here)
+      float* sc = L.t1;                                  // [MT / 16 row groups][64] scratch (t1 is free here)
       *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = ties;
       __syncthreads();
       float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -357,25 +374,29 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
       __syncthreads();                                   // scratch reads done before step 2 writes t1
     }
-    for (int row = rg; row < rows; row += MT / 16) {
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < gi.n) {
-        const float4 a = *reinterpret_cast<const float4*>(a_out + (size_t)(gi.nbase + row) * DD + 4 * c4);
-        if (POOLG) {
-          d = make_float4(dmean.x + (a.x == gmx.x ? share.x : 0.f), dmean.y + (a.y == gmx.y ? share.y : 0.f),
-                          dmean.z + (a.z == gmx.z ? share.z : 0.f), dmean.w + (a.w == gmx.w ? share.w : 0.f));
-        } else {
-          d = *reinterpret_cast<const float4*>(dout + (size_t)(gi.nbase + row) * DD + 4 * c4);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int row = rg + j * (MT / 16);
+      if (j * (MT / 16) < rows && row < rows) {
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < gi.n) {
+          const float4 a = av[j];
+          if (POOLG) {
+            d = make_float4(dmean.x + (a.x == gmx.x ? share.x : 0.f), dmean.y + (a.y == gmx.y ? share.y : 0.f),
+                            dmean.z + (a.z == gmx.z ? share.z : 0.f), dmean.w + (a.w == gmx.w ? share.w : 0.f));
+          } else {
+            d = dv[j];
+          }
+          if (apply_act) {
+            d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
+            d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
+          }
+          dbacc.x += d.x; dbacc.y += d.y; dbacc.z += d.z; dbacc.w += d.w;
+          const float di = L.dinv[row];
+          d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
         }
-        if (apply_act) {
-          d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
-          d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
-        }
-        dbacc.x += d.x; dbacc.y += d.y; dbacc.z += d.z; dbacc.w += d.w;
-        const float di = L.dinv[row];
-        d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
+        *reinterpret_cast<float4*>(L.t0 + row * HS + 4 * c4) = d;
       }
-      *reinterpret_cast<float4*>(L.t0 + row * HS + 4 * c4) = d;
     }
     __syncthreads();
 
