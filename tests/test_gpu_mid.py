@@ -106,3 +106,37 @@ def test_mid_path_reproduces_reference_golden_vectors(H, path):
     assert HF.mid_supported(b._hcg_plan, gd["x"].shape[1], 64)
     assert rel_inf(emb, gd["ref_emb"]) <= 1e-5
     assert float((out[:, 0].cpu() - gd["ref_pred"]).abs().max()) <= 5e-5
+
+
+def test_mid_full_size_properties(H, oracle):
+    """2048 graphs of the reference's sizes (57-117 atoms, F = 25) in one batch -- 178 k nodes: embeddings vs the oracle,
+    five launches bit-identical (forward and every gradient), and graph independence: a 50-graph sub-batch reproduces
+    its slice of the outputs bitwise."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("REAL", num_graphs=2048)
+    params = _rand_params(25, 64, seed=41)
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    with torch.no_grad():
+        out, emb = m(batch, True)
+    o_out, o_emb = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs)
+    assert rel_inf(emb, o_emb) <= TOL and rel_inf(out, o_out, floor=1.0) <= TOL
+    step = FusedTrainStep(m, optimizer_step=False)
+    ref = None
+    for rep in range(5):
+        loss = step(batch)
+        cur = [loss.clone(), step._flat.clone(), step.last_out.clone()]
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur)), rep
+    assert rel_inf(ref[2], out, floor=1.0) <= 1e-6       # training-step head (head.hip) vs inference head (readout.hip): other sum order
+    nsub = 50
+    n_nodes = int((sb.batch < nsub).sum()); n_edges = int((sb.edge_index[0] < n_nodes).sum())
+    sizes = torch.bincount(sb.batch[:n_nodes])
+    b2 = H.Batch(sb.x[:n_nodes].cuda(), sb.edge_index[:, :n_edges].cuda(), sb.batch[:n_nodes].cuda(), nsub,
+                 max_nodes=int(sizes.max()), max_edges=sb.max_edges, edges_grouped=True)
+    with torch.no_grad():
+        o_sub = m(b2)
+    assert torch.equal(o_sub, out[:nsub])
