@@ -305,6 +305,17 @@ def main():
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
     dt_eager = timed(args.steps, eager_step)
     log(f"timed eager (full step): {dt_eager / args.steps * 1e3:.3f} ms/step")
+    # distribution of single steps (median, p10 / p90): HIP events around every step of one more pass
+    evs = []
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eager_step()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    per_step = sorted(a.elapsed_time(b) for a, b in evs)
+    pct = {f"p{q}": per_step[min(len(per_step) - 1, int(len(per_step) * q / 100))] for q in (10, 50, 90)}
     dt_best, dt_fb, dt_graph = dt_eager, None, None
     if "full" in replay:
         for _ in range(max(3, args.warmup // 2)):
@@ -375,6 +386,7 @@ def main():
             "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), inside the timed step",
             "step_path": "FusedTrainStep (no autograd)" if fused_ok else "autograd",
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
+            "eager_step_ms_percentiles_hip_events": pct,
             "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3,
             "hipgraph_ms_per_step": (dt_graph / args.steps * 1e3) if "full" in replay else None, "graph_capture_error": graph_err,
         }
