@@ -612,6 +612,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     TileInfo tin;
     Stager<DD, true> san, sdn;
     TileEdges ten;
+    // x rows of THIS tile: in the variant with registers to spare (no dx, no pooled prologue) they are requested here,
+    // one aggregation ahead of their use, instead of waiting out an HBM round trip in front of the dW MFMAs
+#ifndef HCG_EARLY_X
+#define HCG_EARLY_X 1
+#endif
+    constexpr bool EARLY_X = HCG_EARLY_X && !NEEDS_DX && !POOLG;
+    Stager<KPAD, VEC> sx;
+    if (EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
 
     // ---- 2. dH = dinv (.) ( (C + I)^T dY' ):  A[m = j][k = i] = cnt[i][j] (exact),  B[k = i][col] = dY'[i][col] (split)
     AdjFrags adj;
@@ -641,8 +649,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 
     // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (slot j of k-step s <-> node krow(8s + j, h)),
     //         B[k = node][f] read down the columns of the x tile
-    Stager<KPAD, VEC> sx;
-    sx.load(x, F, N, ti.nbase, ti.n, lane);
+    if (!EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
     sx.write(L.buf, F, ti.n, lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   }
 }
 
-constexpr int CS_MAX_PARTS = 128;   // partial rows after stage 1
+constexpr int CS_MAX_PARTS = 1024;  // partial rows after stage 1 (enough workgroups to fill 256 CUs several times over)
 
 // partial[b][d] = sum over the row chunk of block b of src[m][d] * (mask ? leaky'(mask[m][d]) : 1);
 // 64 feature lanes x 4 row lanes per block, the 4 row lanes combined in a fixed order
@@ -127,7 +127,17 @@ __global__ __launch_bounds__(256) void k_colsum_stage1(const float* __restrict__
   const int64_t mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   float s = 0.f;
   if (d < D) {
-    for (int64_t m = mbeg + rl; m < mend; m += 4) {
+    // four rows in flight per thread (independent loads), added in row order: the result does not depend on the unroll
+    int64_t m = mbeg + rl;
+    for (; m + 12 < mend; m += 16) {
+      float v0 = src[m * D + d], v1 = src[(m + 4) * D + d], v2 = src[(m + 8) * D + d], v3 = src[(m + 12) * D + d];
+      if (mask) {
+        v0 *= hcg_leaky_grad(mask[m * D + d], slope); v1 *= hcg_leaky_grad(mask[(m + 4) * D + d], slope);
+        v2 *= hcg_leaky_grad(mask[(m + 8) * D + d], slope); v3 *= hcg_leaky_grad(mask[(m + 12) * D + d], slope);
+      }
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; m < mend; m += 4) {
       float v = src[m * D + d];
       if (mask) v *= hcg_leaky_grad(mask[m * D + d], slope);
       s += v;
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(256) void k_colsum_stage2(const float* __restrict__
   const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= D) return;
   float s = 0.f;
+#pragma unroll 8
   for (int64_t b = 0; b < nb; ++b) s += partial[(size_t)b * D + d];
   out[d] = s;
 }
