@@ -169,6 +169,11 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   int staged = -1;
   for (int t = blockIdx.x; t < tiles; t += nblk) {
     const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
+    // the targets of this tile are requested here, a whole GEMM ahead of their use (unconditional, clamped)
+    float yv[RCMAX];
+#pragma unroll
+    for (int c = 0; c < RCMAX; ++c)
+      yv[c] = y[(size_t)(g0 + orow < B ? g0 + orow : B - 1) * C + (c < C ? c : C - 1)];
     __syncthreads();                                    // previous tile's readers are done (also orders the weight staging)
     stage_rows<RK>(L.e, ES, emb, g0, n, B);
     __syncthreads();
@@ -206,10 +211,6 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     __syncthreads();
     {   // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y.  Thread (row, j): hidden units 8j..8j+7 of every class,
         // the 8 partial sums of a row meet by xor-shuffles (fixed order); the target is loaded ahead of the arithmetic
-      float yv[RCMAX];
-#pragma unroll
-      for (int c = 0; c < RCMAX; ++c)   // unconditional, clamped (a guarded load would sit behind its own wait)
-        yv[c] = y[(size_t)(g0 + orow < B ? g0 + orow : B - 1) * C + (c < C ? c : C - 1)];
       const float4 za = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj);
       const float4 zb = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj + 4);
 #pragma unroll
