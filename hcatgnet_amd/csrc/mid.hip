@@ -21,7 +21,7 @@ namespace {
 
 constexpr int MW = 8;                 // waves per workgroup (two per SIMD: the per-graph phases are latency chains)
 constexpr int MT = MW * 64;           // threads
-constexpr int MID_MAX_NODES = 192;    // 6 row blocks of 32
+constexpr int MID_MAX_NODES = 224;    // 7 row blocks of 32 (two fp32 tiles + one weight image still fit 160 KB of LDS)
 constexpr int MID_MAX_EDGES = 2048;   // directed edges of one graph (LDS col array, 16-bit ids)
 
 struct MidLds {   // carved out of dynamic shared memory by carve()
@@ -122,12 +122,13 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
   }
   if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
   __syncthreads();
-  // exclusive scan of the row sizes by wave 0 (<= 192 rows: 3 per lane), dinv for every row
+  // exclusive scan of the row sizes by wave 0 (<= 256 rows: 4 per lane), dinv for every row
   if (tid < 64) {
-    int v[MID_MAX_NODES / 64], tot = 0;
+    constexpr int RPL = (MID_MAX_NODES + 63) / 64;
+    int v[RPL], tot = 0;
 #pragma unroll
-    for (int j = 0; j < MID_MAX_NODES / 64; ++j) {
-      const int i = tid * (MID_MAX_NODES / 64) + j;
+    for (int j = 0; j < RPL; ++j) {
+      const int i = tid * RPL + j;
       v[j] = i < nrows ? L.cursor[i] : 0;
       tot += v[j];
     }
@@ -139,8 +140,8 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
     }
     int run = incl - tot;
 #pragma unroll
-    for (int j = 0; j < MID_MAX_NODES / 64; ++j) {
-      const int i = tid * (MID_MAX_NODES / 64) + j;
+    for (int j = 0; j < RPL; ++j) {
+      const int i = tid * RPL + j;
       if (i < nrows) L.rowptr[i] = run;
       run += v[j];
     }
@@ -174,25 +175,26 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
   __syncthreads();
 }
 
-// Stage rows [nbase, nbase + n) of a row-major [Nrows, F] matrix into t[row][0..KPAD) (zero padded to KPAD columns and
-// to whole 32-row blocks).  All MT threads; no trailing barrier.  (Batching every load of the graph into registers first
-// was measured: it costs the forward its second workgroup per CU -- 218 VGPRs -- and ran 1.7x slower.)
+// Stage columns [c0, c0 + KPAD) of rows [nbase, nbase + n) of a row-major [Nrows, F] matrix into t[row][0..KPAD) (zero
+// padded past column F and to whole 32-row blocks).  All MT threads; no trailing barrier.  (Batching every load of the
+// graph into registers first was measured: it costs the forward its second workgroup per CU -- 218 VGPRs -- and ran
+// 1.7x slower.)
 template <int KPAD>
-__device__ __forceinline__ void stage_graph_rows(float* t, const float* __restrict__ g, int F, int nbase, int n, int nblk) {
+__device__ __forceinline__ void stage_graph_rows(float* t, const float* __restrict__ g, int F, int c0, int nbase, int n, int nblk) {
   const int tid = threadIdx.x;
   const int rows = nblk * 32;
-  if (F == KPAD && ((uintptr_t)g % 16 == 0)) {
+  if (c0 + KPAD <= F && (F & 3) == 0 && ((uintptr_t)g % 16 == 0)) {
     constexpr int PER_ROW = KPAD / 4;
     for (int idx = tid; idx < rows * PER_ROW; idx += MT) {
       const int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < n) v = *reinterpret_cast<const float4*>(g + (size_t)(nbase + row) * F + 4 * c4);
+      if (row < n) v = *reinterpret_cast<const float4*>(g + (size_t)(nbase + row) * F + c0 + 4 * c4);
       *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = v;
     }
   } else {
     for (int idx = tid; idx < rows * KPAD; idx += MT) {
       const int row = idx / KPAD, c = idx - row * KPAD;
-      t[row * HS + c] = (row < n && c < F) ? g[(size_t)(nbase + row) * F + c] : 0.f;
+      t[row * HS + c] = (row < n && c0 + c < F) ? g[(size_t)(nbase + row) * F + c0 + c] : 0.f;
     }
   }
 }
@@ -200,41 +202,76 @@ __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restri
 // =====================================================================================================
 // forward of one layer, one graph per workgroup iteration
 // =====================================================================================================
-template <int KPAD, bool POOL>
+// One launch produces 64 output columns [coff, coff + 64) of a layer `ldo` columns wide (ldo = 64: the whole layer; ldo =
+// 128: one of two independent column halves -- W / bias already point at the half's rows).  Inputs wider than 64
+// features are contracted in K-chunks of 64 through the same LDS tile (accumulators stay in registers: a wave owns ONE
+// 32-row block, the host guarantees nblk <= 8).
+template <int KPAD, bool POOL, bool MULTIK>
 __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int64_t* __restrict__ ei,
                                                          int64_t E, const int32_t* __restrict__ graph_ptr,
                                                          const int32_t* __restrict__ edge_ptr, int B, int npad, int emax,
-                                                         float slope, int apply_act, float* __restrict__ out,
+                                                         float slope, int apply_act, float* __restrict__ out, int ldo, int coff,
                                                          float* __restrict__ emb, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const MidLds L = carve(smem, npad, emax, DD, KPAD, false);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
+  const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
 
-  stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F);
+  if (!MULTIK) stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F);    // one chunk: the weight image is loop invariant
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
   __syncthreads();
 
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
-    stage_graph_rows<KPAD>(L.t0, x, F, gi.nbase, gi.n, gi.nblk);
+    stage_graph_rows<KPAD>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
     build_csr<false>(L, gi, ei, E, status, nullptr);                // (ends with a barrier: the x tile is complete too)
 
     // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
-    for (int mb = wave; mb < gi.nblk; mb += MW) {
+    if constexpr (!MULTIK) {
+      for (int mb = wave; mb < gi.nblk; mb += MW) {
+        float* blk = L.t0 + mb * 32 * HS;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
+        mfma_results_fence(acc0, acc1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = krow(i, h);
+          const float dv = L.dinv[mb * 32 + row];
+          blk[row * HS + r] = acc0[i] * dv;
+          blk[row * HS + 32 + r] = acc1[i] * dv;
+        }
+      }
+    } else {
+      // inputs wider than 64 features: K-chunk by K-chunk through the same tile; the accumulators stay in registers (a
+      // wave owns ONE block: the host guarantees nblk <= 8)
+      const int mb = wave;
       float* blk = L.t0 + mb * 32 * HS;
       f32x16 acc0, acc1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-      tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
-      mfma_results_fence(acc0, acc1);
+      for (int kc = 0; kc < nkc; ++kc) {
+        if (kc > 0) {
+          __syncthreads();                                           // every wave is done with the previous chunk
+          stage_graph_rows<KPAD>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
+        }
+        stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F, kc * KPAD);
+        __syncthreads();
+        if (mb < gi.nblk) tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
+      }
+      __syncthreads();                                               // the last x chunk is dead: H' may overwrite it
+      if (mb < gi.nblk) {
+        mfma_results_fence(acc0, acc1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = krow(i, h);
-        const float dv = L.dinv[mb * 32 + row];
-        blk[row * HS + r] = acc0[i] * dv;
-        blk[row * HS + 32 + r] = acc1[i] * dv;
+        for (int i = 0; i < 16; ++i) {
+          const int row = krow(i, h);
+          const float dv = L.dinv[mb * 32 + row];
+          blk[row * HS + r] = acc0[i] * dv;
+          blk[row * HS + 32 + r] = acc1[i] * dv;
+        }
       }
     }
     __syncthreads();
@@ -259,7 +296,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
         if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
         if (valid) {
-          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * DD + 4 * q) = y;
+          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * ldo + coff + 4 * q) = y;
           if (POOL) {
             pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
             psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
@@ -287,8 +324,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
           s += L.red[w * 2 * DD + DD + tid];
         }
         if (gi.n <= 0) m = 0.f;
-        emb[(size_t)g * 2 * DD + tid] = m;
-        emb[(size_t)g * 2 * DD + DD + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
+        emb[(size_t)g * 2 * ldo + coff + tid] = m;                                   // [max | mean], each ldo wide
+        emb[(size_t)g * 2 * ldo + ldo + coff + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
       }
     }
     __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
@@ -301,12 +338,15 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
 //   db += colsum dY ;  dH = Ahat^T dY ;  dW += dH^T x ;  dx = dH W  (NEEDS_DX)
 // per-workgroup partial sums go to `partials[blockIdx][64*KPAD + 64]` (same slab layout as fused.hip).
 // =====================================================================================================
-template <int KPAD, bool NEEDS_DX, bool POOLG>
+// One launch handles 64 of the layer's `ldo` output columns, [coff, coff + 64) (ldo = 128: one of two column halves; W
+// already points at the half's rows, dW / db of the half go to this launch's own slabs).  Inputs wider than 64 features
+// are handled in f-chunks of 64 through the same tiles.  ACC_DX: add to dx instead of storing (second column half).
+template <int KPAD, int NFC, bool NEEDS_DX, bool POOLG>
 __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb,
-    const float* __restrict__ a_out, const float* __restrict__ x, int F, const float* __restrict__ W,
+    const float* __restrict__ a_out, int ldo, int coff, const float* __restrict__ x, int F, const float* __restrict__ W,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
-    int B, int npad, int emax, float slope, int apply_act, float* __restrict__ dx, float* __restrict__ partials,
+    int B, int npad, int emax, float slope, int apply_act, float* __restrict__ dx, int acc_dx, float* __restrict__ partials,
     int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const MidLds L = carve(smem, npad, emax, NEEDS_DX ? KPAD : 0, DD, true);
@@ -314,18 +354,22 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   constexpr int NBF = KPAD / 32;
   constexpr int ld = DD + WPAD, plane = KPAD * ld;
-  const int c4 = tid & 15, rg = tid >> 4;             // step 1: this thread's float4 column group / row group (16 of them)
+  constexpr int FPAD = NFC * KPAD;                    // padded input width of the slab rows
+  const int c4 = tid & 15, rg = tid >> 4;             // step 1: this thread's float4 column group / row group
 
-  if (NEEDS_DX) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
+  if (NEEDS_DX && NFC == 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
   __syncthreads();
 
-  // dW: 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every NPART-th k-step
+  // dW: per f-chunk 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every
+  // NPART-th k-step
   constexpr int NBLOCKS = 2 * NBF, NPART = MW / NBLOCKS;
   const int blk_id = wave % NBLOCKS, part = wave / NBLOCKS;
   const int mbw = blk_id / NBF, nbw = blk_id % NBF;
-  f32x16 dw;
+  f32x16 dw[NFC];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) dw[i] = 0.f;
+  for (int fc = 0; fc < NFC; ++fc)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dw[fc][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
@@ -341,16 +385,17 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int j = 0; j < NR; ++j) {
       const int row = rg + j * (MT / 16);
       if (j * (MT / 16) < rows) {                          // block-uniform
-        const size_t at = (size_t)(gi.nbase + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * DD + 4 * c4;
+        const size_t at = (size_t)(gi.nbase + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * ldo + coff + 4 * c4;
         av[j] = *reinterpret_cast<const float4*>(a_out + at);
         if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(dout + at);
       }
     }
     float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
     if (POOLG) {
-      gmx = *reinterpret_cast<const float4*>(emb + (size_t)g * 2 * DD + 4 * c4);
-      const float4 dmx = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + 4 * c4);
-      dmean = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + DD + 4 * c4);
+      const size_t eb = (size_t)g * 2 * ldo + coff + 4 * c4;       // [max | mean], each ldo wide
+      gmx = *reinterpret_cast<const float4*>(emb + eb);
+      const float4 dmx = *reinterpret_cast<const float4*>(demb + eb);
+      dmean = *reinterpret_cast<const float4*>(demb + eb + ldo);
       const float cntf = (float)(gi.n > 0 ? gi.n : 1);
       dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -421,86 +466,94 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     }
     __syncthreads();
 
-    // ---- 3. x tile -> t0
-    stage_graph_rows<KPAD>(L.t0, x, F, gi.nbase, gi.n, gi.nblk);
-    __syncthreads();
+#pragma unroll
+    for (int fc = 0; fc < NFC; ++fc) {
+      // ---- 3. x chunk -> t0 (and, chunked, the matching rows of the dx operand image)
+      stage_graph_rows<KPAD>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
+      if (NEEDS_DX && NFC > 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F, fc * KPAD);
+      __syncthreads();
 
-    // ---- 4. dW[mbw][nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
-    {
+      // ---- 4. dW[mbw][fc, nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
       for (int ks = part; ks < gi.nblk * 2; ks += NPART) {
-        float av[8], bv[8];
+        float avv[8], bvv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int node = 16 * ks + 8 * h + j;
-          av[j] = L.t1[node * HS + mbw * 32 + r];
-          bv[j] = L.t0[node * HS + nbw * 32 + r];
+          avv[j] = L.t1[node * HS + mbw * 32 + r];
+          bvv[j] = L.t0[node * HS + nbw * 32 + r];
         }
-        const Split3 A = split3(av), Bx = split3(bv);
-        mfma_split(dw, A, Bx.p1, Bx.p2, Bx.p3);
+        const Split3 A = split3(avv), Bx = split3(bvv);
+        mfma_split(dw[fc], A, Bx.p1, Bx.p2, Bx.p3);
       }
-    }
 
-    // ---- 5. dx = dH W, each wave on its own row blocks
-    if (NEEDS_DX) {
-      for (int mb = wave; mb < gi.nblk; mb += MW) {
-        const float* blk = L.t1 + mb * 32 * HS;
-        f32x16 dxa[NBF];
+      // ---- 5. dx[:, chunk] (+)= dH W[:, chunk], each wave on its own row blocks
+      if (NEEDS_DX) {
+        for (int mb = wave; mb < gi.nblk; mb += MW) {
+          const float* blk = L.t1 + mb * 32 * HS;
+          f32x16 dxa[NBF];
 #pragma unroll
-        for (int nb = 0; nb < NBF; ++nb)
+          for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) dxa[nb][i] = 0.f;
+            for (int i = 0; i < 16; ++i) dxa[nb][i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < DD / 16; ++s) {
-          const float4 a0 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h);
-          const float4 a1 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h + 4);
-          const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-          const Split3 A = split3(xa);
-#pragma unroll
-          for (int nb = 0; nb < NBF; ++nb) {
-            const short* w0 = L.wl + (nb * 32 + r) * ld + 16 * s + 8 * h;
-            mfma_split(dxa[nb], A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
-                       *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
-          }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = mb * 32 + krow(i, h);
-          if (row < gi.n) {
+          for (int s = 0; s < DD / 16; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h);
+            const float4 a1 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h + 4);
+            const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const Split3 A = split3(xa);
 #pragma unroll
             for (int nb = 0; nb < NBF; ++nb) {
-              const int f = nb * 32 + r;
-              if (f < F) dx[(size_t)(gi.nbase + row) * F + f] = dxa[nb][i];
+              const short* w0 = L.wl + (nb * 32 + r) * ld + 16 * s + 8 * h;
+              mfma_split(dxa[nb], A, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
+                         *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
+            }
+          }
+#pragma unroll
+          for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = mb * 32 + krow(i, h);
+            if (row < gi.n) {
+#pragma unroll
+              for (int nb = 0; nb < NBF; ++nb) {
+                const int f = fc * KPAD + nb * 32 + r;
+                if (f < F) {
+                  float* dst = dx + (size_t)(gi.nbase + row) * F + f;
+                  *dst = acc_dx ? *dst + dxa[nb][i] : dxa[nb][i];
+                }
+              }
             }
           }
         }
       }
+      __syncthreads();   // t0 / the operand image are free for the next chunk (or the next graph)
     }
-    __syncthreads();   // tiles / CSR free for the next graph
   }
 
-  // ---- publish this workgroup's slab: dW [64][KPAD] | db [64]
-  constexpr int SLABF = DD * KPAD + DD;
+  // ---- publish this workgroup's slab: dW [64][FPAD] | db [64]
+  constexpr int SLABF = DD * FPAD + DD;
   float* slab = partials + (size_t)blockIdx.x * SLABF;
-  mfma_results_fence(dw);
   float* comb = L.t0;                                    // [NBLOCKS][32 * 32]: the K parts of a block meet here, fixed order
   static_assert(NBLOCKS * 1024 * 4 <= 2 * 32 * HS * 4, "combine scratch must fit in the two smallest tiles");
-  for (int round = 0; round < NPART; ++round) {
-    if (part == round) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* c = comb + blk_id * 1024 + krow(i, h) * 32 + r;
-        *c = round == 0 ? dw[i] : *c + dw[i];
+  for (int fc = 0; fc < NFC; ++fc) {
+    mfma_results_fence(dw[fc]);
+    for (int round = 0; round < NPART; ++round) {
+      if (part == round) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* c = comb + blk_id * 1024 + krow(i, h) * 32 + r;
+          *c = round == 0 ? dw[fc][i] : *c + dw[fc][i];
+        }
       }
+      __syncthreads();
+    }
+    for (int idx = tid; idx < NBLOCKS * 1024; idx += MT) {
+      const int b = idx >> 10, rr = (idx >> 5) & 31, cc = idx & 31;
+      slab[((b / NBF) * 32 + rr) * FPAD + fc * KPAD + (b % NBF) * 32 + cc] = comb[idx];
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < NBLOCKS * 1024; idx += MT) {
-    const int b = idx >> 10, rr = (idx >> 5) & 31, cc = idx & 31;
-    slab[((b / NBF) * 32 + rr) * KPAD + (b % NBF) * 32 + cc] = comb[idx];
-  }
-  __syncthreads();
   float* sc = L.t0;                                      // [MT / 16 row groups][64]
   *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = dbacc;
   __syncthreads();
@@ -508,7 +561,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MT / 16; ++k) s += sc[k * DD + tid];
-    slab[DD * KPAD + tid] = s;
+    slab[DD * FPAD + tid] = s;
   }
 }
 
@@ -538,10 +591,11 @@ hipError_t allow_big_lds() {   // (the kernel is a template VALUE parameter: one
 
 }  // namespace
 
-// 1 when the mid-size kernels apply: D = 64, F <= 64, every graph of the batch within 192 nodes / 2048 directed edges
+// 1 when the one-graph-per-workgroup kernels apply: D = 64 or 128 (two independent 64-column halves), F <= 128
+// (contracted in chunks of 64), every graph of the batch within 224 nodes / 2048 directed edges
 extern "C" int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph) {
-  return (D == DD && F >= 1 && F <= 64 && max_nodes_per_graph >= 1 && max_nodes_per_graph <= MID_MAX_NODES &&
-          max_edges_per_graph >= 0 && max_edges_per_graph <= MID_MAX_EDGES) ? 1 : 0;
+  return ((D == DD || D == 2 * DD) && F >= 1 && F <= 2 * DD && max_nodes_per_graph >= 1 &&
+          max_nodes_per_graph <= MID_MAX_NODES && max_edges_per_graph >= 0 && max_edges_per_graph <= MID_MAX_EDGES) ? 1 : 0;
 }
 
 extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
@@ -559,20 +613,29 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   const int kpad = F <= 32 ? 32 : 64;
   const size_t lds = mid_lds_bytes(npad, emax, DD, kpad, false);
   const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
-#define LAUNCH_MID_FWD(KP, PL)                                                                                             \
+#define LAUNCH_MID_FWD(KP, PL, MK)                                                                                         \
   do {                                                                                                                     \
-    auto kfn = k_mid_layer_fwd<KP, PL>;                                                                                    \
-    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL>>();                                                                                     \
+    auto kfn = k_mid_layer_fwd<KP, PL, MK>;                                                                                \
+    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK>>();                                                           \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
-    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, W, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad, emax, \
-                       slope, apply_act, out, emb, status);                                                                \
+    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, Wh, bh, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,    \
+                       emax, slope, apply_act, out, (int)D, coff, emb, status);                                            \
   } while (0)
-  if (kpad == 32) { if (emb) LAUNCH_MID_FWD(32, true); else LAUNCH_MID_FWD(32, false); }
-  else            { if (emb) LAUNCH_MID_FWD(64, true); else LAUNCH_MID_FWD(64, false); }
+  for (int half = 0; half < (int)(D / DD); ++half) {     // 64 output columns per launch
+    const float* Wh = W + (size_t)half * DD * F;
+    const float* bh = b + half * DD;
+    const int coff = half * DD;
+    if (kpad == 32)   { if (emb) LAUNCH_MID_FWD(32, true, false); else LAUNCH_MID_FWD(32, false, false); }
+    else if (F <= 64) { if (emb) LAUNCH_MID_FWD(64, true, false); else LAUNCH_MID_FWD(64, false, false); }
+    else              { if (emb) LAUNCH_MID_FWD(64, true, true); else LAUNCH_MID_FWD(64, false, true); }
+    HCG_CHECK_LAUNCH();
+  }
 #undef LAUNCH_MID_FWD
-  HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
+
+// slab geometry of one column half: dW [64][fpad] | db [64]
+static int mid_fpad(int64_t F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
 
 static int mid_bwd_grid(int64_t B, int64_t F, int64_t max_nodes, int64_t max_edges, size_t* lds_out, bool needs_dx) {
   const int kpad = F <= 32 ? 32 : 64;
@@ -585,13 +648,13 @@ static int mid_bwd_grid(int64_t B, int64_t F, int64_t max_nodes, int64_t max_edg
 
 extern "C" size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges) {
   if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return 0;
-  const int kpad = F <= 32 ? 32 : 64;
-  return (size_t)mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true) * (DD * kpad + DD) * sizeof(float) + 256;
+  const size_t half = (size_t)mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true) * (DD * mid_fpad(F) + DD) * sizeof(float);
+  return (size_t)(D / DD) * half + 256;
 }
 
-// backward, stage 1 (ONE launch).  dout == NULL selects the pooled form (upstream gradient = demb [B, 2D], expanded on
-// chip with `emb`).  dx nullable (first layer).  Leaves one slab per workgroup in `workspace`; describe it with
-// hcg_mid_reduce_job and sum with hcg_reduce_slabs.
+// backward, stage 1 (one launch per 64-column half).  dout == NULL selects the pooled form (upstream gradient = demb
+// [B, 2D], expanded on chip with `emb`).  dx nullable (first layer).  Leaves one slab per workgroup and half in
+// `workspace`; describe them with hcg_mid_reduce_job (one job per half) and sum with hcg_reduce_slabs.
 extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
                                  const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                  const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
@@ -605,42 +668,53 @@ extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const flo
   if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
-  const int npad = pad32(max_nodes), emax = pad8(max_edges), kpad = F <= 32 ? 32 : 64;
+  const int npad = pad32(max_nodes), emax = pad8(max_edges), fpad = mid_fpad(F);
   const bool ndx = dx != nullptr;
   size_t lds = 0;
-  const dim3 grid(mid_bwd_grid(B, F, max_nodes, max_edges, &lds, ndx)), blk(MT);
-  float* partials = (float*)workspace;
-#define LAUNCH_MID_BWD(KP, DX, PG)                                                                                          \
+  const int gsz = mid_bwd_grid(B, F, max_nodes, max_edges, &lds, ndx);
+  const dim3 grid(gsz), blk(MT);
+  const size_t slab_half = (size_t)gsz * (DD * fpad + DD);
+#define LAUNCH_MID_BWD(KP, NF, DX, PG)                                                                                      \
   do {                                                                                                                      \
-    auto kfn = k_mid_layer_bwd<KP, DX, PG>;                                                                                 \
-    hipError_t e = allow_big_lds<k_mid_layer_bwd<KP, DX, PG>>();                                                                                      \
+    auto kfn = k_mid_layer_bwd<KP, NF, DX, PG>;                                                                             \
+    hipError_t e = allow_big_lds<k_mid_layer_bwd<KP, NF, DX, PG>>();                                                        \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                             \
-    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, dout, demb, emb, out, x, (int)F, W, edge_index, E, graph_ptr, edge_ptr, \
-                       (int)B, npad, emax, slope, apply_act, dx, partials, status);                                         \
+    hipLaunchKernelGGL(kfn, grid, blk, lds, stream, dout, demb, emb, out, (int)D, coff, x, (int)F, Wh, edge_index, E,        \
+                       graph_ptr, edge_ptr, (int)B, npad, emax, slope, apply_act, dx, half > 0 ? 1 : 0, partials, status);   \
   } while (0)
-#define DISPATCH_MID_BWD(KP)                                                                          \
-  do {                                                                                                \
-    if (ndx) { if (poolg) LAUNCH_MID_BWD(KP, true, true); else LAUNCH_MID_BWD(KP, true, false); }     \
-    else     { if (poolg) LAUNCH_MID_BWD(KP, false, true); else LAUNCH_MID_BWD(KP, false, false); }   \
+#define DISPATCH_MID_BWD(KP, NF)                                                                              \
+  do {                                                                                                        \
+    if (ndx) { if (poolg) LAUNCH_MID_BWD(KP, NF, true, true); else LAUNCH_MID_BWD(KP, NF, true, false); }     \
+    else     { if (poolg) LAUNCH_MID_BWD(KP, NF, false, true); else LAUNCH_MID_BWD(KP, NF, false, false); }   \
   } while (0)
-  if (kpad == 32) DISPATCH_MID_BWD(32); else DISPATCH_MID_BWD(64);
+  for (int half = 0; half < (int)(D / DD); ++half) {
+    const float* Wh = W + (size_t)half * DD * F;
+    const int coff = half * DD;
+    float* partials = (float*)workspace + (size_t)half * slab_half;
+    if (fpad == 32) DISPATCH_MID_BWD(32, 1);
+    else if (fpad == 64) DISPATCH_MID_BWD(64, 1);
+    else DISPATCH_MID_BWD(64, 2);
+    HCG_CHECK_LAUNCH();
+  }
 #undef DISPATCH_MID_BWD
 #undef LAUNCH_MID_BWD
-  HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
 
+// job `half` (0 .. D/64 - 1): rows [64 half, 64 half + 64) of dW [D, F] and of db [D]
 extern "C" int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int64_t D,
-                                  int64_t max_nodes, int64_t max_edges, float* dW, float* db, hcg_reduce_job* job) {
-  if (!hcg_mid_supported(F, D, max_nodes, max_edges) || !dW || !db || !job || !workspace || B <= 0) return HCG_ERR_INVALID_ARG;
+                                  int64_t max_nodes, int64_t max_edges, int half, float* dW, float* db, hcg_reduce_job* job) {
+  if (!hcg_mid_supported(F, D, max_nodes, max_edges) || !dW || !db || !job || !workspace || B <= 0 || half < 0 || half >= D / DD)
+    return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
-  const int kpad = F <= 32 ? 32 : 64;
-  job->slabs = (const float*)workspace;
-  job->nslabs = mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true);
-  job->slab_floats = DD * kpad + DD;
+  const int fpad = mid_fpad(F);
+  const int gsz = mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true);
+  job->slabs = (const float*)workspace + (size_t)half * gsz * (DD * fpad + DD);
+  job->nslabs = gsz;
+  job->slab_floats = DD * fpad + DD;
   job->nseg = 2;
   job->reserved = 0;
-  job->seg[0] = hcg_reduce_seg{0, DD * kpad, kpad, (int32_t)F, dW};
-  job->seg[1] = hcg_reduce_seg{DD * kpad, DD, 1, 1, db};
+  job->seg[0] = hcg_reduce_seg{0, DD * fpad, fpad, (int32_t)F, dW + (size_t)half * DD * F};
+  job->seg[1] = hcg_reduce_seg{DD * fpad, DD, 1, 1, db + half * DD};
   return HCG_OK;
 }

@@ -93,8 +93,9 @@ __device__ __forceinline__ void mfma_exact_a(f32x16& acc, const bf16x8& a, const
 //   TRANS = true : image row f, column d  <-  g[d * cols + f]   (B[d][f] = W[d][f]: the dX = dH W operand)
 // `rows_img` x `K` is the image extent (zero padded past the matrix), `g` is [grows][cols] row-major.
 template <bool TRANS>
+// `col0`: first column of `g` the image's column window (TRANS: row window) starts at (K-chunked operands).
 __device__ __forceinline__ void stage_weight_split(short* wl, int rows_img, int K, const float* __restrict__ g, int grows,
-                                                   int cols) {
+                                                   int cols, int col0 = 0) {
   const int ld = K + WPAD, plane = rows_img * ld;
   const int total = TRANS ? grows * rows_img : rows_img * K;    // iterate in global-memory order where possible
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -102,14 +103,14 @@ __device__ __forceinline__ void stage_weight_split(short* wl, int rows_img, int 
     float v;
     if (TRANS) {      // idx = d * rows_img + f
       const int d = idx / rows_img, f = idx - d * rows_img;
-      v = g[(size_t)d * cols + (f < cols ? f : cols - 1)];
-      if (f >= cols) v = 0.f;
+      v = g[(size_t)d * cols + (col0 + f < cols ? col0 + f : cols - 1)];
+      if (col0 + f >= cols) v = 0.f;
       ir = f;
       ic = d;
     } else {          // idx = n * K + k
       const int n = idx / K, k = idx - n * K;
-      v = g[(size_t)(n < grows ? n : grows - 1) * cols + (k < cols ? k : cols - 1)];
-      if (k >= cols || n >= grows) v = 0.f;
+      v = g[(size_t)(n < grows ? n : grows - 1) * cols + (col0 + k < cols ? col0 + k : cols - 1)];
+      if (col0 + k >= cols || n >= grows) v = 0.f;
       ir = n;
       ic = k;
     }

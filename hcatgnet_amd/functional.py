@@ -291,10 +291,12 @@ class _MidLayerFn(torch.autograd.Function):
                                    plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
                                    _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)
         _lib.check(rc, "hcg_mid_layer_bwd")
-        job = ctypes.create_string_buffer(lib.hcg_reduce_job_bytes())
-        _lib.check(lib.hcg_mid_reduce_job(_lib.ptr(ws), wsb, plan.B, F, D, plan.max_nodes, plan.max_edges, _lib.ptr(dW),
-                                          _lib.ptr(db), ctypes.addressof(job)), "hcg_mid_reduce_job")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(job), 1, stream), "hcg_reduce_slabs")
+        jb, halves = lib.hcg_reduce_job_bytes(), D // 64          # one slab set (= one job) per 64-column half
+        jobs = ctypes.create_string_buffer(jb * halves)
+        for half in range(halves):
+            _lib.check(lib.hcg_mid_reduce_job(_lib.ptr(ws), wsb, plan.B, F, D, plan.max_nodes, plan.max_edges, half,
+                                              _lib.ptr(dW), _lib.ptr(db), ctypes.addressof(jobs) + half * jb), "hcg_mid_reduce_job")
+        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), halves, stream), "hcg_reduce_slabs")
         return dx, dW, db, None, None, None, None
 
 

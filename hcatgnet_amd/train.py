@@ -226,7 +226,7 @@ class FusedTrainStep:
                                            p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(dx), p(plan.status), p(ws),
                                            wsb, stream)
                 _lib.check(rc, "hcg_mid_layer_bwd")
-                _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, g(convs[l].lin.weight), g(convs[l].bias),
+                _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, 0, g(convs[l].lin.weight), g(convs[l].bias),
                                                   jaddr + njobs * jb), "hcg_mid_reduce_job")
             njobs += 1
             dh = dx

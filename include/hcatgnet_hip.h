@@ -187,9 +187,10 @@ int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_
                            int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
                            hcg_stream_t stream);
 
-/* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 192 nodes and <= 2048
- * directed edges per graph, D = 64, F <= 64 -- the size range of the reference's own reaction graphs (56-184 atoms,
- * F = 25 / 32).  Same contract as hcg_fused_layer_*: raw int64 edge_index grouped by graph + graph_ptr / edge_ptr of
+/* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 224 nodes and <= 2048
+ * directed edges per graph, D = 64 or 128 (two 64-column halves, one launch each), F <= 128 (contracted in chunks of 64)
+ * -- the size range of the reference's own reaction graphs (56-184 atoms, F = 25 / 32) and of BASELINE's large-ligand
+ * configuration (200 nodes, 128-d).  Same contract as hcg_fused_layer_*: raw int64 edge_index grouped by graph + graph_ptr / edge_ptr of
  * a BLOCKED plan, gcn_norm and the CSR rebuilt on chip per graph, unweighted edges, optional pooled epilogue /
  * pooled-gradient prologue, per-workgroup gradient slabs (hcg_mid_reduce_job + hcg_reduce_slabs).
  * `max_nodes` / `max_edges` = largest graph of the batch (host metadata; sizes the dynamic LDS); a graph that exceeds
@@ -272,8 +273,9 @@ int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z
                              void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                             float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+/* one job per 64-column half (half = 0 .. D/64 - 1): rows [64 half, 64 half + 64) of dW [D, F] / db [D] */
 int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int64_t D,
-                       int64_t max_nodes, int64_t max_edges, float* dW, float* db, hcg_reduce_job* job_host);
+                       int64_t max_nodes, int64_t max_edges, int half, float* dW, float* db, hcg_reduce_job* job_host);
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);

@@ -140,3 +140,39 @@ def test_mid_full_size_properties(H, oracle):
     with torch.no_grad():
         o_sub = m(b2)
     assert torch.equal(o_sub, out[:nsub])
+
+
+@pytest.mark.parametrize("nodes,jitter,feat,extra,deg,D,B,seed", [(200, 0, 128, 13, 6, 128, 24, 10), (100, 60, 70, 6, 4, 128, 40, 10),
+                                                                  (50, 10, 25, 3, 4, 128, 40, 19), (120, 40, 100, 6, 4, 64, 40, 10)])
+def test_mid_wide_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, extra, deg, D, B, seed):
+    """BASELINE's large-ligand regime (200 nodes, degree <= 6, 128-d) and other wide shapes through the
+    one-graph-per-workgroup kernels: embedding_dim 128 = two 64-column halves per layer, inputs wider than 64 features
+    contracted in K-chunks / f-chunks of 64 (incl. a width that is no multiple of 4), dx accumulated across the halves."""
+    from hcatgnet_amd import functional as HF, synth
+    sb = synth.make_batch(num_graphs=B, nodes=nodes, extra_bonds=extra, max_degree=deg, feat=feat, nodes_jitter=jitter, seed=seed)
+    params = _rand_params(feat, D, seed=31)
+    _, _, acts0 = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
+    assert _near_ties(acts0[-1], sb.batch, sb.num_graphs) == 0, "pick another seed: this batch has a near-tie in the max pooling"
+    m = _model_from_params(H, params)
+    batch = sb.as_batch("cuda")
+    plan = H.BatchPlan.build(batch.edge_index, batch.batch, batch.x.shape[0], num_graphs=sb.num_graphs, mode="blocked",
+                             max_nodes=sb.max_nodes, max_edges=sb.max_edges)
+    batch._hcg_plan = plan
+    assert HF.mid_supported(plan, feat, D) and HF.mid_supported(plan, D, D)
+    m.use_fused = True
+    out_f, emb_f, g_f = _step_grads(m, batch, batch.y)
+    assert plan.check_status() == 0
+    m.use_fused = False
+    out_g, emb_g, g_g = _step_grads(m, batch, batch.y)
+    o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+    assert rel_inf(emb_f, o_emb) <= TOL and rel_inf(out_f, o_out, floor=1.0) <= TOL
+    assert rel_inf(emb_f, emb_g) <= 2e-6 and rel_inf(out_f, out_g, floor=1.0) <= 2e-6
+    for k, ref in o_grads.items():
+        assert rel_inf(g_f[k], ref) <= (TOL_DW if k.endswith("weight") else TOL), k
+        assert rel_inf(g_f[k], g_g[k]) <= TOL, k
+    with torch.no_grad():
+        h = m.conv1(batch.x, plan, apply_act=True, fused=True)
+    assert rel_inf(h, acts0[0]) <= TOL
+    m.use_fused = True
+    out_2, emb_2, g_2 = _step_grads(m, batch, batch.y)
+    assert torch.equal(out_f, out_2) and torch.equal(emb_f, emb_2) and all(torch.equal(g_f[k], g_2[k]) for k in g_f)
