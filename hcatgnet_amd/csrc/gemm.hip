@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256) void k_colsum_stage2(const float* __restrict__
 size_t hcg_gemm_partial_floats(int64_t M, int64_t N, int64_t K, int* splits_out) {
   const int64_t tiles = hcg_cdiv(M, BM) * hcg_cdiv(N, BN);
   int64_t splits = 1;
-  if (tiles < 256 && K >= 2048) {
-    splits = 512 / tiles;   // ~2 workgroups per CU; more splits only lengthen the reduction
-    const int64_t max_splits = hcg_cdiv(K, 512);
+  if (tiles < 256 && K >= 512) {
+    // few output tiles and a long contraction (weight gradients: K = rows of the batch): each tile's K loop is a chain of
+    // dependent stage-and-multiply rounds, so spread it -- ~2 workgroups per CU, at least 128 of K per split
+    splits = 512 / tiles;
+    const int64_t max_splits = hcg_cdiv(K, 128);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
