@@ -179,12 +179,31 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
 // padded past column F and to whole 32-row blocks).  All MT threads; no trailing barrier.  (Batching every load of the
 // graph into registers first was measured: it costs the forward its second workgroup per CU -- 218 VGPRs -- and ran
 // 1.7x slower.)
-template <int KPAD>
+// BATCH: request every row of the graph before the first LDS write (one exposed HBM round trip instead of one per loop
+// iteration) -- for the kernels whose register budget has room (they run one workgroup per CU anyway).
+template <int KPAD, bool BATCH = false>
 __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restrict__ g, int F, int c0, int nbase, int n, int nblk) {
   const int tid = threadIdx.x;
   const int rows = nblk * 32;
   if (c0 + KPAD <= F && (F & 3) == 0 && ((uintptr_t)g % 16 == 0)) {
     constexpr int PER_ROW = KPAD / 4;
+    if constexpr (BATCH) {
+      constexpr int NIT = (MID_MAX_NODES * PER_ROW + MT - 1) / MT;
+      float4 v[NIT];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int idx = tid + j * MT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+        if (j * MT < rows * PER_ROW)           // block-uniform guard, clamped address: no per-lane branch around the load
+          v[j] = *reinterpret_cast<const float4*>(g + (size_t)(nbase + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + c0 + 4 * c4);
+      }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int idx = tid + j * MT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+        if (j * MT < rows * PER_ROW && row < rows)
+          *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = row < n ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
     for (int idx = tid; idx < rows * PER_ROW; idx += MT) {
       const int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
 
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
-    stage_graph_rows<KPAD>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
+    stage_graph_rows<KPAD, MULTIK>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
     build_csr<false>(L, gi, ei, E, status, nullptr);                // (ends with a barrier: the x tile is complete too)
 
     // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
       for (int kc = 0; kc < nkc; ++kc) {
         if (kc > 0) {
           __syncthreads();                                           // every wave is done with the previous chunk
-          stage_graph_rows<KPAD>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
+          stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
         }
         stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F, kc * KPAD);
         __syncthreads();
@@ -469,7 +488,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
 #pragma unroll
     for (int fc = 0; fc < NFC; ++fc) {
       // ---- 3. x chunk -> t0 (and, chunked, the matching rows of the dx operand image)
-      stage_graph_rows<KPAD>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
+      stage_graph_rows<KPAD, true>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
       if (NEEDS_DX && NFC > 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F, fc * KPAD);
       __syncthreads();
 
