@@ -1,0 +1,23 @@
+"""Dev tool: many launches of the full fused step (no optimizer update) on C3 and on the reference-sized batch; counts
+launches whose loss / gradients / activations differ bitwise from the majority."""
+import sys, os, collections, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hcatgnet_amd as H
+from hcatgnet_amd import synth
+from hcatgnet_amd.train import FusedTrainStep
+def digest(ts): 
+    h = hashlib.md5()
+    for t in ts: h.update(t.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+for cfg, reps in (("C3", int(sys.argv[1]) if len(sys.argv) > 1 else 300), ("REAL", int(sys.argv[2]) if len(sys.argv) > 2 else 80)):
+    sb = synth.make_config(cfg)
+    m = H.make_network("GCN", H.default_options(), synth.CONFIGS[cfg]["feat"]).cuda()
+    batch = sb.as_batch("cuda")
+    step = FusedTrainStep(m, optimizer_step=False)
+    c = collections.Counter()
+    for rep in range(reps):
+        loss = step(batch)
+        bufs = next(iter(step._bufs.values()))
+        c[digest([loss, step._flat, bufs["acts"][0], bufs["acts"][1], bufs["emb"], bufs["demb"], bufs["dacts"][0], bufs["out"]])] += 1
+    print(cfg, "launches", reps, "distinct results", len(c), "-> BAD launches:", reps - c.most_common(1)[0][1], flush=True)
