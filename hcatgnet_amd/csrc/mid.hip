@@ -22,7 +22,7 @@ namespace {
 constexpr int MW = 8;                 // waves per workgroup (two per SIMD: the per-graph phases are latency chains)
 constexpr int MT = MW * 64;           // threads
 constexpr int MID_MAX_NODES = 224;    // 7 row blocks of 32 (two fp32 tiles + one weight image still fit 160 KB of LDS)
-constexpr int MID_MAX_EDGES = 2048;   // directed edges of one graph (LDS col array, 16-bit ids)
+constexpr int MID_MAX_EDGES = 1024;   // directed edges of one graph (2 per thread kept in registers; LDS col array, 16-bit ids)
 
 struct MidLds {   // carved out of dynamic shared memory by carve()
   float* t0;              // [npad][HS]   forward: X -> H';   backward: dY' -> X
@@ -85,19 +85,35 @@ __device__ __forceinline__ GraphInfo graph_info(int g, const int32_t* __restrict
   return gi;
 }
 
+// A graph's raw edges, two per thread, requested one graph AHEAD (loads only: unconditional, clamped index -- E >= 1 and
+// `ei` readable are guaranteed by the host wrappers) and consumed by build_csr of the next iteration.
+constexpr int EPT = MID_MAX_EDGES / MT;
+struct EdgeRegs {
+  long long s[EPT], d[EPT];
+  __device__ __forceinline__ void load(const GraphInfo& gi, const int64_t* __restrict__ ei, int64_t E) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int e = threadIdx.x + j * MT;
+      int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
+      if (k > E - 1) k = E - 1;
+      s[j] = ei[k];
+      d[j] = ei[E + k];
+    }
+  }
+};
+
 // In-degree -> dinv, and a CSR of the graph in LDS.  BY_SRC = false: rows = targets, col = sources (forward
 // aggregation); BY_SRC = true: rows = sources, col = targets (the transpose, for the backward).  dinv is always
 // (1 + in-degree)^-1/2.  Explicit (i, i) edges collapse into the unit self loop (PyG add_remaining_self_loops).
 // Every row ends up sorted by id, whatever order the LDS atomics ran in.  All MT threads; ends with a barrier.
 template <bool BY_SRC>
-__device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, const int64_t* __restrict__ ei, int64_t E,
-                                          int32_t* status, int* degin_scratch) {
+__device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, const EdgeRegs& er, int32_t* status,
+                                          int* degin_scratch) {
   const int tid = threadIdx.x;
   const int nrows = gi.nblk * 32;
   for (int i = tid; i < nrows; i += MT) { L.cursor[i] = 0; if (BY_SRC) degin_scratch[i] = 0; }
   __syncthreads();
-  // this thread's edges stay in registers from the counting pass to the fill pass (one global read per edge)
-  constexpr int EPT = MID_MAX_EDGES / MT;
+  // this thread's edges (already in registers) -> local ids, kept from the counting pass to the fill pass
   unsigned short es[EPT], ed[EPT];
   bool bad = false;
 #pragma unroll
@@ -106,9 +122,7 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
     es[j] = 0xffff;
     ed[j] = 0xffff;
     if (e < gi.ne) {
-      int64_t k = (int64_t)gi.ebase + e;
-      if (k > E - 1) k = E - 1;
-      const long long s = ei[k], d = ei[E + k];
+      const long long s = er.s[j], d = er.d[j];
       const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
       const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (s >> 31) == 0 && (d >> 31) == 0;
       bad |= !ok;
@@ -242,10 +256,15 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
   __syncthreads();
 
+  GraphInfo gi;
+  EdgeRegs er;
+  if ((int)blockIdx.x < B) {
+    gi = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
+    er.load(gi, ei, E);
+  }
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
-    const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
     stage_graph_rows<KPAD, MULTIK>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
-    build_csr<false>(L, gi, ei, E, status, nullptr);                // (ends with a barrier: the x tile is complete too)
+    build_csr<false>(L, gi, er, status, nullptr);                   // (ends with a barrier: the x tile is complete too)
 
     // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
     if constexpr (!MULTIK) {
@@ -295,13 +314,20 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
     }
     __syncthreads();
 
+    // the NEXT graph's scalars and edges are requested here: they land while this graph is aggregated and stored
+    const GraphInfo gcur = gi;
+    if (g + (int)gridDim.x < B) {
+      gi = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
+      er.load(gi, ei, E);
+    }
+
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
+    for (int u = wave; u < gcur.nblk * 2; u += MW) {      // units of 16 rows
 #pragma unroll 2
       for (int pass = 0; pass < 4; ++pass) {
         const int row = u * 16 + pass * 4 + r4;
-        const bool valid = row < gi.n;
+        const bool valid = row < gcur.n;
         const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
         float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
         for (int k = kb; __any(k < ke); ++k) {
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
         if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
         if (valid) {
-          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * ldo + coff + 4 * q) = y;
+          *reinterpret_cast<float4*>(out + (size_t)(gcur.nbase + row) * ldo + coff + 4 * q) = y;
           if (POOL) {
             pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
             psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
@@ -342,9 +368,9 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
           m = fmaxf(m, L.red[w * 2 * DD + tid]);
           s += L.red[w * 2 * DD + DD + tid];
         }
-        if (gi.n <= 0) m = 0.f;
+        if (gcur.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * ldo + coff + tid] = m;                                   // [max | mean], each ldo wide
-        emb[(size_t)g * 2 * ldo + ldo + coff + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
+        emb[(size_t)g * 2 * ldo + ldo + coff + tid] = s / (float)(gcur.n > 0 ? gcur.n : 1);
       }
     }
     __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
@@ -391,10 +417,20 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int i = 0; i < 16; ++i) dw[fc][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  GraphInfo gnext;
+  EdgeRegs er;
+  if ((int)blockIdx.x < B) {
+    gnext = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
+    er.load(gnext, ei, E);
+  }
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
-    const GraphInfo gi = graph_info(g, graph_ptr, edge_ptr, npad, emax, status);
-    build_csr<true>(L, gi, ei, E, status, reinterpret_cast<int*>(L.red));
+    const GraphInfo gi = gnext;
+    build_csr<true>(L, gi, er, status, reinterpret_cast<int*>(L.red));
     const int rows = gi.nblk * 32;
+    if (g + (int)gridDim.x < B) {                          // the NEXT graph's scalars and edges: in flight for the whole graph
+      gnext = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
+      er.load(gnext, ei, E);
+    }
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
     //         this thread's rows (row group rg, float4 column group c4): all global loads first, used by both passes
@@ -611,7 +647,7 @@ hipError_t allow_big_lds() {   // (the kernel is a template VALUE parameter: one
 }  // namespace
 
 // 1 when the one-graph-per-workgroup kernels apply: D = 64 or 128 (two independent 64-column halves), F <= 128
-// (contracted in chunks of 64), every graph of the batch within 224 nodes / 2048 directed edges
+// (contracted in chunks of 64), every graph of the batch within 224 nodes / 1024 directed edges
 extern "C" int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph) {
   return ((D == DD || D == 2 * DD) && F >= 1 && F <= 2 * DD && max_nodes_per_graph >= 1 &&
           max_nodes_per_graph <= MID_MAX_NODES && max_edges_per_graph >= 0 && max_edges_per_graph <= MID_MAX_EDGES) ? 1 : 0;

@@ -187,7 +187,7 @@ int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_
                            int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
                            hcg_stream_t stream);
 
-/* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 224 nodes and <= 2048
+/* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 224 nodes and <= 1024
  * directed edges per graph, D = 64 or 128 (two 64-column halves, one launch each), F <= 128 (contracted in chunks of 64)
  * -- the size range of the reference's own reaction graphs (56-184 atoms, F = 25 / 32) and of BASELINE's large-ligand
  * configuration (200 nodes, 128-d).  Same contract as hcg_fused_layer_*: raw int64 edge_index grouped by graph + graph_ptr / edge_ptr of
