@@ -259,10 +259,30 @@ def main():
         return dt
 
     log(f"inputs resident: N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
+
+    def count_launching_calls():
+        """Library entry points that enqueue kernels during ONE eager step (launches per step)."""
+        skip = ("_bytes", "_job", "_supported", "_per_tile", "hcg_version", "hcg_error_string")
+        names = [n for n in _lib.SIGNATURES if not n.endswith(skip) and n not in skip]
+        counts, origs = {}, {}
+        for n in names:
+            origs[n] = getattr(lib, n)
+            def wrap(*a, _n=n):
+                counts[_n] = counts.get(_n, 0) + 1
+                return origs[_n](*a)
+            setattr(lib, n, wrap)
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+        finally:
+            for n in names:
+                setattr(lib, n, origs[n])
+        return counts
     for _ in range(args.warmup):
         eager_step()
     torch.cuda.synchronize()
     log("warm-up done")
+    launch_counts = count_launching_calls()
 
     launch_mode, graph_err = "eager", None
     if not args.no_graph:
@@ -385,6 +405,7 @@ def main():
                                                         "note": "same step without the Adam update (gradients only)"},
             "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), inside the timed step",
             "step_path": "FusedTrainStep (no autograd)" if fused_ok else "autograd",
+            "library_launching_calls_per_step": {"total": sum(launch_counts.values()), "by_entry_point": launch_counts},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "eager_step_ms_percentiles_hip_events": pct,
             "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3,

@@ -117,3 +117,22 @@ def test_algorithmic_bytes_match_survey_numbers():
     assert algbytes.conv_fwd(122880, 262144, 64, 64) == 64_962_820
     assert algbytes.forward_bytes(122880, 262144, 4096, 64, 64) == 165_643_280
     assert algbytes.step_bytes(122880, 262144, 4096, 64, 64) == 438_242_860
+
+
+def test_fused_train_step_support_check_is_host_only():
+    """`FusedTrainStep.unsupported_reason` decides on the host (no GPU needed) whether a model / batch can take the
+    no-autograd step: small-graph tiles up to 32 nodes, one-graph-per-workgroup kernels up to 224 nodes, D = 64 head."""
+    import hcatgnet_amd as H
+    from hcatgnet_amd.train import FusedTrainStep
+    m = H.make_network("GCN", H.default_options(), 25)
+    x = torch.zeros(4, 25); ei = torch.zeros(2, 0, dtype=torch.int64); bv = torch.zeros(4, dtype=torch.int64)
+    mk = lambda **kw: H.Batch(x, ei, bv, 1, y=torch.zeros(1), **kw)
+    assert FusedTrainStep.unsupported_reason(m, mk(max_nodes=30, max_edges=64, edges_grouped=True)) is None
+    assert FusedTrainStep.unsupported_reason(m, mk(max_nodes=184, max_edges=390, edges_grouped=True)) is None
+    assert "shape" in FusedTrainStep.unsupported_reason(m, mk(max_nodes=300, max_edges=700, edges_grouped=True))
+    assert "metadata" in FusedTrainStep.unsupported_reason(m, mk())
+    assert "targets" in FusedTrainStep.unsupported_reason(m, H.Batch(x, ei, bv, 1, max_nodes=30, max_edges=64, edges_grouped=True))
+    wide = H.make_network("GCN", H.default_options(embedding_dim=128), 25)
+    assert "head" in FusedTrainStep.unsupported_reason(wide)
+    deep = H.make_network("GCN", H.default_options(readout_layers=3), 25)
+    assert "readout" in FusedTrainStep.unsupported_reason(deep)
