@@ -344,7 +344,7 @@ def main():
         log(f"timed hipGraph replay (full step): {dt_graph / args.steps * 1e3:.3f} ms/step")
         if dt_graph <= dt_eager:
             dt_best = dt_graph
-        else:   # the no-autograd step issues 7 launches from a host loop that runs ahead of the GPU: replay need not win
+        else:   # the no-autograd step issues 6 launches from a host loop that runs ahead of the GPU: replay need not win
             launch_mode = "eager"
         if not args.forward_only:
             for _ in range(3):

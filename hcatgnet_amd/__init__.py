@@ -8,7 +8,7 @@ Public surface (mirrors the reference's names for this path):
     DeviceGraphStore, DeviceLoader              dataset resident in HBM, batches collated on the GPU
     DataParallelGCN                             one-process-per-GPU gradient all-reduce (RCCL)
     train.FusedTrainStep, train.train_network / eval_network / predict_network
-                                                the reference's loops (utils/utils_model.py:55-111); the step as 7 launches
+                                                the reference's loops (utils/utils_model.py:55-111); the step as 6 launches
     io.load_processed_dir / write_embeddings_csv the reference's on-disk formats (reaction_N.pt in, embeddings.csv out)
     explain.set_masks / clear_masks             explain-mode edge masks (PyG Explainer hooks)
 Compute lives in csrc/libhcatgnet_hip.so (hand-written HIP for gfx950) behind include/hcatgnet_hip.h.

@@ -46,7 +46,7 @@ def _sync_words(dev: torch.device) -> torch.Tensor:
 
 
 class FusedTrainStep:
-    """One training step of the reference's loop as <= 8 enqueued launches, no autograd, no host sync.
+    """One training step of the reference's loop as 6 enqueued launches (small-graph tiles; n_conv + 4 in general), no autograd, no host sync.
 
         step = FusedTrainStep(model)            # model: hcatgnet_amd.GCN on the GPU
         loss = step(batch)                      # 0-d device tensor: sqrt(MSE) of this batch, weights already updated
