@@ -1,6 +1,6 @@
 """FusedAdam: `torch.optim.Adam` semantics (the reference builds `Adam(self.parameters(), lr, eps=1e-9)`,
 model/networks.py:38) with the update done by ONE HIP launch when the gradients sit in one flat buffer
-(which the fused backward guarantees), one launch per parameter otherwise.
+(which the fused backward guarantees), one gather + one launch otherwise.
 
 It IS a `torch.optim.Optimizer` (param_groups, state_dict, zero_grad, lr schedulers -- e.g. the reference's
 `ReduceLROnPlateau` -- all work): `lr` is read from `param_groups` at every step.  Parameters and both
@@ -203,16 +203,12 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(lib.hcg_adam_step(fl["p"].data_ptr(), g0.data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(),
                                              fl["n"], lr, b1, b2, eps, step, stream), "hcg_adam_step")
             else:
-                off = 0
-                for p, g in zip(ps, grads):
-                    g = g.contiguous()
-                    if g.dtype != torch.float32:
-                        raise _lib.HcgError("FusedAdam handles float32 gradients only")
-                    k = p.numel()
-                    _lib.check(lib.hcg_adam_step(fl["p"].data_ptr() + 4 * off, g.data_ptr(), fl["m"].data_ptr() + 4 * off,
-                                                 fl["v"].data_ptr() + 4 * off, k, lr, b1, b2, eps, step, stream),
-                               "hcg_adam_step")
-                    off += k
+                # per-tensor gradients (autograd path): ONE gather into a flat buffer, then the same single launch
+                if any(g.dtype != torch.float32 for g in grads):
+                    raise _lib.HcgError("FusedAdam handles float32 gradients only")
+                gflat = torch.cat([g.reshape(-1) for g in grads])
+                _lib.check(lib.hcg_adam_step(fl["p"].data_ptr(), gflat.data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(),
+                                             fl["n"], lr, b1, b2, eps, step, stream), "hcg_adam_step")
             for p in ps:
                 self.state[p]["step"] = torch.tensor(float(step))
         return loss
