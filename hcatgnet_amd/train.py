@@ -94,18 +94,29 @@ class FusedTrainStep:
 
     # ------------------------------------------------------------------ the step
     def _buffers(self, key, N, B, F, D, C, n_conv, dev):
-        b = self._bufs.get(key)
-        if b is not None:
-            return b
+        """Step buffers: allocated for the largest (N, B) seen so far and handed out as views -- the variable-size
+        batches of a shuffled epoch then reuse one allocation instead of ~12 `torch.empty` per step."""
         lib = _lib.load()
-        f32 = dict(dtype=torch.float32, device=dev)
-        b = {"acts": [torch.empty(N, D, **f32) for _ in range(n_conv)],
-             "dacts": [torch.empty(N, D, **f32) for _ in range(n_conv - 1)],
-             "emb": torch.empty(B, 2 * D, **f32), "demb": torch.empty(B, 2 * D, **f32),
-             "z": torch.empty(B, D, **f32), "out": torch.empty(B, C, **f32), "loss": torch.empty(2, **f32)}
-        hb = lib.hcg_head_workspace_bytes(B)
-        b["ws_head"], b["ws_head_bytes"] = torch.empty(hb, dtype=torch.uint8, device=dev), hb
-        self._bufs = {key: b}          # one live shape at a time (a new shape replaces the old buffers)
+        cap = self._bufs.get("cap")
+        sig = (F, D, C, n_conv, dev)
+        if cap is None or cap["sig"] != sig or cap["N"] < N or cap["B"] < B:
+            capN = max(N, int(cap["N"] * 1.25) if cap and cap["sig"] == sig else 0)
+            capB = max(B, cap["B"] if cap and cap["sig"] == sig else 0)
+            f32 = dict(dtype=torch.float32, device=dev)
+            hb = lib.hcg_head_workspace_bytes(capB)
+            cap = {"sig": sig, "N": capN, "B": capB,
+                   "acts": [torch.empty(capN, D, **f32) for _ in range(n_conv)],
+                   "dacts": [torch.empty(capN, D, **f32) for _ in range(n_conv - 1)],
+                   "emb": torch.empty(capB, 2 * D, **f32), "demb": torch.empty(capB, 2 * D, **f32),
+                   "z": torch.empty(capB, D, **f32), "out": torch.empty(capB, C, **f32), "loss": torch.empty(2, **f32),
+                   "ws_head": torch.empty(hb, dtype=torch.uint8, device=dev), "ws": {}}
+            self._bufs = {"cap": cap}
+        b = self._bufs.get(key)
+        if b is None:
+            b = {"acts": [t[:N] for t in cap["acts"]], "dacts": [t[:N] for t in cap["dacts"]], "emb": cap["emb"][:B],
+                 "demb": cap["demb"][:B], "z": cap["z"][:B], "out": cap["out"][:B], "loss": cap["loss"],
+                 "ws_head": cap["ws_head"], "ws_head_bytes": lib.hcg_head_workspace_bytes(B), "ws": cap["ws"]}
+            self._bufs = {"cap": cap, key: b}          # views of the current shape (one live shape at a time)
         return b
 
     def _flat_grads(self, params, dev):
@@ -127,7 +138,12 @@ class FusedTrainStep:
                 off += p.numel()
         return flat
 
-    def __call__(self, batch):
+    def evaluate(self, batch):
+        """Forward + loss only (the reference's `eval_network` body, utils/utils_model.py:75-78): plan, conv stack, head
+        -- 3 launches; the head kernel's backward half runs too (a few us) but nothing is reduced or updated."""
+        return self(batch, _forward_only=True)
+
+    def __call__(self, batch, _forward_only: bool = False):
         model = self.model
         why = self.unsupported_reason(model, batch)
         if why is not None:
@@ -177,24 +193,28 @@ class FusedTrainStep:
                     _lib.check(rc, "hcg_mid_layer_fwd")
                 h = acts[l]
         # ---- head: readout forward, loss, readout backward
-        params = [q for q in model.parameters() if q.requires_grad]
-        flat = self._flat_grads(params, dev)
-        views, off = {}, 0
-        for q in params:
-            views[id(q)] = flat[off:off + q.numel()]
-            off += q.numel()
-        g = lambda prm: p(views[id(prm)])
-        # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
-        # advances the step number that launch reads
         opt = model.optimizer
-        step_word = None
-        if self.optimizer_step and self.grad_sync is None and hasattr(opt, "fused_update_ready"):
-            step_word = opt.fused_update_ready(flat)
+        step_word, flat, g = None, None, None
+        if not _forward_only:
+            params = [q for q in model.parameters() if q.requires_grad]
+            flat = self._flat_grads(params, dev)
+            views, off = {}, 0
+            for q in params:
+                views[id(q)] = flat[off:off + q.numel()]
+                off += q.numel()
+            g = lambda prm: p(views[id(prm)])
+            # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
+            # advances the step number that launch reads
+            if self.optimizer_step and self.grad_sync is None and hasattr(opt, "fused_update_ready"):
+                step_word = opt.fused_update_ready(flat)
         rc = lib.hcg_head_fwd_bwd(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
                                   p(HF._f32c(l1.bias)), B, D, C, slope, int(self.rmse), p(bufs["z"]), p(bufs["out"]),
                                   p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
                                   p(_sync_words(dev)), p(step_word), stream)
         _lib.check(rc, "hcg_head_fwd_bwd")
+        if _forward_only:
+            self.last_out = bufs["out"]
+            return bufs["loss"][0]
         jb = lib.hcg_reduce_job_bytes()
         jobs = ctypes.create_string_buffer(jb * 4)
         jaddr = ctypes.addressof(jobs)
@@ -208,10 +228,10 @@ class FusedTrainStep:
             dx = bufs["dacts"][l - 1] if l > 0 else None
             small = gpts[l] > 0
             wsb = lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l]) if small else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)
-            ws = bufs.get(("ws", l))
+            ws = bufs["ws"].get(l)
             if ws is None or ws.numel() < wsb:
-                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                bufs[("ws", l)] = ws
+                ws = torch.empty(int(wsb * 1.25), dtype=torch.uint8, device=dev)
+                bufs["ws"][l] = ws
             last = l == n_conv - 1
             up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
             if small:
@@ -297,6 +317,13 @@ def _rmse_autograd(model, batch):
     return torch.sqrt(model.loss(out, batch.y.unsqueeze(1)))
 
 
+def _accumulate(total, loss, num_graphs):
+    """total += loss * num_graphs on the device, one launch (the reference does `loss.item() * batch.num_graphs`)."""
+    if total is None:
+        return loss.detach() * float(num_graphs)
+    return total.add_(loss.detach(), alpha=float(num_graphs))
+
+
 def train_network(model, train_loader, device):
     """reference utils/utils_model.py:55-70: one epoch; returns sum(loss * num_graphs) / len(dataset).
     The per-batch `loss.item()` of the reference is replaced by a device-side accumulation and ONE sync."""
@@ -319,8 +346,7 @@ def train_network(model, train_loader, device):
             loss.backward()
             model.optimizer.step()
             loss = loss.detach()
-        contrib = loss * float(batch.num_graphs)
-        total = contrib.clone() if total is None else total + contrib
+        total = _accumulate(total, loss, batch.num_graphs)
     if total is None:
         return 0.0
     return float(total.item()) / len(train_loader.dataset)
@@ -329,13 +355,22 @@ def train_network(model, train_loader, device):
 def eval_network(model, loader, device):
     """reference utils/utils_model.py:72-79 (forward + sqrt(MSE) per batch; no parameter update)."""
     model.eval()
+    fused = getattr(model, "_hcg_train_step", None)
+    if fused is None:
+        fused = FusedTrainStep(model)
+        try:
+            model._hcg_train_step = fused
+        except Exception:
+            pass
     total = None
     with torch.no_grad():
         for batch in loader:
             batch = batch.to(device)
-            loss = _rmse_autograd(model, batch)
-            contrib = loss * float(batch.num_graphs)
-            total = contrib.clone() if total is None else total + contrib
+            if FusedTrainStep.unsupported_reason(model, batch) is None:
+                loss = fused.evaluate(batch)
+            else:
+                loss = _rmse_autograd(model, batch)
+            total = _accumulate(total, loss, batch.num_graphs)
     if total is None:
         return 0.0
     return float(total.item()) / len(loader.dataset)

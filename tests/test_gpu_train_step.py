@@ -189,7 +189,7 @@ def test_forty_launches_are_bitwise_identical(H):
     ref = None
     for rep in range(40):
         loss = step(batch)
-        bufs = next(iter(step._bufs.values()))
+        bufs = [v for k, v in step._bufs.items() if k != "cap"][0]
         cur = [loss.clone(), step._flat.clone(), bufs["acts"][0].clone(), bufs["acts"][1].clone(), bufs["emb"].clone(),
                bufs["demb"].clone(), bufs["dacts"][0].clone(), bufs["out"].clone()]
         if ref is None:
@@ -240,3 +240,22 @@ def test_fused_trainer_with_rccl_exchange_world1(H):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_fused_evaluate_matches_the_autograd_forward_and_leaves_the_model_alone(H):
+    """FusedTrainStep.evaluate (eval_network's body): same loss as model(batch) -> sqrt(MSE), no parameter or gradient
+    is touched; small-graph and reference-sized batches."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    for nodes in (30, 87):
+        sb = synth.make_config("C2", num_graphs=64, nodes=nodes)
+        m = H.make_network("GCN", H.default_options(), 64).cuda()
+        batch = sb.as_batch("cuda")
+        before = [p.detach().clone() for p in m.parameters()]
+        step = FusedTrainStep(m)
+        loss = step.evaluate(batch)
+        with torch.no_grad():
+            ref = torch.sqrt(m.loss(m(batch), batch.y.unsqueeze(1)))
+        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
+        assert all(p.grad is None for p in m.parameters())

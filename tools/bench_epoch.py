@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Dev tool: one training epoch as the reference runs it (scripts_experiments/train_GNN.py:73-80: 535 training graphs,
+batch_size 40, shuffle; utils/utils_model.py:55-70) -- hcatgnet_amd.train.train_network over a DeviceLoader vs the CPU
+oracle's loop on the same graphs.  Prints ms per epoch and graphs/s."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hcatgnet_amd as H
+from hcatgnet_amd import synth
+from hcatgnet_amd.train import train_network, eval_network
+from oracle import gcn_oracle
+G, BS = 535, 40
+sb = synth.make_config("REAL", num_graphs=G)
+graphs = sb.as_graph_list()
+store = H.DeviceGraphStore(graphs, device="cuda")
+loader = H.DeviceLoader(store, batch_size=BS, shuffle=True, seed=0)
+model = H.make_network("GCN", H.default_options(), 25).cuda()
+for _ in range(3):
+    train_network(model, loader, "cuda")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+EP = 20
+for _ in range(EP):
+    loss = train_network(model, loader, "cuda")
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / EP
+print(f"MI355X  train_network: {dt * 1e3:8.2f} ms/epoch ({len(loader)} batches of {BS}; {G / dt:10.0f} graphs/s), last epoch loss {loss:.4f}")
+t0 = time.perf_counter()
+for _ in range(EP):
+    eval_network(model, loader, "cuda")
+torch.cuda.synchronize(); dte = (time.perf_counter() - t0) / EP
+print(f"MI355X  eval_network : {dte * 1e3:8.2f} ms/epoch")
+# CPU: the oracle's loop with the host collate (what the reference does through PyG on the CPU)
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+params = {k: v.detach().cpu().clone() for k, v in H.make_network("GCN", H.default_options(), 25).state_dict().items()}
+p, opt = gcn_oracle.make_train_state(params)
+cl = H.DataLoader(graphs, batch_size=BS, shuffle=True)
+def cpu_epoch():
+    for b in cl:
+        gcn_oracle.train_step(p, opt, b.x, b.edge_index, b.batch, b.y, b.num_graphs)
+cpu_epoch(); t0 = time.perf_counter()
+for _ in range(3): cpu_epoch()
+dtc = (time.perf_counter() - t0) / 3
+print(f"CPU oracle loop ({torch.get_num_threads()} threads): {dtc * 1e3:8.2f} ms/epoch ({G / dtc:10.0f} graphs/s) -> x{dtc / dt:.1f}")
