@@ -6,10 +6,10 @@ import torch, hcatgnet_amd as H
 from hcatgnet_amd import synth
 sb = synth.make_config("C2"); m = H.make_network("GCN", H.default_options(), 64).cuda()
 x, ei, bv, y = sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.y.cuda(); y2 = y.unsqueeze(1)
-def step():
-    m.optimizer.zero_grad(set_to_none=True)
-    b = H.Batch(x, ei, bv, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
-    out = m(b); loss = torch.sqrt(m.loss(out, y2)); loss.backward()
+from hcatgnet_amd.train import FusedTrainStep
+trainer = FusedTrainStep(m)
+def step():      # the product's training step (no autograd)
+    trainer(H.Batch(x, ei, bv, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True))
 for _ in range(20): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
