@@ -92,3 +92,20 @@ def test_predict_network_on_gpu_reproduces_reference_embeddings_csv(path, tmp_pa
     assert rel_inf(torch.from_numpy(got["emb"]), gd["ref_emb"]) <= 1e-5
     assert float(np.abs(got["pred"] - gd["ref_pred"].numpy()).max()) <= 5e-5
     assert np.allclose(got["exp"], gd["y"].numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_example_training_run_like_the_reference(tmp_path):
+    """examples/train_like_reference.py: the reference's inner training run (epochs, ReduceLROnPlateau every 5th epoch,
+    early stopping, best state-dict, predictions, embeddings.csv) end to end on the GPU with synthetic reaction-sized graphs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_like_reference",
+                                                  os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "train_like_reference.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "embeddings.csv")
+    best = mod.main(["--graphs", "200", "--epochs", "11", "--out", out])
+    assert np.isfinite(best) and best < 20.0 and os.path.isfile(out)   # random targets ~ N(0, 10^2): validation stays near 10
+    from hcatgnet_amd.io import read_embeddings_csv
+    got = read_embeddings_csv(out)
+    assert got["emb"].shape == (200, 128) and set(got["set"]) == {"training", "val", "test"}
