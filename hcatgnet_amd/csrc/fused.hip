@@ -323,6 +323,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   // weight operands: W [64][F] -> three bf16 planes in LDS, once per workgroup
   stage_weight_split<false>(w1l, DD, KPAD, W, DD, F);
   if (STACK2) stage_weight_split<false>(w2l, DD, DD, W2, DD, DD);
+  const float slope_eff = apply_act ? slope : 1.0f;
   float b0 = bias[r], b1 = bias[32 + r];
   float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
   // retire the bias loads HERE: left pending, their first use (in the epilogue of the tile loop) makes
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         const int row = krow(i, h);
         float v0 = fmaf(y0[i], dvr[i], bb0), v1 = fmaf(y1[i], dvr[i], bb1);
         // LeakyReLU as max(v, slope*v): exact for 0 <= slope <= 1 (the host rejects other slopes)
-        if (apply_act) { v0 = fmaxf(v0, slope * v0); v1 = fmaxf(v1, slope * v1); }
+        v0 = fmaxf(v0, slope_eff * v0);          // no activation: slope_eff = 1 -> max(v, v) = v (no per-element select)
+        v1 = fmaxf(v1, slope_eff * v1);
         y0[i] = v0;
         y1[i] = v1;
         L.buf[row * HS + r] = v0;
@@ -510,6 +512,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   WaveLdsB& L = lds[wave];
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   constexpr int NBF = KPAD / 32;  // column blocks of dW (input-feature dimension)
+  const float slope_eff = apply_act ? slope : 1.0f;
   const int stride = gridDim.x * WAVES;
 
   // first tile's loads go out before anything else
@@ -591,10 +594,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < ti.n) {
         d = dy[it];
-        if (apply_act) {
-          const float4 a = sa.v4[it];
-          d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
-          d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
+        {
+          const float4 a = sa.v4[it];            // (no activation: slope_eff = 1 -> factor 1 either way, no branch)
+          d.x *= hcg_leaky_grad(a.x, slope_eff); d.y *= hcg_leaky_grad(a.y, slope_eff);
+          d.z *= hcg_leaky_grad(a.z, slope_eff); d.w *= hcg_leaky_grad(a.w, slope_eff);
         }
         dbacc = f4_add(dbacc, d);
         const float di = L.ldinv[i];
