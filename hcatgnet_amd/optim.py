@@ -58,6 +58,19 @@ class FusedAdam(torch.optim.Optimizer):
             return int(fl["step_dev"][0].item())     # synchronises
         return fl["step"]
 
+    def load_state_dict(self, state_dict):
+        """Restored moments / step counts are copied into fresh flat buffers right away (torch's `load_state_dict` may
+        alias the tensors of the dict it is given: a source optimizer that keeps stepping must not leak into this one)."""
+        super().load_state_dict(state_dict)
+        self._flat = {}
+        with torch.no_grad():
+            for gi, group in enumerate(self.param_groups):
+                ps = [p for p in group["params"] if p.requires_grad]
+                if ps and all(p.is_cuda for p in ps):
+                    fl = self._rebase(gi, group)
+                    if self.capturable:
+                        self._make_dev_state(fl, group)
+
     def state_dict(self):
         for gi, group in enumerate(self.param_groups):
             fl = self._flat.get(gi)

@@ -259,3 +259,26 @@ def test_fused_evaluate_matches_the_autograd_forward_and_leaves_the_model_alone(
         assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
         assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
         assert all(p.grad is None for p in m.parameters())
+
+
+def test_fused_adam_state_dict_round_trip_in_capturable_mode(H):
+    """Optimizer state saved after k fused steps and loaded into a fresh model continues the trajectory bit for bit
+    (moments and the device-side step count survive `state_dict()` / `load_state_dict()`)."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=128)
+    batch = sb.as_batch("cuda")
+    a = H.make_network("GCN", H.default_options(), 64).cuda()
+    sa = FusedTrainStep(a)
+    for _ in range(3):
+        sa(batch)
+    b = H.make_network("GCN", H.default_options(), 64).cuda()
+    b.load_state_dict(a.state_dict())
+    b.optimizer.load_state_dict(a.optimizer.state_dict())
+    sb_ = FusedTrainStep(b)
+    la = [float(sa(batch)) for _ in range(3)]
+    lb = [float(sb_(batch)) for _ in range(3)]
+    assert la == lb
+    assert a.optimizer.steps_done() == b.optimizer.steps_done() == 6
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
