@@ -78,6 +78,8 @@ class FusedTrainStep:
             return "head shape (embedding_dim must be 64, n_classes <= 8)"
         if type(model.loss).__name__ != "MSELoss":
             return "loss other than MSE"
+        if not all(q.requires_grad for q in model.parameters()):
+            return "frozen parameters (the fused backward writes every gradient)"
         if batch is not None:
             if getattr(batch, "y", None) is None:
                 return "batch has no targets"

@@ -176,3 +176,47 @@ def test_mid_wide_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, fe
     m.use_fused = True
     out_2, emb_2, g_2 = _step_grads(m, batch, batch.y)
     assert torch.equal(out_f, out_2) and torch.equal(emb_f, emb_2) and all(torch.equal(g_f[k], g_2[k]) for k in g_f)
+
+
+def test_mid_at_the_shape_limits(H, oracle):
+    """A 224-node graph with exactly 1024 directed edges (the limits of the one-graph-per-workgroup kernels) next to a
+    33-node graph: forward and gradients equal the any-shape path; one node / one edge more and the layer falls back."""
+    from hcatgnet_amd import functional as HF
+    g = torch.Generator().manual_seed(11)
+    n1, n2 = 224, 33
+    bonds = [(i, (i + 1) % n1) for i in range(n1)]                       # ring: 224 bonds
+    k = 2
+    while len(bonds) < 512:                                               # chords until 512 bonds = 1024 directed edges
+        for i in range(0, n1, 3):
+            if len(bonds) < 512:
+                bonds.append((i, (i + k * 7) % n1))
+        k += 1
+    src = [a for a, b in bonds for _ in (0, 1)]; dst = [b for a, b in bonds for _ in (0, 1)]
+    e1 = torch.tensor([[a if j % 2 == 0 else b for j, (a, b) in enumerate(zip(src, dst))],
+                       [b if j % 2 == 0 else a for j, (a, b) in enumerate(zip(src, dst))]], dtype=torch.int64)
+    e2 = torch.tensor([[i for i in range(n2 - 1)] + [i + 1 for i in range(n2 - 1)],
+                       [i + 1 for i in range(n2 - 1)] + [i for i in range(n2 - 1)]], dtype=torch.int64) + n1
+    ei = torch.cat([e1, e2], 1)
+    assert e1.shape[1] == 1024
+    x = torch.randn(n1 + n2, 32, generator=g)
+    bv = torch.cat([torch.zeros(n1, dtype=torch.int64), torch.ones(n2, dtype=torch.int64)])
+    y = torch.randn(2, generator=g)
+    params = _rand_params(32, 64, seed=43)
+    m = _model_from_params(H, params)
+    batch = H.Batch(x.cuda(), ei.cuda(), bv.cuda(), 2, y=y.cuda(), max_nodes=n1, max_edges=1024, edges_grouped=True)
+    plan = H.BatchPlan.build(batch.edge_index, batch.batch, n1 + n2, num_graphs=2, mode="blocked", max_nodes=n1, max_edges=1024)
+    batch._hcg_plan = plan
+    assert HF.mid_supported(plan, 32, 64)
+    m.use_fused = True
+    out_f, emb_f, g_f = _step_grads(m, batch, batch.y)
+    assert plan.check_status() == 0
+    m.use_fused = False
+    out_g, emb_g, g_g = _step_grads(m, batch, batch.y)
+    o_out, o_emb = oracle.gcn_forward(params, x, ei, bv, 2)
+    assert rel_inf(emb_f, o_emb) <= TOL and rel_inf(out_f, o_out, floor=1.0) <= TOL
+    assert rel_inf(emb_f, emb_g) <= 2e-6
+    for k_ in g_f:
+        assert rel_inf(g_f[k_], g_g[k_]) <= TOL, k_
+    for mn, me in ((225, 1024), (224, 1025)):
+        p2 = H.BatchPlan.build(batch.edge_index, batch.batch, n1 + n2, num_graphs=2, mode="blocked", max_nodes=mn, max_edges=me)
+        assert not HF.mid_supported(p2, 32, 64)
