@@ -512,7 +512,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   WaveLdsB& L = lds[wave];
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   constexpr int NBF = KPAD / 32;  // column blocks of dW (input-feature dimension)
-  const float slope_eff = apply_act ? slope : 1.0f;
+  const float slope_eff = (apply_act & 1) ? slope : 1.0f;
+  // bit 1 of apply_act: dx leaves this kernel already multiplied by leaky'(x) -- x is the previous layer's activated
+  // output, so that layer's backward runs with bit 0 clear and never reads its own output (a_out == nullptr there)
+  const bool premask = NEEDS_DX && (apply_act & 2);
+  const bool use_out = a_out != nullptr;
   const int stride = gridDim.x * WAVES;
 
   // first tile's loads go out before anything else
@@ -520,13 +524,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   bool have = t < num_tiles;
   TileInfo ti;
   TileRaw raw_next;
-  Stager<DD, true> sa, sd;
+  Stager<DD, true> sa{}, sd;
   TileEdges te;
   if (have) {
     const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
     raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
     ti = tile_finish(raw0, gpt, lane, status);
-    sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
+    if (POOLG || use_out) sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
     if (!POOLG) sd.load(dout, DD, N, ti.nbase, ti.n, lane);
     te.load(ti, graph_ptr, ei, E, lane);
   }
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < ti.n) {
         d = dy[it];
-        {
+        if (POOLG || use_out) {
           const float4 a = sa.v4[it];            // (no activation: slope_eff = 1 -> factor 1 either way, no branch)
           d.x *= hcg_leaky_grad(a.x, slope_eff); d.y *= hcg_leaky_grad(a.y, slope_eff);
           d.z *= hcg_leaky_grad(a.z, slope_eff); d.w *= hcg_leaky_grad(a.w, slope_eff);
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const TileRaw raw_cur = raw_next;
     raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
     TileInfo tin;
-    Stager<DD, true> san, sdn;
+    Stager<DD, true> san{}, sdn;
     TileEdges ten;
     // x rows of THIS tile: in the variant with registers to spare (no dx, no pooled prologue) they are requested here,
     // one aggregation ahead of their use, instead of waiting out an HBM round trip in front of the dW MFMAs
@@ -654,6 +658,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     //         B[k = node][f] read down the columns of the x tile
     if (!EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
     sx.write(L.buf, F, ti.n, lane);
+    // premask, wide rows: bit 4 it + c <-> x[row it*4 + r4][4 q + c] > 0 -- one register carried to the dx stores
+    // instead of the rows (measured against bits taken in the accumulator layout inside the dW loop: those spill)
+    uint32_t xpos = 0;
+    if (NEEDS_DX && VEC) {
+      if (premask) {
+#pragma unroll
+        for (int it = 0; it < TM / 4; ++it) {
+          const float4 v = sx.v4[it];
+          xpos |= (uint32_t)(v.x > 0.f) << (4 * it) | (uint32_t)(v.y > 0.f) << (4 * it + 1) |
+                  (uint32_t)(v.z > 0.f) << (4 * it + 2) | (uint32_t)(v.w > 0.f) << (4 * it + 3);
+        }
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const float a0[8] = {dh0[8 * s], dh0[8 * s + 1], dh0[8 * s + 2], dh0[8 * s + 3],
@@ -707,7 +724,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         for (int i = 0; i < 16; ++i)
 #pragma unroll
           for (int nb = 0; nb < NBF; ++nb) L.buf[krow(i, h) * HS + nb * 32 + r] = dxa[nb][i];
-        if (ti.n > 0) {   // rows >= n redirected to row n-1 (duplicate identical stores, no per-lane branch)
+        if (premask) {    // own rows only (the mask bits are this lane's rows), rows >= n not stored
+          if (4 * q < KPAD) {
+            float4 ov[TM / 4];
+#pragma unroll
+            for (int it = 0; it < TM / 4; ++it) {
+              ov[it] = *reinterpret_cast<const float4*>(L.buf + (it * 4 + r4) * HS + 4 * q);
+              ov[it].x *= (xpos >> (4 * it) & 1) ? 1.f : slope;
+              ov[it].y *= (xpos >> (4 * it + 1) & 1) ? 1.f : slope;
+              ov[it].z *= (xpos >> (4 * it + 2) & 1) ? 1.f : slope;
+              ov[it].w *= (xpos >> (4 * it + 3) & 1) ? 1.f : slope;
+            }
+#pragma unroll
+            for (int it = 0; it < TM / 4; ++it)
+              if (it * 4 + r4 < ti.n)
+                *reinterpret_cast<float4*>(dx + (size_t)(ti.nbase + it * 4 + r4) * F + 4 * q) = ov[it];
+          }
+        } else if (ti.n > 0) {   // rows >= n redirected to row n-1 (duplicate identical stores, no per-lane branch)
           const int qc = 4 * q < KPAD ? q : 0;
           float4 ov[TM / 4];
 #pragma unroll
@@ -729,7 +762,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 #pragma unroll
             for (int nb = 0; nb < NBF; ++nb) {
               const int f = nb * 32 + r;
-              if (f < F) dx[(size_t)(ti.nbase + row) * F + f] = dxa[nb][i];
+              if (f < F) {
+                const size_t at = (size_t)(ti.nbase + row) * F + f;
+                dx[at] = premask ? dxa[nb][i] * hcg_leaky_grad(x[at], slope) : dxa[nb][i];
+              }
             }
           }
         }
@@ -739,7 +775,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     have = have_next;
     if (have_next) {
       tin = tile_finish(raw_cur, gpt, lane, status);
-      san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+      if (POOLG || use_out) san.load(a_out, DD, N, tin.nbase, tin.n, lane);
       if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
       ten.load(tin, graph_ptr, ei, E, lane);
       t = tn;
@@ -909,8 +945,12 @@ extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const f
   if (N < 0 || B < 0 || E < 0 || !W || !workspace) return HCG_ERR_INVALID_ARG;
   const bool poolg = (dout == nullptr);
   if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
-  if (N > 0 && B > 0 && (!out || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index)))
+  if (apply_act & ~3) return HCG_ERR_INVALID_ARG;
+  if ((apply_act & 2) && !dx) return HCG_ERR_INVALID_ARG;
+  // `out` is only read for the activation derivative and the pooled-gradient routing
+  if (N > 0 && B > 0 && (((poolg || (apply_act & 1)) && !out) || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index)))
     return HCG_ERR_INVALID_ARG;
+  if (!poolg && !(apply_act & 1)) out = nullptr;
   const int kpad = F <= 32 ? 32 : 64;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = (N > 0 && B > 0) ? pick_grid(tiles) : 0;

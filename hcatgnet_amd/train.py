@@ -223,7 +223,9 @@ class FusedTrainStep:
         _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
                                            g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
         # ---- conv stack backward, last layer first
-        njobs, dh = 1, None
+        # a fused-tile layer can hand its dx down already multiplied by the activation derivative of the layer below
+        # (it holds those rows anyway, for dW); that layer then never reads its own output: one tensor less per step
+        njobs, dh, premasked = 1, None, False
         for l in reversed(range(n_conv)):
             inp = x if l == 0 else acts[l - 1]
             Fl = inp.shape[1]
@@ -237,9 +239,11 @@ class FusedTrainStep:
             last = l == n_conv - 1
             up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
             if small:
-                rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                             p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope, 1, p(dx), p(plan.status), p(ws),
-                                             wsb, stream)
+                act = 0 if premasked else 1
+                premasked = l > 0 and gpts[l - 1] > 0
+                rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
+                                             plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
+                                             act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_fused_layer_bwd")
                 _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")

@@ -174,7 +174,11 @@ int hcg_fused_stack2_fwd(const float* x, const float* W1, const float* b1, const
  * demb[B, 2D] and is expanded on chip with `emb` (ties of the max split evenly).  dx nullable (first
  * layer).  Leaves one partial slab [D*KPAD + D] per workgroup in `workspace`
  * (hcg_fused_workspace_bytes); stage 2 = hcg_fused_reduce_grads sums them in a fixed order into
- * dW [D, F], db [D]: bitwise reproducible. */
+ * dW [D, F], db [D]: bitwise reproducible.
+ * apply_act here is a bit set: bit 0 = multiply the upstream gradient by LeakyReLU'(out) (as in the forward);
+ * bit 1 = hand dx down ALREADY multiplied by LeakyReLU'(x) -- x being the previous layer's activated output, whose
+ * rows this kernel holds anyway -- so that layer's backward is called with bit 0 clear and `out` = NULL and never
+ * reads its own output.  `out` is only required with bit 0 set or in the pooled form. */
 int hcg_fused_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
                         const float* out, const float* x, const float* W,
                         const int64_t* edge_index, int64_t E,

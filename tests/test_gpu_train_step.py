@@ -282,3 +282,56 @@ def test_fused_adam_state_dict_round_trip_in_capturable_mode(H):
     assert a.optimizer.steps_done() == b.optimizer.steps_done() == 6
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("feat,pooled", [(64, False), (64, True), (25, False)])
+def test_fused_backward_hands_down_a_premasked_dx(H, feat, pooled):
+    """apply_act bit 1 of hcg_fused_layer_bwd: dx leaves the kernel multiplied by LeakyReLU'(x) and the layer below is
+    then called with bit 0 clear and out = NULL.  Both are ONE extra f32 multiply moved across a launch boundary, so
+    the results are bitwise those of the plain call sequence."""
+    from hcatgnet_amd import synth, _lib
+    from hcatgnet_amd import functional as HF
+    lib, p = _lib.load(), _lib.ptr
+    sb = synth.make_config("C2", num_graphs=300, seed=5)
+    from hcatgnet_amd.plan import BatchPlan
+    b = sb.as_batch("cuda")
+    plan = BatchPlan.build(b.edge_index, b.batch, b.x.shape[0], num_graphs=b.num_graphs, mode="blocked",
+                           max_nodes=sb.max_nodes, max_edges=sb.max_edges)
+    N, B, D, slope = plan.N, plan.B, 64, 0.01
+    gen = torch.Generator().manual_seed(7)
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda()
+    x, out, W = rnd(N, feat), rnd(N, D), rnd(D, feat) * 0.2          # x: "previous layer's output", both signs
+    x[::7] = 0.0                                                       # exact zeros take the slope side, like the forward
+    dout, emb, demb = rnd(N, D), None, None
+    if pooled:
+        emb = torch.cat([torch.stack([out[plan.graph_ptr[g]:plan.graph_ptr[g + 1]].max(0).values for g in range(B)]),
+                         torch.zeros(B, D, device="cuda")], 1).contiguous()
+        demb, dout = rnd(B, 2 * D), None
+    gpt = HF.fused_graphs_per_tile(plan, feat, D)
+    assert gpt > 0
+    wsb = lib.hcg_fused_workspace_bytes(B, feat, D, gpt)
+
+    def bwd(dout_, out_, x_, W_, F_, flags, want_dx=True):
+        ws = torch.empty(wsb if F_ == feat else lib.hcg_fused_workspace_bytes(B, F_, D, gpt), dtype=torch.uint8, device="cuda")
+        dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
+        dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
+        rc = lib.hcg_fused_layer_bwd(p(dout_), p(demb) if dout_ is None else None, p(emb) if dout_ is None else None, p(out_),
+                                     p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, F_, D,
+                                     gpt, slope, flags, p(dx), p(plan.status), p(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "hcg_fused_layer_bwd")
+        _lib.check(lib.hcg_fused_reduce_grads(p(ws), ws.numel(), N, B, F_, D, gpt, p(dW), p(db), _lib.stream_ptr()), "reduce")
+        return dx, dW, db
+
+    dx, dW, db = bwd(dout, out, x, W, feat, 1)
+    dxm, dWm, dbm = bwd(dout, out, x, W, feat, 3)
+    assert torch.equal(dW, dWm) and torch.equal(db, dbm)
+    assert torch.equal(dxm, dx * torch.where(x > 0, 1.0, slope).to(dx.dtype))
+    if feat == 64:      # the layer below: premasked gradient, no activation, no `out` -- vs the plain call on the raw gradient
+        x0, W0 = rnd(N, 25), rnd(D, 25) * 0.2
+        _, dW_a, db_a = bwd(dx, x, x0, W0, 25, 1, want_dx=False)
+        _, dW_b, db_b = bwd(dxm, None, x0, W0, 25, 0, want_dx=False)
+        assert torch.equal(dW_a, dW_b) and torch.equal(db_a, db_b)
+    # misuse is refused, not ignored
+    assert lib.hcg_fused_layer_bwd(p(dx), None, None, None, p(x), p(W), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                   p(plan.edge_ptr), N, B, feat, D, gpt, slope, 1, None, p(plan.status),
+                                   p(torch.empty(wsb, dtype=torch.uint8, device="cuda")), wsb, _lib.stream_ptr()) != 0
