@@ -56,24 +56,35 @@ class EntryTimer:
     """HIP-event timing of ONE C-ABI entry point on the stream it launches on (torch's current
     stream: the library only enqueues on the stream it is handed)."""
 
+    # entry points that launch the SAME kernel family as the named one (training forms of the pooled layer)
+    SAME_KERNEL = {"hcg_fused_layer_bwd": ("hcg_fused_layer_bwd_poolbits",),
+                   "hcg_fused_stack2_fwd": ("hcg_fused_stack2_fwd_train",),
+                   "hcg_fused_layer_fwd": ("hcg_fused_layer_fwd_train",)}
+
     def __init__(self, lib, name):
-        self.lib, self.name, self.orig = lib, name, getattr(lib, name)
+        self.lib, self.name = lib, name
+        self.names = (name,) + self.SAME_KERNEL.get(name, ())
+        self.orig = {n: getattr(lib, n) for n in self.names}
         self.events, self.enabled = [], False
 
     def install(self):
-        def wrapper(*a):
-            if not self.enabled:
-                return self.orig(*a)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            rc = self.orig(*a)
-            e.record()
-            self.events.append((s, e))
-            return rc
-        setattr(self.lib, self.name, wrapper)
+        def make(orig):
+            def wrapper(*a):
+                if not self.enabled:
+                    return orig(*a)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = orig(*a)
+                e.record()
+                self.events.append((s, e))
+                return rc
+            return wrapper
+        for n in self.names:
+            setattr(self.lib, n, make(self.orig[n]))
 
     def uninstall(self):
-        setattr(self.lib, self.name, self.orig)
+        for n in self.names:
+            setattr(self.lib, n, self.orig[n])
 
     def mean_ms(self, per_step_calls):
         torch.cuda.synchronize()

@@ -41,6 +41,10 @@ SIGNATURES = {
     "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
     "hcg_fused_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
+    "hcg_fused_poolbits_bytes": (SZ, [I64, INT]),
+    "hcg_fused_layer_fwd_train": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
+    "hcg_fused_stack2_fwd_train": (INT, [P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P, P]),
+    "hcg_fused_layer_bwd_poolbits": (INT, [P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
     "hcg_fused_stack2_fwd": (INT, [P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P, P]),
     "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
     "hcg_mid_supported": (INT, [I64, I64, I64, I64]),

@@ -287,13 +287,18 @@ struct Stager {
 // layout the next GEMM reads (the epilogue puts it there for the wide stores), the adjacency fragments and
 // dinv are shared, and the second launch's prologue / tile staging / count build disappear.  POOL then
 // refers to layer 2.
-template <int KPAD, bool VEC, bool POOL, bool STACK2>
+// BITS (training, needs POOL): the pooled layer's activations do NOT go to HBM; what the pooled backward needs of
+// them leaves as two bits per element, in the accumulator layout: poolbits[tile][0][lane] bit 16 b + i <-> value at
+// (row krow(i, h), column 32 b + r) is > 0, poolbits[tile][1][lane] the same positions: value == its graph's column max.
+template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ W2, const float* __restrict__ bias2,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
-    float* __restrict__ out, float* __restrict__ out2, float* __restrict__ emb, int32_t* __restrict__ status) {
+    float* __restrict__ out, float* __restrict__ out2, float* __restrict__ emb, uint32_t* __restrict__ poolbits,
+    int32_t* __restrict__ status) {
+  static_assert(!BITS || POOL, "the bit form belongs to the pooled layer");
   __shared__ WaveLdsF lds[WAVES];
   __shared__ __attribute__((aligned(16))) short w1l[3 * DD * (KPAD + WPAD)];
   __shared__ __attribute__((aligned(16))) short w2l[STACK2 ? 3 * DD * (DD + WPAD) : 8];
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       //      dwordx4 per lane instead of 64 exec-masked dword stores -- and, stacked, so that they ARE the
       //      next layer's input tile.
       const float bb0 = layer == 0 ? b0 : c0, bb1 = layer == 0 ? b1 : c1;
+      const bool to_hbm = !(BITS && layer == (STACK2 ? 1 : 0));   // (folds: the layer loop is unrolled)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = krow(i, h);
@@ -416,12 +422,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         v1 = fmaxf(v1, slope_eff * v1);
         y0[i] = v0;
         y1[i] = v1;
-        L.buf[row * HS + r] = v0;
-        L.buf[row * HS + 32 + r] = v1;
+        if (to_hbm) {
+          L.buf[row * HS + r] = v0;
+          L.buf[row * HS + 32 + r] = v1;
+        }
       }
       if (layer == 0) STAMP(7 + 8 * stamp_it);
       if (layer == 1 && stamp_it == 0) STAMP(44);
-      if (ti.n > 0) {   // wave-uniform
+      if (to_hbm && ti.n > 0) {   // wave-uniform
         // rows >= n are redirected to row n-1 (read AND write): duplicate identical stores instead of a
         // per-lane branch around every store -> all 8 LDS reads and 8 stores stay in one basic block
         const int q = lane & 15, r4 = lane >> 4;
@@ -441,6 +449,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
       if (stamp_it == 0) STAMP(layer == 0 ? 40 : 45);
     }
     if (POOL) {
+      uint32_t pos = 0, ismax = 0;
+      if (BITS) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pos |= (uint32_t)(y0[i] > 0.f) << i | (uint32_t)(y1[i] > 0.f) << (16 + i);
+      }
       for (int g = ti.g0; g < ti.g1; ++g) {
         const int gb = L.lgp[g - ti.g0], ge = L.lgp[g - ti.g0 + 1];
         float m0 = -INFINITY, m1 = -INFINITY, s0 = 0.f, s1 = 0.f;
@@ -453,6 +466,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
         m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
         s0 += __shfl_xor(s0, 32, 64);
         s1 += __shfl_xor(s1, 32, 64);
+        if (BITS) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = krow(i, h);
+            if (row >= gb && row < ge) ismax |= (uint32_t)(y0[i] == m0) << i | (uint32_t)(y1[i] == m1) << (16 + i);
+          }
+        }
         if (h == 0) {
           const int n = ge - gb;
           const float cntf = (float)(n > 0 ? n : 1);
@@ -463,6 +483,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
           e[DD + r] = s0 / cntf;
           e[DD + 32 + r] = s1 / cntf;
         }
+      }
+      if (BITS) {
+        poolbits[(size_t)t * 128 + lane] = pos;
+        poolbits[(size_t)t * 128 + 64 + lane] = ismax;
       }
     }
     STAMP(5 + 8 * stamp_it);
@@ -497,10 +521,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 //   db += colsum dY ;  dH = Ahat^T dY ;  dW += dH^T x ;  dx = dH W  (NEEDS_DX)
 // per-workgroup partial sums go to `partials[blockIdx][64*KPAD + 64]`.
 // =====================================================================================================
-template <int KPAD, bool VEC, bool NEEDS_DX, bool POOLG>
+// BITS (needs POOLG): the layer's output was never stored; its sign / is-the-column-max bits (`poolbits`, written by the
+// BITS forward over the same tiles) stand in for a_out and emb.
+template <int KPAD, bool VEC, bool NEEDS_DX, bool POOLG, bool BITS = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb,
-    const float* __restrict__ a_out, const float* __restrict__ x, int F, const float* __restrict__ W,
+    const float* __restrict__ a_out, const uint32_t* __restrict__ poolbits, const float* __restrict__ x, int F,
+    const float* __restrict__ W,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
     float* __restrict__ dx, float* __restrict__ partials, int32_t* __restrict__ status) {
@@ -515,8 +542,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   const float slope_eff = (apply_act & 1) ? slope : 1.0f;
   // bit 1 of apply_act: dx leaves this kernel already multiplied by leaky'(x) -- x is the previous layer's activated
   // output, so that layer's backward runs with bit 0 clear and never reads its own output (a_out == nullptr there)
+  static_assert(!BITS || POOLG, "the bit form is the pooled backward");
   const bool premask = NEEDS_DX && (apply_act & 2);
-  const bool use_out = a_out != nullptr;
+  const bool use_out = !BITS && a_out != nullptr;
   const int stride = gridDim.x * WAVES;
 
   // first tile's loads go out before anything else
@@ -525,12 +553,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   TileInfo ti;
   TileRaw raw_next;
   Stager<DD, true> sa{}, sd;
+  uint32_t pos = 0, ismax = 0;
   TileEdges te;
   if (have) {
     const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
     raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
     ti = tile_finish(raw0, gpt, lane, status);
-    if (POOLG || use_out) sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
+    if (BITS) {
+      pos = poolbits[(size_t)t * 128 + lane];
+      ismax = poolbits[(size_t)t * 128 + 64 + lane];
+    } else if (POOLG || use_out) {
+      sa.load(a_out, DD, N, ti.nbase, ti.n, lane);
+    }
     if (!POOLG) sd.load(dout, DD, N, ti.nbase, ti.n, lane);
     te.load(ti, graph_ptr, ei, E, lane);
   }
@@ -548,12 +582,49 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 #pragma unroll
       for (int i = 0; i < 16; ++i) dw[mb][nb][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dbl0 = 0.f, dbl1 = 0.f;   // BITS: column r / 32 + r of db (this lane's half of the rows)
 
   while (have) {
     te.build(L.cnt, L.ldinv, L.lgp, ti, ei, E, lane, status);
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> buf (rows >= n zero); A / dA stay in registers
     float4 dy[TM / 4];
+    if constexpr (BITS) {
+      // accumulator layout (lane = column, 16 rows in registers): the pooled gradient is two scalars per lane and graph
+      // every row < n belongs to exactly one graph of the tile: each graph writes its own rows of dY', the rest are zero
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = krow(i, h);
+        if (row >= ti.n) { L.buf[row * HS + r] = 0.f; L.buf[row * HS + 32 + r] = 0.f; }
+      }
+      for (int g = ti.g0; g < ti.g1; ++g) {
+        const int gb = L.lgp[g - ti.g0], ge = L.lgp[g - ti.g0 + 1];
+        if (ge <= gb) continue;
+        const float* de = demb + (size_t)g * 2 * DD;
+        const float cntf = (float)(ge - gb);
+        const float dmx0 = de[r], dmx1 = de[32 + r], dme0 = de[DD + r] / cntf, dme1 = de[DD + 32 + r] / cntf;
+        uint32_t rows = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rows |= (uint32_t)(krow(i, h) >= gb && krow(i, h) < ge) << i;
+        float t0 = (float)__builtin_popcount(ismax & rows), t1 = (float)__builtin_popcount((ismax >> 16) & rows);
+        t0 += __shfl_xor(t0, 32, 64);
+        t1 += __shfl_xor(t1, 32, 64);
+        const float share0 = dmx0 / fmaxf(t0, 1.f), share1 = dmx1 / fmaxf(t1, 1.f);   // ties of the max split evenly
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (rows >> i & 1) {
+            const int row = krow(i, h);
+            const float g0 = (dme0 + ((ismax >> i & 1) ? share0 : 0.f)) * ((pos >> i & 1) ? 1.f : slope_eff);
+            const float g1 = (dme1 + ((ismax >> (16 + i) & 1) ? share1 : 0.f)) * ((pos >> (16 + i) & 1) ? 1.f : slope_eff);
+            dbl0 += g0;
+            dbl1 += g1;
+            const float di = L.ldinv[row];
+            L.buf[row * HS + r] = di * g0;
+            L.buf[row * HS + 32 + r] = di * g1;
+          }
+        }
+      }
+    } else {
     if (POOLG) {
 #pragma unroll
       for (int it = 0; it < TM / 4; ++it) dy[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -608,6 +679,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
       }
       *reinterpret_cast<float4*>(L.buf + i * HS + 4 * q) = d;
+    }
     }
 
     // next tile of this wave: scalars one tile further ahead (the row loads wait until the accumulators leave room:
@@ -775,7 +847,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     have = have_next;
     if (have_next) {
       tin = tile_finish(raw_cur, gpt, lane, status);
-      if (POOLG || use_out) san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+      if (BITS) {
+        pos = poolbits[(size_t)tn * 128 + lane];
+        ismax = poolbits[(size_t)tn * 128 + 64 + lane];
+      } else if (POOLG || use_out) {
+        san.load(a_out, DD, N, tin.nbase, tin.n, lane);
+      }
       if (!POOLG) sdn.load(dout, DD, N, tin.nbase, tin.n, lane);
       ten.load(tin, graph_ptr, ei, E, lane);
       t = tn;
@@ -798,6 +875,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dw[mb][nb]);
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 16));
   dbacc = f4_add(dbacc, f4_shfl_xor(dbacc, 32));
+  dbl0 += __shfl_xor(dbl0, 32, 64);
+  dbl1 += __shfl_xor(dbl1, 32, 64);
   float tot[PER_T];
 #pragma unroll
   for (int j = 0; j < PER_T; ++j) tot[j] = 0.f;
@@ -812,7 +891,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
           for (int i = 0; i < 16; ++i) mine[(mb * 32 + krow(i, h)) * KPAD + nb * 32 + r] = dw[mb][nb][i];
-      if (r4 == 0) *reinterpret_cast<float4*>(mine + DD * KPAD + 4 * q) = dbacc;
+      if (BITS) {
+        if (h == 0) { mine[DD * KPAD + r] = dbl0; mine[DD * KPAD + 32 + r] = dbl1; }
+      } else if (r4 == 0) {
+        *reinterpret_cast<float4*>(mine + DD * KPAD + 4 * q) = dbacc;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -886,26 +969,31 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
 static int launch_fused_fwd(const float* x, const float* W, const float* b, const float* W2, const float* b2,
                             const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                             int64_t N, int64_t B, int64_t F, int64_t D, int graphs_per_tile, float slope, int apply_act,
-                            float* out, float* out2, float* emb, int32_t* status, hipStream_t stream) {
+                            float* out, float* out2, float* emb, uint32_t* poolbits, int32_t* status, hipStream_t stream) {
   const bool stack2 = W2 != nullptr;
+  const bool bits = poolbits != nullptr;   // the pooled layer's activations stay on chip (training form)
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;  // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
-  if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
-  if (stack2 && (!b2 || !out2)) return HCG_ERR_INVALID_ARG;
+  if (!x || !W || !b || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (bits && !emb) return HCG_ERR_INVALID_ARG;
+  if (!out && !(bits && !stack2)) return HCG_ERR_INVALID_ARG;
+  if (stack2 && (!b2 || (!out2 && !bits))) return HCG_ERR_INVALID_ARG;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = pick_grid(tiles);
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no tile has edges
-#define LAUNCH_FWD(KP, VC, PL, ST)                                                                                    \
-  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, E,  \
-                     graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, out2, emb, status)
-#define DISPATCH_FWD(KP, VC)                                                                       \
-  do {                                                                                             \
-    if (stack2) { if (emb) LAUNCH_FWD(KP, VC, true, true); else LAUNCH_FWD(KP, VC, false, true); }  \
-    else        { if (emb) LAUNCH_FWD(KP, VC, true, false); else LAUNCH_FWD(KP, VC, false, false); } \
+#define LAUNCH_FWD(KP, VC, PL, ST, BT)                                                                                \
+  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST, BT>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, \
+                     E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, out2, emb,      \
+                     poolbits, status)
+#define DISPATCH_FWD(KP, VC)                                                                                     \
+  do {                                                                                                           \
+    if (bits)        { if (stack2) LAUNCH_FWD(KP, VC, true, true, true); else LAUNCH_FWD(KP, VC, true, false, true); } \
+    else if (stack2) { if (emb) LAUNCH_FWD(KP, VC, true, true, false); else LAUNCH_FWD(KP, VC, false, true, false); }  \
+    else             { if (emb) LAUNCH_FWD(KP, VC, true, false, false); else LAUNCH_FWD(KP, VC, false, false, false); } \
   } while (0)
   if (F <= 32) { if (vec) DISPATCH_FWD(32, true); else DISPATCH_FWD(32, false); }
   else         { if (vec) DISPATCH_FWD(64, true); else DISPATCH_FWD(64, false); }
@@ -920,7 +1008,34 @@ extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* 
                                    int64_t D, int graphs_per_tile, float slope, int apply_act, float* out, float* emb,
                                    int32_t* status, hcg_stream_t stream) {
   return launch_fused_fwd(x, W, b, nullptr, nullptr, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, out, nullptr, emb, status, (hipStream_t)stream);
+                          apply_act, out, nullptr, emb, nullptr, status, (hipStream_t)stream);
+}
+
+// ---- training forms: the pooled (last) conv layer's activations never reach HBM.  The pooled backward needs two facts
+// per element -- its sign (LeakyReLU') and whether it is its graph's column maximum -- and they leave as 2 bits per
+// element (`poolbits`, hcg_fused_poolbits_bytes) for hcg_fused_layer_bwd_poolbits over the same plan / graphs_per_tile.
+extern "C" size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile) {
+  if (graphs_per_tile <= 0 || B <= 0) return 0;
+  return (size_t)((B + graphs_per_tile - 1) / graphs_per_tile) * 128 * sizeof(uint32_t);
+}
+
+extern "C" int hcg_fused_layer_fwd_train(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
+                                         const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                                         int64_t D, int graphs_per_tile, float slope, int apply_act, float* emb,
+                                         uint32_t* poolbits, int32_t* status, hcg_stream_t stream) {
+  if (!poolbits) return HCG_ERR_INVALID_ARG;
+  return launch_fused_fwd(x, W, b, nullptr, nullptr, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
+                          apply_act, nullptr, nullptr, emb, poolbits, status, (hipStream_t)stream);
+}
+
+extern "C" int hcg_fused_stack2_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                                          const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
+                                          const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
+                                          int graphs_per_tile, float slope, int apply_act, float* out1, float* emb,
+                                          uint32_t* poolbits, int32_t* status, hcg_stream_t stream) {
+  if (!W2 || !b2 || !poolbits) return HCG_ERR_INVALID_ARG;
+  return launch_fused_fwd(x, W1, b1, W2, b2, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
+                          apply_act, out1, nullptr, emb, poolbits, status, (hipStream_t)stream);
 }
 
 // two stacked conv layers (F -> 64 -> 64) in ONE launch: out1 = layer-1 node embeddings, out2 = layer-2
@@ -932,18 +1047,23 @@ extern "C" int hcg_fused_stack2_fwd(const float* x, const float* W1, const float
                                     int32_t* status, hcg_stream_t stream) {
   if (!W2 || !b2 || !out2) return HCG_ERR_INVALID_ARG;
   return launch_fused_fwd(x, W1, b1, W2, b2, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, out1, out2, emb, status, (hipStream_t)stream);
+                          apply_act, out1, out2, emb, nullptr, status, (hipStream_t)stream);
 }
 
-extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
-                                   const float* x, const float* W, const int64_t* edge_index, int64_t E,
-                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
-                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
-                                   void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int launch_fused_bwd(const float* dout, const float* demb, const float* emb, const float* out,
+                            const uint32_t* poolbits, const float* x, const float* W, const int64_t* edge_index, int64_t E,
+                            const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                            int64_t D, int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
   if (N < 0 || B < 0 || E < 0 || !W || !workspace) return HCG_ERR_INVALID_ARG;
   const bool poolg = (dout == nullptr);
+  const bool bits = poolbits != nullptr;
+  if (bits) {   // stands in for `out` and `emb`
+    if (!poolg || !demb) return HCG_ERR_INVALID_ARG;
+    out = x;    // (never read; keeps the pointer checks below uniform)
+    emb = demb;
+  }
   if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
   if (apply_act & ~3) return HCG_ERR_INVALID_ARG;
   if ((apply_act & 2) && !dx) return HCG_ERR_INVALID_ARG;
@@ -962,14 +1082,15 @@ extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const f
     const bool ndx = dx != nullptr;
     const dim3 g(grid), blk(WAVES * 64);
     if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy
-#define LAUNCH_BWD(KP, VC, DX, PG)                                                                                   \
-  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG>), g, blk, 0, stream, dout, demb, emb, out, x, (int)F, W,     \
-                     edge_index, E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, dx,     \
-                     partials, status)
-#define DISPATCH_BWD(KP, VC)                                                             \
-  do {                                                                                   \
-    if (ndx) { if (poolg) LAUNCH_BWD(KP, VC, true, true); else LAUNCH_BWD(KP, VC, true, false); } \
-    else     { if (poolg) LAUNCH_BWD(KP, VC, false, true); else LAUNCH_BWD(KP, VC, false, false); } \
+#define LAUNCH_BWD(KP, VC, DX, PG, BT)                                                                                \
+  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG, BT>), g, blk, 0, stream, dout, demb, emb, out, poolbits, x,    \
+                     (int)F, W, edge_index, E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, \
+                     dx, partials, status)
+#define DISPATCH_BWD(KP, VC)                                                                                   \
+  do {                                                                                                         \
+    if (bits)     { if (ndx) LAUNCH_BWD(KP, VC, true, true, true); else LAUNCH_BWD(KP, VC, false, true, true); }   \
+    else if (ndx) { if (poolg) LAUNCH_BWD(KP, VC, true, true, false); else LAUNCH_BWD(KP, VC, true, false, false); } \
+    else          { if (poolg) LAUNCH_BWD(KP, VC, false, true, false); else LAUNCH_BWD(KP, VC, false, false, false); } \
   } while (0)
     if (kpad == 32) { if (vec) DISPATCH_BWD(32, true); else DISPATCH_BWD(32, false); }
     else            { if (vec) DISPATCH_BWD(64, true); else DISPATCH_BWD(64, false); }
@@ -978,6 +1099,26 @@ extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const f
     HCG_CHECK_LAUNCH();
   }
   return HCG_OK;
+}
+
+extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
+                                   const float* x, const float* W, const int64_t* edge_index, int64_t E,
+                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
+                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
+                                   void* workspace, size_t workspace_bytes, hcg_stream_t stream) {
+  return launch_fused_bwd(dout, demb, emb, out, nullptr, x, W, edge_index, E, graph_ptr, edge_ptr, N, B, F, D,
+                          graphs_per_tile, slope, apply_act, dx, status, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// pooled backward of a layer whose forward ran in the training form (poolbits instead of out / emb)
+extern "C" int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* poolbits, const float* x, const float* W,
+                                            const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
+                                            const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
+                                            int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
+                                            void* workspace, size_t workspace_bytes, hcg_stream_t stream) {
+  if (!poolbits || !demb) return HCG_ERR_INVALID_ARG;
+  return launch_fused_bwd(nullptr, demb, nullptr, nullptr, poolbits, x, W, edge_index, E, graph_ptr, edge_ptr, N, B, F, D,
+                          graphs_per_tile, slope, apply_act, dx, status, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // second stage of the backward: dW[D, F], db[D] <- the per-workgroup slabs left in `workspace` by

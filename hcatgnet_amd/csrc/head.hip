@@ -61,13 +61,19 @@ struct HeadLds {
 // A workgroup publishes its slot, then wave 0 polls all slots until every stamp is current -- nobody can get past that
 // before every workgroup has read the generation, so workgroup 0 may advance it right afterwards.  Every workgroup
 // adds the same partials in the same lane order: the loss is bitwise reproducible.
-__device__ __forceinline__ float exchange_partials(int* sync, int nblk, int gen, float my_partial, float* bcast) {
+// Split in two so that work which does not need the sum can sit between them: publish_partial() right after the
+// forward, collect_partials() only where the sum is first needed.
+__device__ __forceinline__ void publish_partial(int* sync, int gen, float my_partial) {
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(sync + 2);
-  const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) {
     const unsigned long long v = ((unsigned long long)(unsigned)(gen + 1) << 32) | (unsigned long long)__float_as_uint(my_partial);
     __hip_atomic_store(&slots[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__device__ __forceinline__ float collect_partials(int* sync, int nblk, int gen, float* bcast) {
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(sync + 2);
+  const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
     float s = 0.f;
     bool done;
@@ -246,24 +252,32 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   const float block_sse = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
   HSTAMP(3);
 
-  // ---------------------------------------------------------------- grid-wide: every workgroup gets the batch's squared error
-  const float total_sse = exchange_partials(sync, nblk, gen, block_sse, L.bcast);
-  HSTAMP(4);
-
-  // ---------------------------------------------------------------- phase 2: loss, dout, backward
-  if (threadIdx.x == 0) {
-    const float mse = total_sse / ((float)B * (float)C);
-    const float lv = rmse ? sqrtf(mse) : mse;
-    L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
-    if (blockIdx.x == 0) {
-      loss[0] = lv;
-      loss[1] = mse;
-      if (step_counter) step_counter[0] += 1;          // this training step's number, for the update launched later
+  // ---------------------------------------------------------------- grid-wide: every workgroup needs the batch's squared error
+  // -- but only as ONE scalar factor of a backward that is linear in it (dloss/dout = gscale * diff).  The partial is
+  // published here, the backward below runs on the unscaled diff while the other workgroups' partials arrive, and the
+  // sum is collected where the first result leaves the chip (demb); the weight-gradient sums are scaled once at the end.
+  publish_partial(sync, gen, block_sse);
+  float gscale = 0.f;
+  bool have_scale = false;
+  auto collect = [&]() {                               // block-uniform; every workgroup runs it exactly once
+    const float total_sse = collect_partials(sync, nblk, gen, L.bcast);
+    HSTAMP(4);
+    if (threadIdx.x == 0) {
+      const float mse = total_sse / ((float)B * (float)C);
+      const float lv = rmse ? sqrtf(mse) : mse;
+      L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
+      if (blockIdx.x == 0) {
+        loss[0] = lv;
+        loss[1] = mse;
+        if (step_counter) step_counter[0] += 1;        // this training step's number, for the update launched later
+      }
     }
-  }
-  __syncthreads();
-  const float gscale = L.bcast[0];
+    __syncthreads();
+    gscale = L.bcast[0];
+    have_scale = true;
+  };
 
+  // ---------------------------------------------------------------- phase 2: backward (unscaled), loss, scale
   const int q = lane & 15, r4 = lane >> 4;
   const int cb = wave;                                 // backward: this wave's 32-column block of the 128-wide embedding
   f32x16 dw0[2];
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
 #pragma unroll
         for (int c = 0; c < RCMAX; ++c) {
           if (c < C) {
-            const float go = gscale * L.diff[row][c];
+            const float go = L.diff[row][c];                  // (unscaled: see above)
             const float4 w = *reinterpret_cast<const float4*>(L.w1 + c * RD + 4 * q);
             d.x += go * w.x; d.y += go * w.y; d.z += go * w.z; d.w += go * w.w;
             dw1[c].x += go * zz.x; dw1[c].y += go * zz.y; dw1[c].z += go * zz.z; dw1[c].w += go * zz.w;
@@ -347,12 +361,14 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     }
     mfma_results_fence(de);
     HSTAMP(6);
+    if (!have_scale) collect();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = krow(i, h);
-      if (row < n) demb[(size_t)(g0 + row) * RK + cb * 32 + r] = de[i];
+      if (row < n) demb[(size_t)(g0 + row) * RK + cb * 32 + r] = gscale * de[i];
     }
   }
+  if (!have_scale) collect();                          // (a workgroup without a tile still takes part in the exchange)
 
   // ---------------------------------------------------------------- one slab per workgroup
   float* slab = slabs + (size_t)blockIdx.x * SLAB;
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) slab[(mb * 32 + krow(i, h)) * RK + cb * 32 + r] = dw0[mb][i];
+    for (int i = 0; i < 16; ++i) slab[(mb * 32 + krow(i, h)) * RK + cb * 32 + r] = gscale * dw0[mb][i];
   // db0 / dW1 / db1: thread (rowgroup = threadIdx >> 4, q) holds partial sums for columns 4q..4q+3; combine the four
   // row groups of a wave by shuffles, the four waves through LDS -- all in a fixed order
   auto fold = [](float4 v) {
@@ -378,18 +394,23 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     if (r4 == 0) *reinterpret_cast<float4*>(mine + 4 * q) = db0;
 #pragma unroll
     for (int c = 0; c < RCMAX; ++c) {
-      const float4 v = fold(dw1[c]);
-      if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
-      float sc = db1[c];                               // lanes with q == 0 hold the partial sums (4 of them)
-      sc += __shfl_xor(sc, 16, 64);
-      sc += __shfl_xor(sc, 32, 64);
-      if (lane == 0) mine[RD + RCMAX * RD + c] = sc;
+      if (c < C) {                                     // block-uniform: classes the model does not have cost no shuffles
+        const float4 v = fold(dw1[c]);
+        if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
+        float sc = db1[c];                             // lanes with q == 0 hold the partial sums (4 of them)
+        sc += __shfl_xor(sc, 16, 64);
+        sc += __shfl_xor(sc, 32, 64);
+        if (lane == 0) mine[RD + RCMAX * RD + c] = sc;
+      } else {
+        if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) mine[RD + RCMAX * RD + c] = 0.f;
+      }
     }
   }
   __syncthreads();
   HSTAMP(7);
   for (int idx = threadIdx.x; idx < SMALL; idx += HW * 64)
-    slab[RD * RK + idx] = ((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx];
+    slab[RD * RK + idx] = gscale * (((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx]);
 }
 
 int head_grid(int64_t B) {

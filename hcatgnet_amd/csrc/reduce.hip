@@ -52,6 +52,27 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
     adam_c[0] = A.lr_dev[0] / (float)(1.0 - hcg_powi((double)A.b1, t));
     adam_c[1] = (float)sqrt(1.0 - hcg_powi((double)A.b2, t));
   }
+  // where this output element goes (threads of slice 0 only), and -- fused update -- its parameter and moments,
+  // requested BEFORE the slab loop: the update then waits on nothing but the sum
+  float* gdst = nullptr;
+  size_t off = 0;
+  float m0 = 0.f, v0 = 0.f, p0 = 0.f;
+  if (sl == 0 && idx < J.slab_floats) {
+    for (int g = 0; g < J.nseg; ++g) {
+      const hcg_reduce_seg& S = J.seg[g];
+      const int rel = idx - S.begin;
+      if (rel >= 0 && rel < S.count) {
+        const int rr = rel / S.row_in, cc = rel - rr * S.row_in;
+        if (cc < S.row_out) gdst = S.dst + (size_t)rr * S.row_out + cc;
+      }
+    }
+    if (ADAM && gdst) {
+      off = (size_t)(gdst - A.grad_flat);
+      m0 = A.m[off];
+      v0 = A.v[off];
+      p0 = A.p[off];
+    }
+  }
   float s = 0.f;
   if (idx < J.slab_floats) {
 #pragma unroll 8
@@ -59,28 +80,17 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
   }
   part[sl][o] = s;
   __syncthreads();
-  if (sl == 0 && idx < J.slab_floats) {
+  if (gdst) {
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < RS; ++k) tot += part[k][o];
-    for (int g = 0; g < J.nseg; ++g) {
-      const hcg_reduce_seg& S = J.seg[g];
-      const int rel = idx - S.begin;
-      if (rel >= 0 && rel < S.count) {
-        const int rr = rel / S.row_in, cc = rel - rr * S.row_in;
-        if (cc < S.row_out) {
-          float* gdst = S.dst + (size_t)rr * S.row_out + cc;
-          *gdst = tot;
-          if (ADAM) {
-            const size_t off = (size_t)(gdst - A.grad_flat);
-            const float mi = A.b1 * A.m[off] + (1.0f - A.b1) * tot;
-            const float vi = A.b2 * A.v[off] + (1.0f - A.b2) * tot * tot;
-            A.m[off] = mi;
-            A.v[off] = vi;
-            A.p[off] -= adam_c[0] * (mi / (sqrtf(vi) / adam_c[1] + A.eps));
-          }
-        }
-      }
+    *gdst = tot;
+    if (ADAM) {
+      const float mi = A.b1 * m0 + (1.0f - A.b1) * tot;
+      const float vi = A.b2 * v0 + (1.0f - A.b2) * tot * tot;
+      A.m[off] = mi;
+      A.v[off] = vi;
+      A.p[off] = p0 - adam_c[0] * (mi / (sqrtf(vi) / adam_c[1] + A.eps));
     }
   }
 }

@@ -24,6 +24,7 @@ the autograd path with the same arithmetic contract.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -32,6 +33,12 @@ from . import _lib
 from . import functional as HF
 
 _SYNC_WORDS = {}
+
+
+# development switches (A/B measurements only): HCG_NO_POOLBITS=1 stores the pooled layer's activations as the plain
+# forms do, HCG_NO_PREMASK=1 leaves every activation derivative to the layer that owns it
+_POOLBITS = os.environ.get("HCG_NO_POOLBITS", "0") != "1"
+_PREMASK = os.environ.get("HCG_NO_PREMASK", "0") != "1"
 
 
 def _sync_words(dev: torch.device) -> torch.Tensor:
@@ -173,17 +180,34 @@ class FusedTrainStep:
         p = _lib.ptr
         W = [HF._f32c(c.lin.weight) for c in convs]
         bs = [HF._f32c(c.bias) for c in convs]
-        # ---- forward (conv stack + pooling)
-        if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
+        # ---- forward (conv stack + pooling).  Small-graph tiles: the pooled layer's activations stay on chip, two bits
+        #      per element (sign, is-the-column-max) are all its backward needs of them
+        poolbits = None
+        if gpts[-1] > 0 and _POOLBITS:
+            nb = lib.hcg_fused_poolbits_bytes(B, gpts[-1])
+            poolbits = bufs["ws"].get("poolbits")
+            if poolbits is None or poolbits.numel() < nb:
+                poolbits = bufs["ws"]["poolbits"] = torch.empty(int(nb * 1.25), dtype=torch.uint8, device=dev)
+        if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0 and poolbits is None:
             rc = lib.hcg_fused_stack2_fwd(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
                                           p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1, p(acts[0]),
                                           p(acts[1]), p(emb), p(plan.status), stream)
             _lib.check(rc, "hcg_fused_stack2_fwd")
+        elif n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
+            rc = lib.hcg_fused_stack2_fwd_train(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
+                                                p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1,
+                                                p(acts[0]), p(emb), p(poolbits), p(plan.status), stream)
+            _lib.check(rc, "hcg_fused_stack2_fwd_train")
         else:
             h = x
             for l in range(n_conv):
                 pe = p(emb) if l == n_conv - 1 else None
-                if gpts[l] > 0:
+                if gpts[l] > 0 and pe is not None and poolbits is not None:
+                    rc = lib.hcg_fused_layer_fwd_train(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                                       p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, pe,
+                                                       p(poolbits), p(plan.status), stream)
+                    _lib.check(rc, "hcg_fused_layer_fwd_train")
+                elif gpts[l] > 0:
                     rc = lib.hcg_fused_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                                  p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]), pe,
                                                  p(plan.status), stream)
@@ -238,9 +262,17 @@ class FusedTrainStep:
                 bufs["ws"][l] = ws
             last = l == n_conv - 1
             up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
-            if small:
+            if small and last and poolbits is not None:
+                premasked = _PREMASK and l > 0 and gpts[l - 1] > 0
+                rc = lib.hcg_fused_layer_bwd_poolbits(p(bufs["demb"]), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E,
+                                                      p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
+                                                      1 | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
+                _lib.check(rc, "hcg_fused_layer_bwd_poolbits")
+                _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
+                                                    g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
+            elif small:
                 act = 0 if premasked else 1
-                premasked = l > 0 and gpts[l - 1] > 0
+                premasked = _PREMASK and l > 0 and gpts[l - 1] > 0
                 rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
                                              plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
                                              act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)

@@ -190,6 +190,33 @@ int hcg_fused_layer_bwd(const float* dout /*nullable*/, const float* demb, const
 int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B,
                            int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
                            hcg_stream_t stream);
+/* Training forms of the POOLED (last) conv layer: its node activations never reach HBM.  All the pooled backward needs
+ * of them is, per element, the sign (LeakyReLU') and whether it is its graph's column maximum (torch amax backward:
+ * ties share the gradient evenly) -- they leave as two bits per element, `poolbits` (hcg_fused_poolbits_bytes: 512 B per
+ * 32-row tile, in the matrix-core accumulator layout), and hcg_fused_layer_bwd_poolbits over the SAME plan and
+ * graphs_per_tile reads them in place of `out` and `emb`.  emb is required; everything else as in the plain forms
+ * (apply_act bit 1 of the backward = premasked dx, see hcg_fused_layer_bwd).  Gradients equal the plain forms' up to
+ * the summation order of db. */
+size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile);
+int hcg_fused_layer_fwd_train(const float* x, const float* W, const float* b,
+                              const int64_t* edge_index, int64_t E,
+                              const int32_t* graph_ptr, const int32_t* edge_ptr,
+                              int64_t N, int64_t B, int64_t F, int64_t D,
+                              int graphs_per_tile, float slope, int apply_act,
+                              float* emb, uint32_t* poolbits, int32_t* status, hcg_stream_t stream);
+int hcg_fused_stack2_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                               const int64_t* edge_index, int64_t E,
+                               const int32_t* graph_ptr, const int32_t* edge_ptr,
+                               int64_t N, int64_t B, int64_t F, int64_t D,
+                               int graphs_per_tile, float slope, int apply_act,
+                               float* out1, float* emb, uint32_t* poolbits, int32_t* status, hcg_stream_t stream);
+int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* poolbits, const float* x, const float* W,
+                                 const int64_t* edge_index, int64_t E,
+                                 const int32_t* graph_ptr, const int32_t* edge_ptr,
+                                 int64_t N, int64_t B, int64_t F, int64_t D,
+                                 int graphs_per_tile, float slope, int apply_act,
+                                 float* dx /*nullable*/, int32_t* status,
+                                 void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
 /* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 224 nodes and <= 1024
  * directed edges per graph, D = 64 or 128 (two 64-column halves, one launch each), F <= 128 (contracted in chunks of 64)

@@ -335,3 +335,60 @@ def test_fused_backward_hands_down_a_premasked_dx(H, feat, pooled):
     assert lib.hcg_fused_layer_bwd(p(dx), None, None, None, p(x), p(W), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                    p(plan.edge_ptr), N, B, feat, D, gpt, slope, 1, None, p(plan.status),
                                    p(torch.empty(wsb, dtype=torch.uint8, device="cuda")), wsb, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("nodes,feat,ties", [(30, 64, False), (10, 64, False), (30, 25, False), (7, 64, True), (30, 64, True)])
+def test_training_forms_keep_the_pooled_layer_on_chip(H, nodes, feat, ties):
+    """hcg_fused_*_fwd_train + hcg_fused_layer_bwd_poolbits: the pooled layer's activations are replaced by two bits per
+    element.  Same arithmetic per element as the plain forms -> emb, out1, dW, dx bitwise equal; db is summed in another
+    (fixed) order.  `ties`: W2 = 0 makes every node of a graph the column maximum (gradient split n ways)."""
+    from hcatgnet_amd import synth, _lib
+    from hcatgnet_amd import functional as HF
+    from hcatgnet_amd.plan import BatchPlan
+    lib, p = _lib.load(), _lib.ptr
+    sb = synth.make_config("C2", num_graphs=203, nodes=nodes, seed=3)
+    b = sb.as_batch("cuda")
+    plan = BatchPlan.build(b.edge_index, b.batch, b.x.shape[0], num_graphs=b.num_graphs, mode="blocked",
+                           max_nodes=sb.max_nodes, max_edges=sb.max_edges)
+    N, B, D, slope = plan.N, plan.B, 64, 0.01
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda()
+    x = b.x[:, :feat].contiguous()
+    W1, b1, W2, b2 = rnd(D, feat) * 0.2, rnd(D) * 0.1, rnd(D, D) * (0.0 if ties else 0.2), rnd(D) * 0.1
+    gpt = HF.fused_graphs_per_tile(plan, feat, D)
+    assert gpt == 32 // nodes
+    st, geo = _lib.stream_ptr(), (p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B)
+    new = lambda *s: torch.full(s, float("nan"), device="cuda")
+    out1, out2, emb = new(N, D), new(N, D), new(B, 2 * D)
+    _lib.check(lib.hcg_fused_stack2_fwd(p(x), p(W1), p(b1), p(W2), p(b2), *geo, feat, D, gpt, slope, 1, p(out1), p(out2), p(emb),
+                                        p(plan.status), st), "stack2")
+    bits = torch.zeros(lib.hcg_fused_poolbits_bytes(B, gpt), dtype=torch.uint8, device="cuda")
+    out1t, embt = new(N, D), new(B, 2 * D)
+    _lib.check(lib.hcg_fused_stack2_fwd_train(p(x), p(W1), p(b1), p(W2), p(b2), *geo, feat, D, gpt, slope, 1, p(out1t), p(embt),
+                                              p(bits), p(plan.status), st), "stack2 train")
+    assert torch.equal(out1, out1t) and torch.equal(emb, embt)
+    # single pooled layer on its own (the form a stack of != 2 layers ends with): same bits, same emb
+    bits1, emb1 = torch.zeros_like(bits), new(B, 2 * D)
+    _lib.check(lib.hcg_fused_layer_fwd_train(p(out1), p(W2), p(b2), *geo, D, D, gpt, slope, 1, p(emb1), p(bits1), p(plan.status),
+                                             st), "layer train")
+    assert torch.equal(emb1, emb) and torch.equal(bits1, bits)
+
+    demb = rnd(B, 2 * D)
+    wsb = lib.hcg_fused_workspace_bytes(B, D, D, gpt)
+
+    def run(fn, *lead):
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        dx, dW, db = new(N, D), new(D, D), new(D)
+        _lib.check(fn(*lead, p(out1), p(W2), *geo, D, D, gpt, slope, 3, p(dx), p(plan.status), p(ws), wsb, st), "bwd")
+        _lib.check(lib.hcg_fused_reduce_grads(p(ws), wsb, N, B, D, D, gpt, p(dW), p(db), st), "reduce")
+        return dx, dW, db
+
+    dx, dW, db = run(lib.hcg_fused_layer_bwd, None, p(demb), p(emb), p(out2))
+    dxt, dWt, dbt = run(lib.hcg_fused_layer_bwd_poolbits, p(demb), p(bits))
+    assert torch.equal(dx, dxt) and torch.equal(dW, dWt)
+    assert rel_inf(dbt, db) <= 1e-6
+    if ties:        # every node shares the max: db of the max half = sum_g demb_max[g] (n_g shares of 1/n_g each)
+        lk = torch.where(emb[0, :D] > 0, 1.0, slope)
+        want = (demb[:, :D].sum(0) + demb[:, D:].sum(0)) * lk
+        assert rel_inf(dbt, want) <= 1e-5
+    assert int(plan.status[0]) == 0

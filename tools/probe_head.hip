@@ -24,10 +24,13 @@ int main() {
 #ifdef HCG_HEAD_STAMP
   unsigned long long st[256];
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_head_stamp), sizeof(st)));
-  const char* names[] = {"loads+W->LDS+emb", "fwd MFMA", "z/out/sse", "exchange", "dz", "bwd MFMA", "demb+dw0 store+fold"};
+  // stamps in program order: 0 start, 1 tile staged, 2 forward MFMA, 3 squared error (partial published right after),
+  // 5 dz, 6 backward MFMA, 4 sum collected (the exchange wait ends), 7 sums folded
+  const char* names[] = {"loads+W->LDS+emb", "fwd MFMA", "z/out/sse", "dz", "bwd MFMA", "wait for the sum", "scale+stores+fold"};
+  const int order[] = {0, 1, 2, 3, 5, 6, 4, 7};
   for (int b : {0, 1, 7, 15}) {
     printf("block %2d:", b);
-    for (int i = 0; i < 7; ++i) printf(" %s %llu |", names[i], st[b * 16 + i + 1] - st[b * 16 + i]);
+    for (int i = 0; i < 7; ++i) printf(" %s %llu |", names[i], st[b * 16 + order[i + 1]] - st[b * 16 + order[i]]);
     printf(" total %llu\n", st[b * 16 + 7] - st[b * 16]);
   }
   unsigned long long mn = ~0ull, mx = 0;
