@@ -392,3 +392,50 @@ def test_training_forms_keep_the_pooled_layer_on_chip(H, nodes, feat, ties):
         want = (demb[:, :D].sum(0) + demb[:, D:].sum(0)) * lk
         assert rel_inf(dbt, want) <= 1e-5
     assert int(plan.status[0]) == 0
+
+
+@pytest.mark.parametrize("seed,n_conv", [(0, 2), (1, 2), (2, 2), (3, 2), (4, 1), (5, 3), (6, 3), (7, 1)])
+def test_fused_train_step_random_batches(H, oracle, seed, n_conv):
+    """Randomised sweep of the no-autograd step (on-chip pooled layer, premasked dx, one-launch head): random graph
+    sizes (1..32 nodes, empty graph slots, several graphs per tile on even seeds), random multigraph edges (self loops,
+    duplicates, one direction only, isolated nodes), random F, 1-3 conv layers, 1-3 targets -- every gradient vs the
+    oracle's autograd."""
+    from hcatgnet_amd.train import FusedTrainStep
+    g = torch.Generator().manual_seed(300 + seed)
+    B = int(torch.randint(1, 90, (1,), generator=g))
+    feat = int(torch.randint(7, 65, (1,), generator=g))
+    C = 1 + seed % 3
+    sizes = torch.randint(0, 33, (B,), generator=g)
+    if seed % 2 == 0:
+        sizes = sizes.clamp(max=10)
+    sizes[int(torch.randint(0, B, (1,), generator=g))] = max(1, int(sizes.max()))
+    xs, eis, bs, off, max_e = [], [], [], 0, 0
+    for gi, n in enumerate(sizes.tolist()):
+        if n == 0:
+            continue
+        xs.append(torch.randn(n, feat, generator=g))
+        bs.append(torch.full((n,), gi, dtype=torch.int64))
+        ne = int(torch.randint(0, 3 * n + 1, (1,), generator=g))
+        if ne:
+            eis.append(torch.randint(0, n, (2, ne), generator=g) + off)
+        max_e = max(max_e, ne)
+        off += n
+    x, b = torch.cat(xs), torch.cat(bs)
+    ei = torch.cat(eis, 1) if eis else torch.zeros(2, 0, dtype=torch.int64)
+    y = torch.randn(B, C, generator=g)
+    params = _rand_params(feat, 64, n_conv=n_conv, n_classes=C, seed=400 + seed)
+    m = _model_from_params(H, params)
+    batch = H.Batch(x.cuda(), ei.cuda(), b.cuda(), B, y=y.cuda(), max_nodes=int(sizes.max()), max_edges=max_e, edges_grouped=True)
+    step = FusedTrainStep(m, optimizer_step=False)
+    assert step.unsupported_reason(m, batch) is None
+    loss = step(batch)
+    assert batch._hcg_plan.check_status() == 0
+    # oracle autograd on the same restatement the other parity tests use (targets with C columns)
+    p64 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o_out = oracle.gcn_forward(p64, x, ei, b, B)[0]
+    o_loss = torch.sqrt(F.mse_loss(o_out, y))
+    o_loss.backward()
+    assert abs(float(loss) - float(o_loss.detach())) <= TOL * max(1.0, abs(float(o_loss.detach())))
+    assert rel_inf(step.last_out, o_out.detach(), floor=1.0) <= TOL
+    for k, v in m.named_parameters():
+        assert rel_inf(v.grad, p64[k].grad) <= 2 * TOL, k
