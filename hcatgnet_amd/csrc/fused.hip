@@ -62,6 +62,16 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP_FLUSH() do { } while (0)
 #define STAMP(idx) do { } while (0)
 #endif
+// the backward's stamps (same buffer): only with -DHCG_STAMP -DHCG_STAMP_BWD, and the probe then runs a backward last
+#if defined(HCG_STAMP) && defined(HCG_STAMP_BWD)
+#define BSTAMP_DECL STAMP_DECL
+#define BSTAMP(idx) STAMP(idx)
+#define BSTAMP_FLUSH() STAMP_FLUSH()
+#else
+#define BSTAMP_DECL
+#define BSTAMP(idx) do { } while (0)
+#define BSTAMP_FLUSH() do { } while (0)
+#endif
 
 namespace {
 
@@ -534,6 +544,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   __shared__ WaveLdsB lds[WAVES];
   // dx operand: image row f, column d <- W[d][f], three bf16 planes, shared by the 8 waves
   __shared__ __attribute__((aligned(16))) short wtl[NEEDS_DX ? 3 * KPAD * (DD + WPAD) : 8];
+  BSTAMP_DECL
+  int bstamp_it = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveLdsB& L = lds[wave];
@@ -583,9 +595,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int i = 0; i < 16; ++i) dw[mb][nb][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbl0 = 0.f, dbl1 = 0.f;   // BITS: column r / 32 + r of db (this lane's half of the rows)
+  BSTAMP(0);
 
   while (have) {
     te.build(L.cnt, L.ldinv, L.lgp, ti, ei, E, lane, status);
+    BSTAMP(1 + 8 * bstamp_it);
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> buf (rows >= n zero); A / dA stay in registers
     float4 dy[TM / 4];
@@ -602,6 +616,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
         if (ge <= gb) continue;
         const float* de = demb + (size_t)g * 2 * DD;
         const float cntf = (float)(ge - gb);
+        // (requesting these four ahead of the count build was measured: 12 spilled registers, +1.8 us)
         const float dmx0 = de[r], dmx1 = de[32 + r], dme0 = de[DD + r] / cntf, dme1 = de[DD + 32 + r] / cntf;
         uint32_t rows = 0;
 #pragma unroll
@@ -682,6 +697,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     }
     }
 
+    BSTAMP(2 + 8 * bstamp_it);
     // next tile of this wave: scalars one tile further ahead (the row loads wait until the accumulators leave room:
     // measured with the loads here, the dx / pooled variants spill 24-89 VGPRs and run 20-30 % SLOWER)
     const int tn = t + stride;
@@ -726,10 +742,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       for (int i = 0; i < 16; ++i) { dh0[i] *= dvr[i]; dh1[i] *= dvr[i]; }
     }
 
+    BSTAMP(3 + 8 * bstamp_it);
     // ---- 3. x tile -> buf ; dW += dH^T x.  A operand = the dH accumulators (slot j of k-step s <-> node krow(8s + j, h)),
     //         B[k = node][f] read down the columns of the x tile
     if (!EARLY_X) sx.load(x, F, N, ti.nbase, ti.n, lane);
     sx.write(L.buf, F, ti.n, lane);
+    BSTAMP(4 + 8 * bstamp_it);
     // premask, wide rows: bit 4 it + c <-> x[row it*4 + r4][4 q + c] > 0 -- one register carried to the dx stores
     // instead of the rows (measured against bits taken in the accumulator layout inside the dW loop: those spill)
     uint32_t xpos = 0;
@@ -761,6 +779,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       }
     }
 
+    BSTAMP(5 + 8 * bstamp_it);
     // ---- 4. dx = dH W: dH -> buf as [node][d] (the contraction runs over the accumulator's LANE
     //         dimension, so this one needs the LDS transpose), B[k = d][j = f] = W[d][f] from the pre-split image
     if (NEEDS_DX) {
@@ -791,6 +810,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       }
 #pragma unroll
       for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
+      BSTAMP(6 + 8 * bstamp_it);
       if (VEC) {   // F == KPAD: rows are whole float4 groups -> transpose through LDS, dwordx4 stores
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -844,6 +864,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       }
     }
 
+    BSTAMP(7 + 8 * bstamp_it);
     have = have_next;
     if (have_next) {
       tin = tile_finish(raw_cur, gpt, lane, status);
@@ -861,7 +882,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
       if (!POOLG) sd = sdn;
       te = ten;
     }
+    BSTAMP(8 + 8 * bstamp_it);
+    if (bstamp_it < 5) ++bstamp_it;
   }
+  BSTAMP(60);
 
   // ---- combine the waves of this workgroup (fixed order, two rounds of four waves through a flat
   //      view of the LDS) and publish one partial slab
@@ -910,6 +934,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const int idx = threadIdx.x + j * WAVES * 64;
     if (idx < SLABF) slab[idx] = tot[j];
   }
+  BSTAMP(63);
+  BSTAMP_FLUSH();
 }
 
 // dW[d][f] = sum_b slab[b][d*KPAD + f],  db[d] = sum_b slab[b][64*KPAD + d]   (fixed order over b)

@@ -84,6 +84,34 @@ int main() {
 #ifndef HCG_STAMP
   return 0;
 #endif
+#ifdef HCG_STAMP_BWD
+  {  // the product's layer-2 backward (bit form, premasked dx) LAST: its stamps are the ones in the buffer
+    float *ddx, *dws; CK(hipMalloc(&ddx, (size_t)N * F * 4));
+    uint32_t* bits; CK(hipMalloc(&bits, hcg_fused_poolbits_bytes(B, 1))); CK(hipMemset(bits, 0x55, hcg_fused_poolbits_bytes(B, 1)));
+    size_t wsb = hcg_fused_workspace_bytes(B, F, D, 1); CK(hipMalloc(&dws, wsb));
+    for (int it = 0; it < 25; ++it) {
+      if (it == 5) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
+      hcg_fused_layer_bwd_poolbits(demb, bits, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 1, 0.01f, 3, ddx, dstatus, dws, wsb, 0);
+    }
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("bwd layer 2, bit form + premask: %.2f us per launch\n", ms * 1000.f / 20);
+    std::vector<unsigned long long> sb(4 * WAVES * 64);
+    CK(hipMemcpy(sb.data(), dstamp, sb.size() * 8, hipMemcpyDeviceToHost));
+    const char* nm[] = {"count build", "dY'", "agg MFMA", "x staged", "dW MFMA", "dx GEMM", "dx stores", "next loads"};
+    for (int w : {0, 1, 8, 17}) {
+      const unsigned long long* s = sb.data() + (size_t)w * 64;
+      printf("wave %2d:", w);
+      for (int it = 0; it < 3 && s[1 + 8 * it]; ++it) {
+        printf(" tile%d:", it);
+        for (int k = 0; k < 8; ++k) printf(" %s %llu", nm[k], s[k + 1 + 8 * it] - (k == 0 ? (it == 0 ? s[0] : s[8 * it]) : s[k + 8 * it]));
+        printf(" |");
+      }
+      printf(" combine+slab %llu | total %llu\n", s[63] - s[60], s[63] - s[0]);
+    }
+    return 0;
+  }
+#endif
   std::vector<unsigned long long> st(4 * WAVES * 64);
   CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
   int status[4]; CK(hipMemcpy(status, dstatus, 16, hipMemcpyDeviceToHost)); printf("status %d\n", status[0]);
