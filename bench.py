@@ -44,7 +44,7 @@ def parse():
                     "REAL / REAL40 = the reference's own graph sizes (57-117 atoms, F = 25) at B = 4096 / 40")
     ap.add_argument("--num-graphs", type=int, default=None, help="override graphs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=60)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
