@@ -401,6 +401,11 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   constexpr int ld = DD + WPAD, plane = KPAD * ld;
   constexpr int FPAD = NFC * KPAD;                    // padded input width of the slab rows
   const int c4 = tid & 15, rg = tid >> 4;             // step 1: this thread's float4 column group / row group
+  // apply_act bits as in hcg_fused_layer_bwd: bit 0 = multiply the upstream gradient by leaky'(a_out); bit 1 = hand dx
+  // down already multiplied by leaky'(x) (the x chunk sits in t0 when dx is stored), so the layer below runs with bit 0
+  // clear and never reads its own output
+  const bool act_here = apply_act & 1, premask = NEEDS_DX && (apply_act & 2);
+  const bool need_a = POOLG || act_here;
 
   if (NEEDS_DX && NFC == 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
   __syncthreads();
@@ -435,13 +440,13 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
     //         this thread's rows (row group rg, float4 column group c4): all global loads first, used by both passes
     constexpr int NR = MID_MAX_NODES / (MT / 16);
-    float4 av[NR], dv[NR];
+    float4 av[NR] = {}, dv[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int row = rg + j * (MT / 16);
       if (j * (MT / 16) < rows) {                          // block-uniform
         const size_t at = (size_t)(gi.nbase + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * ldo + coff + 4 * c4;
-        av[j] = *reinterpret_cast<const float4*>(a_out + at);
+        if (need_a) av[j] = *reinterpret_cast<const float4*>(a_out + at);   // (kernel-uniform)
         if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(dout + at);
       }
     }
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
           } else {
             d = dv[j];
           }
-          if (apply_act) {
+          if (act_here) {
             d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
             d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
           }
@@ -574,7 +579,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
                 const int f = fc * KPAD + nb * 32 + r;
                 if (f < F) {
                   float* dst = dx + (size_t)(gi.nbase + row) * F + f;
-                  *dst = acc_dx ? *dst + dxa[nb][i] : dxa[nb][i];
+                  const float v = premask ? dxa[nb][i] * hcg_leaky_grad(L.t0[row * HS + nb * 32 + r], slope) : dxa[nb][i];
+                  *dst = acc_dx ? *dst + v : v;
                 }
               }
             }
@@ -717,10 +723,12 @@ extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const flo
                                  size_t workspace_bytes, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
-  if (N <= 0 || B <= 0 || E < 0 || !W || !workspace || !out || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index))
+  if (N <= 0 || B <= 0 || E < 0 || !W || !workspace || !x || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index))
     return HCG_ERR_INVALID_ARG;
   const bool poolg = (dout == nullptr);
   if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
+  if ((apply_act & ~3) || ((apply_act & 2) && !dx)) return HCG_ERR_INVALID_ARG;
+  if ((poolg || (apply_act & 1)) && !out) return HCG_ERR_INVALID_ARG;   // `out` is only read for leaky' and the pooled routing
   if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const int npad = pad32(max_nodes), emax = pad8(max_edges), fpad = mid_fpad(F);

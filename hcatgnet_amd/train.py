@@ -263,7 +263,7 @@ class FusedTrainStep:
             last = l == n_conv - 1
             up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
             if small and last and poolbits is not None:
-                premasked = _PREMASK and l > 0 and gpts[l - 1] > 0
+                premasked = _PREMASK and l > 0
                 rc = lib.hcg_fused_layer_bwd_poolbits(p(bufs["demb"]), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E,
                                                       p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
                                                       1 | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
@@ -272,7 +272,7 @@ class FusedTrainStep:
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
             elif small:
                 act = 0 if premasked else 1
-                premasked = _PREMASK and l > 0 and gpts[l - 1] > 0
+                premasked = _PREMASK and l > 0
                 rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
                                              plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
                                              act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
@@ -280,9 +280,11 @@ class FusedTrainStep:
                 _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
             else:
-                rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(dx), p(plan.status), p(ws),
-                                           wsb, stream)
+                act = 0 if premasked else 1
+                premasked = _PREMASK and l > 0
+                rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
+                                           plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope,
+                                           act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_mid_layer_bwd")
                 _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, 0, g(convs[l].lin.weight), g(convs[l].bias),
                                                   jaddr + njobs * jb), "hcg_mid_reduce_job")

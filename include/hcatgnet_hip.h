@@ -225,7 +225,8 @@ int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* poolbits, co
  * a BLOCKED plan, gcn_norm and the CSR rebuilt on chip per graph, unweighted edges, optional pooled epilogue /
  * pooled-gradient prologue, per-workgroup gradient slabs (hcg_mid_reduce_job + hcg_reduce_slabs).
  * `max_nodes` / `max_edges` = largest graph of the batch (host metadata; sizes the dynamic LDS); a graph that exceeds
- * them is skipped and flagged HCG_STATUS_SHAPE_LIMIT. */
+ * them is skipped and flagged HCG_STATUS_SHAPE_LIMIT.  apply_act of hcg_mid_layer_bwd is the same bit set as in
+ * hcg_fused_layer_bwd (bit 1 = premasked dx; `out` nullable when bit 0 is clear and dout is given). */
 int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph);
 size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges);
 int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,

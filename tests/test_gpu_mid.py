@@ -220,3 +220,58 @@ def test_mid_at_the_shape_limits(H, oracle):
     for mn, me in ((225, 1024), (224, 1025)):
         p2 = H.BatchPlan.build(batch.edge_index, batch.batch, n1 + n2, num_graphs=2, mode="blocked", max_nodes=mn, max_edges=me)
         assert not HF.mid_supported(p2, 32, 64)
+
+
+@pytest.mark.parametrize("D,feat", [(64, 64), (64, 25), (128, 128)])
+def test_mid_backward_hands_down_a_premasked_dx(H, D, feat):
+    """apply_act bit 1 of hcg_mid_layer_bwd (as hcg_fused_layer_bwd): dx leaves multiplied by LeakyReLU'(x); the layer
+    below then runs with bit 0 clear and out = NULL.  One f32 multiply moved across a launch boundary: bitwise the plain
+    sequence for D = 64; a 128-wide layer adds its two column halves into dx, so there (a + b) m vs a m + b m."""
+    import ctypes
+    from hcatgnet_amd import synth, _lib
+    from hcatgnet_amd.plan import BatchPlan
+    lib, p = _lib.load(), _lib.ptr
+    sb = synth.make_config("C2", num_graphs=70, nodes=90, seed=4)
+    b = sb.as_batch("cuda")
+    plan = BatchPlan.build(b.edge_index, b.batch, b.x.shape[0], num_graphs=b.num_graphs, mode="blocked",
+                           max_nodes=sb.max_nodes, max_edges=sb.max_edges)
+    N, B, slope, mxn, mxe = plan.N, plan.B, 0.01, sb.max_nodes, sb.max_edges
+    assert lib.hcg_mid_supported(feat, D, mxn, mxe)
+    gen = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=gen).cuda()
+    x, out, W, dout = rnd(N, feat), rnd(N, D), rnd(D, feat) * 0.2, rnd(N, D)
+    x[::5] = 0.0
+    st = _lib.stream_ptr()
+
+    def bwd(dout_, out_, x_, W_, F_, flags, want_dx=True):
+        wsb = lib.hcg_mid_workspace_bytes(B, F_, D, mxn, mxe)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
+        dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
+        _lib.check(lib.hcg_mid_layer_bwd(p(dout_), None, None, p(out_), p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                         p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
+                                         st), "hcg_mid_layer_bwd")
+        jb = lib.hcg_reduce_job_bytes()
+        jobs = ctypes.create_string_buffer(jb * 2)
+        for half in range(D // 64):
+            _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, F_, D, mxn, mxe, half, p(dW), p(db), ctypes.addressof(jobs) + half * jb),
+                       "hcg_mid_reduce_job")
+        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), D // 64, st), "hcg_reduce_slabs")
+        return dx, dW, db
+
+    dx, dW, db = bwd(dout, out, x, W, feat, 1)
+    dxm, dWm, dbm = bwd(dout, out, x, W, feat, 3)
+    assert torch.equal(dW, dWm) and torch.equal(db, dbm)
+    want = dx * torch.where(x > 0, 1.0, slope)
+    assert torch.equal(dxm, want) if D == 64 else rel_inf(dxm, want) <= 1e-6
+    if feat == D:     # the layer below takes the premasked gradient with bit 0 clear and no `out`
+        x0, W0 = rnd(N, 25), rnd(D, 25) * 0.2
+        _, dW_a, db_a = bwd(dx, x, x0, W0, 25, 1, want_dx=False)
+        _, dW_b, db_b = bwd(want, None, x0, W0, 25, 0, want_dx=False)
+        assert torch.equal(dW_a, dW_b) and torch.equal(db_a, db_b)
+    # misuse is refused: activation derivative asked for without `out`
+    wsb = lib.hcg_mid_workspace_bytes(B, feat, D, mxn, mxe)
+    assert lib.hcg_mid_layer_bwd(p(dout), None, None, None, p(x), p(W), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                 p(plan.edge_ptr), N, B, feat, D, mxn, mxe, slope, 1, None, p(plan.status),
+                                 p(torch.empty(wsb, dtype=torch.uint8, device="cuda")), wsb, st) != 0
+    assert int(plan.status[0]) == 0
