@@ -336,8 +336,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   }
 
   // weight operands: W [64][F] -> three bf16 planes in LDS, once per workgroup
-  stage_weight_split<false>(w1l, DD, KPAD, W, DD, F);
-  if (STACK2) stage_weight_split<false>(w2l, DD, DD, W2, DD, DD);
+  stage_weight_split<false, WAVES * 64, DD, KPAD>(w1l, W, DD, F);
+  if (STACK2) stage_weight_split<false, WAVES * 64, DD, DD>(w2l, W2, DD, DD);
   const float slope_eff = apply_act ? slope : 1.0f;
   float b0 = bias[r], b1 = bias[32 + r];
   float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   }
 
   if (NEEDS_DX) {
-    stage_weight_split<true>(wtl, KPAD, DD, W, DD, F);
+    stage_weight_split<true, WAVES * 64, KPAD, DD>(wtl, W, DD, F);
     __syncthreads();
   }
 

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
 
-  if (!MULTIK) stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F);    // one chunk: the weight image is loop invariant
+  if (!MULTIK) stage_weight_split<false, MT, DD, KPAD>(L.wl, W, DD, F);    // one chunk: the weight image is loop invariant
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
   __syncthreads();
 
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
           __syncthreads();                                           // every wave is done with the previous chunk
           stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
         }
-        stage_weight_split<false>(L.wl, DD, KPAD, W, DD, F, kc * KPAD);
+        stage_weight_split<false, MT, DD, KPAD>(L.wl, W, DD, F, kc * KPAD);
         __syncthreads();
         if (mb < gi.nblk) tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
       }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   const bool act_here = apply_act & 1, premask = NEEDS_DX && (apply_act & 2);
   const bool need_a = POOLG || act_here;
 
-  if (NEEDS_DX && NFC == 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F);   // image row f, column d <- W[d][f]
+  if (NEEDS_DX && NFC == 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F);   // image row f, column d <- W[d][f]
   __syncthreads();
 
   // dW: per f-chunk 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int fc = 0; fc < NFC; ++fc) {
       // ---- 3. x chunk -> t0 (and, chunked, the matching rows of the dx operand image)
       stage_graph_rows<KPAD, true>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
-      if (NEEDS_DX && NFC > 1) stage_weight_split<true>(L.wl, KPAD, DD, W, DD, F, fc * KPAD);
+      if (NEEDS_DX && NFC > 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F, fc * KPAD);
       __syncthreads();
 
       // ---- 4. dW[mbw][fc, nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns

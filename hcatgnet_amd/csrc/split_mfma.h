@@ -91,31 +91,47 @@ __device__ __forceinline__ void mfma_exact_a(f32x16& acc, const bf16x8& a, const
 // Block-cooperative (every thread of the workgroup takes part), coalesced global reads.
 //   TRANS = false: image row n, column k  <-  g[n * cols + k]   (B[k][n] = W[n][k]: the H = X W^T operand)
 //   TRANS = true : image row f, column d  <-  g[d * cols + f]   (B[d][f] = W[d][f]: the dX = dH W operand)
-// `rows_img` x `K` is the image extent (zero padded past the matrix), `g` is [grows][cols] row-major.
-template <bool TRANS>
-// `col0`: first column of `g` the image's column window (TRANS: row window) starts at (K-chunked operands).
-__device__ __forceinline__ void stage_weight_split(short* wl, int rows_img, int K, const float* __restrict__ g, int grows,
-                                                   int cols, int col0 = 0) {
-  const int ld = K + WPAD, plane = rows_img * ld;
-  const int total = TRANS ? grows * rows_img : rows_img * K;    // iterate in global-memory order where possible
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+// `ROWS` x `K` is the image extent (zero padded past the matrix), `g` is [grows][cols] row-major, `col0` the first
+// column of `g` the image's column window (TRANS: row window) starts at (K-chunked operands).
+// NT = threads of the workgroup, a compile-time constant so that the element loop unrolls completely and EVERY global
+// load is issued before the first LDS write: as a run-time loop hipcc emits load -> s_waitcnt vmcnt(0) -> 3 x
+// ds_write_b16 per element, i.e. 8 (two weights: 16) serialised memory round trips in the prologue of every workgroup.
+template <bool TRANS, int NT, int ROWS, int K>
+__device__ __forceinline__ void stage_weight_split(short* wl, const float* __restrict__ g, int grows, int cols, int col0 = 0) {
+  constexpr int ld = K + WPAD, plane = ROWS * ld;
+  constexpr int total = ROWS * K;            // TRANS: idx = d * ROWS + f (d < K = DD rows of g); else idx = n * K + k
+  static_assert(total % NT == 0, "image elements per thread");
+  constexpr int PER = total / NT;
+  float v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    if (TRANS) {
+      const int d = idx / ROWS, f = idx - d * ROWS;
+      v[j] = g[(size_t)(d < grows ? d : grows - 1) * cols + (col0 + f < cols ? col0 + f : cols - 1)];
+    } else {
+      const int n = idx / K, k = idx - n * K;
+      v[j] = g[(size_t)(n < grows ? n : grows - 1) * cols + (col0 + k < cols ? col0 + k : cols - 1)];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = threadIdx.x + j * NT;
     int ir, ic;       // image row / column
-    float v;
-    if (TRANS) {      // idx = d * rows_img + f
-      const int d = idx / rows_img, f = idx - d * rows_img;
-      v = g[(size_t)d * cols + (col0 + f < cols ? col0 + f : cols - 1)];
-      if (col0 + f >= cols) v = 0.f;
+    float x = v[j];
+    if (TRANS) {
+      const int d = idx / ROWS, f = idx - d * ROWS;
+      if (col0 + f >= cols || d >= grows) x = 0.f;
       ir = f;
       ic = d;
-    } else {          // idx = n * K + k
+    } else {
       const int n = idx / K, k = idx - n * K;
-      v = g[(size_t)(n < grows ? n : grows - 1) * cols + (col0 + k < cols ? col0 + k : cols - 1)];
-      if (col0 + k >= cols || n >= grows) v = 0.f;
+      if (col0 + k >= cols || n >= grows) x = 0.f;
       ir = n;
       ic = k;
     }
-    const unsigned u1 = pk_bf16(v, 0.f) & 0xffffu;
-    const float r1 = v - __uint_as_float(u1 << 16);
+    const unsigned u1 = pk_bf16(x, 0.f) & 0xffffu;
+    const float r1 = x - __uint_as_float(u1 << 16);
     const unsigned u2 = pk_bf16(r1, 0.f) & 0xffffu;
     const float r2 = r1 - __uint_as_float(u2 << 16);
     const unsigned u3 = pk_bf16(r2, 0.f) & 0xffffu;
