@@ -336,11 +336,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   }
 
   // weight operands: W [64][F] -> three bf16 planes in LDS, once per workgroup
+  // (bias loads first: behind the staging they were one more memory round trip in front of the first tile)
+  float b0 = bias[r], b1 = bias[32 + r];
+  float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
   stage_weight_split<false, WAVES * 64, DD, KPAD>(w1l, W, DD, F);
   if (STACK2) stage_weight_split<false, WAVES * 64, DD, DD>(w2l, W2, DD, DD);
   const float slope_eff = apply_act ? slope : 1.0f;
-  float b0 = bias[r], b1 = bias[32 + r];
-  float c0 = STACK2 ? bias2[r] : 0.f, c1 = STACK2 ? bias2[32 + r] : 0.f;
   // retire the bias loads HERE: left pending, their first use (in the epilogue of the tile loop) makes
   // hipcc wait on the vector-memory counter there, which also drains the next-tile prefetch
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));

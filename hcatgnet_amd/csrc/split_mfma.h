@@ -108,10 +108,10 @@ __device__ __forceinline__ void stage_weight_split(short* wl, const float* __res
     const int idx = threadIdx.x + j * NT;
     if (TRANS) {
       const int d = idx / ROWS, f = idx - d * ROWS;
-      v[j] = g[(size_t)(d < grows ? d : grows - 1) * cols + (col0 + f < cols ? col0 + f : cols - 1)];
+      v[j] = g[(d < grows ? d : grows - 1) * cols + (col0 + f < cols ? col0 + f : cols - 1)];   // (a weight: 32-bit offsets)
     } else {
       const int n = idx / K, k = idx - n * K;
-      v[j] = g[(size_t)(n < grows ? n : grows - 1) * cols + (col0 + k < cols ? col0 + k : cols - 1)];
+      v[j] = g[(n < grows ? n : grows - 1) * cols + (col0 + k < cols ? col0 + k : cols - 1)];
     }
   }
 #pragma unroll
