@@ -939,33 +939,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   BSTAMP_FLUSH();
 }
 
-// dW[d][f] = sum_b slab[b][d*KPAD + f],  db[d] = sum_b slab[b][64*KPAD + d]   (fixed order over b)
-constexpr int RED_SLICES = 16;
-__global__ __launch_bounds__(256) void k_fused_reduce(const float* __restrict__ partials, int nslabs, int KPAD, int F,
-                                                      float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float part[RED_SLICES][16];
-  const int slab_floats = DD * KPAD + DD;
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + o;
-  float s = 0.f;
-  if (idx < slab_floats) {
-#pragma unroll 8
-    for (int b = sl; b < nslabs; b += RED_SLICES) s += partials[(size_t)b * slab_floats + idx];
-  }
-  part[sl][o] = s;
-  __syncthreads();
-  if (sl == 0 && idx < slab_floats) {
-    float tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < RED_SLICES; ++k) tot += part[k][o];
-    if (idx < DD * KPAD) {
-      const int d = idx / KPAD, f = idx % KPAD;
-      if (f < F) dW[(size_t)d * F + f] = tot;
-    } else {
-      db[idx - DD * KPAD] = tot;
-    }
-  }
-}
 
 int pick_grid(int num_tiles) {
   int dev = 0, cus = 256;
@@ -1151,18 +1124,13 @@ extern "C" int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* p
 // second stage of the backward: dW[D, F], db[D] <- the per-workgroup slabs left in `workspace` by
 // hcg_fused_layer_bwd (same B, F, D, graphs_per_tile), summed in a fixed order.
 extern "C" int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F,
-                                      int64_t D, int graphs_per_tile, float* dW, float* db, hcg_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1 || !dW || !db) return HCG_ERR_INVALID_ARG;
-  const int kpad = F <= 32 ? 32 : 64;
-  const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
-  const int grid = (N > 0 && B > 0) ? pick_grid(tiles) : 0;
-  const int slab_floats = DD * kpad + DD;
-  if (workspace_bytes < (size_t)grid * slab_floats * sizeof(float)) return HCG_ERR_WORKSPACE;
-  hipLaunchKernelGGL(k_fused_reduce, dim3((slab_floats + 15) / 16), dim3(256), 0, stream, (const float*)workspace, grid,
-                     kpad, (int)F, dW, db);
-  HCG_CHECK_LAUNCH();
-  return HCG_OK;
+                                      int64_t D, int graphs_per_tile, float* dW, float* db, hcg_stream_t stream) {
+  // one job for the shared slab-reduction kernel: the same summation order as the batched reduction of a whole step, so
+  // the per-layer and the whole-model paths stay bitwise equal
+  hcg_reduce_job job;
+  const int rc = hcg_fused_reduce_job(workspace, workspace_bytes, N, B, F, D, graphs_per_tile, dW, db, &job);
+  if (rc != HCG_OK) return rc;
+  return hcg_reduce_slabs(&job, 1, stream);
 }
 
 // host-side description of this layer's slab set for hcg_reduce_slabs (no launch)

@@ -259,31 +259,6 @@ __global__ __launch_bounds__(RWAVES * 64, 1) void k_readout_bwd(const float* __r
   }
 }
 
-constexpr int RR_SLICES = 16;
-__global__ __launch_bounds__(256) void k_readout_reduce(const float* __restrict__ slabs, int nslabs, int C,
-                                                        float* __restrict__ dW0, float* __restrict__ db0,
-                                                        float* __restrict__ dW1, float* __restrict__ db1) {
-  __shared__ float part[RR_SLICES][16];
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + o;
-  float s = 0.f;
-  if (idx < SLAB) {
-#pragma unroll 8
-    for (int b = sl; b < nslabs; b += RR_SLICES) s += slabs[(size_t)b * SLAB + idx];
-  }
-  part[sl][o] = s;
-  __syncthreads();
-  if (sl == 0 && idx < SLAB) {
-    float tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < RR_SLICES; ++k) tot += part[k][o];
-    if (idx < RD * RK) dW0[idx] = tot;
-    else if (idx < RD * RK + RD) db0[idx - RD * RK] = tot;
-    else if (idx < RD * RK + RD + RCMAX * RD) { const int j = idx - RD * RK - RD; if (j < C * RD) dW1[j] = tot; }
-    else { const int c = idx - RD * RK - RD - RCMAX * RD; if (c < C) db1[c] = tot; }
-  }
-}
-
 // backward: one workgroup per tile (4 waves = 4 column blocks); forward: one workgroup per 2 tiles
 int readout_grid(int64_t B) {
   int grid = (int)((B + RT - 1) / RT);
@@ -329,10 +304,18 @@ extern "C" int hcg_readout2_bwd(const float* dout, const float* emb, const float
                        slope, demb, (float*)workspace);
     HCG_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_readout_reduce, dim3((SLAB + 15) / 16), dim3(256), 0, stream, (const float*)workspace,
-                     grid, (int)C, dW0, db0, dW1, db1);
-  HCG_CHECK_LAUNCH();
-  return HCG_OK;
+  if (grid == 0) {   // empty batch: the gradients are zero
+    HCG_TRY(hcg_hip_err(hipMemsetAsync(dW0, 0, sizeof(float) * RD * RK, stream)));
+    HCG_TRY(hcg_hip_err(hipMemsetAsync(db0, 0, sizeof(float) * RD, stream)));
+    HCG_TRY(hcg_hip_err(hipMemsetAsync(dW1, 0, sizeof(float) * C * RD, stream)));
+    HCG_TRY(hcg_hip_err(hipMemsetAsync(db1, 0, sizeof(float) * C, stream)));
+    return HCG_OK;
+  }
+  // the shared slab-reduction kernel (same summation order as the batched reduction of a whole step)
+  hcg_reduce_job job;
+  const int rc = hcg_readout2_reduce_job(workspace, workspace_bytes, B, C, dW0, db0, dW1, db1, &job);
+  if (rc != HCG_OK) return rc;
+  return hcg_reduce_slabs(&job, 1, stream_);
 }
 
 // backward without the slab reduction (pair with hcg_readout2_reduce_job + hcg_reduce_slabs)

@@ -24,7 +24,10 @@ struct Jobs {
   hcg_reduce_job job[HCG_REDUCE_MAX_JOBS];
 };
 
-constexpr int RS = 16;  // slab slices per output element
+// slab slices per output element.  8 slices x 32 outputs per block: every slab row a wave touches is a full 128-byte line
+// (measured per launch at C3: 32 x 8 = 9.5 us, 16 x 16 = 6.2, 8 x 32 = 4.8, 4 x 64 = 6.0; 16 loads in flight per thread: 4.5)
+constexpr int RS = 8;
+constexpr int RO = 256 / RS;   // output elements per 256-thread block
 
 // Adam state for the fused "reduce, then update" variant: every reduced gradient element is written to its place in
 // the flat gradient buffer AND immediately used for torch.optim.Adam's update of the parameter at the same offset
@@ -41,11 +44,11 @@ struct AdamArgs {
 
 template <bool ADAM>
 __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
-  __shared__ float part[RS][16];
+  __shared__ float part[RS][RO];
   const hcg_reduce_job& J = jobs.job[blockIdx.y];
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + o;
-  if (blockIdx.x * 16 >= J.slab_floats) return;   // block-uniform
+  const int o = threadIdx.x % RO, sl = threadIdx.x / RO;
+  const int idx = blockIdx.x * RO + o;
+  if (blockIdx.x * RO >= J.slab_floats) return;   // block-uniform
   __shared__ float adam_c[3];                        // lr / bias-correction-1, sqrt(bias-correction-2)
   if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation
     const int t = A.step_dev[0];                     // number of THIS update (advanced earlier in the step)
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
   }
   float s = 0.f;
   if (idx < J.slab_floats) {
-#pragma unroll 8
+#pragma unroll 16   // (the head's 128 slabs = exactly one group of 16 per thread, the conv layers' 256 two)
     for (int b = sl; b < J.nslabs; b += RS) s += J.slabs[(size_t)b * J.slab_floats + idx];
   }
   part[sl][o] = s;
@@ -118,7 +121,7 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
     if (J.slab_floats > max_floats) max_floats = J.slab_floats;
   }
   for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
-  const dim3 grid((max_floats + 15) / 16, njobs);
+  const dim3 grid((max_floats + RO - 1) / RO, njobs);
   if (adam) hipLaunchKernelGGL(k_reduce_jobs<true>, grid, dim3(256), 0, stream, jobs, *adam);
   else hipLaunchKernelGGL(k_reduce_jobs<false>, grid, dim3(256), 0, stream, jobs, AdamArgs{});
   HCG_CHECK_LAUNCH();
