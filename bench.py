@@ -2,34 +2,37 @@
 """bench.py -- graphs/sec of the GCN fwd+bwd hot path on N MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
-    batch plan (CSR / gcn_norm from the int64 edge_index, rebuilt EVERY step)
+    batch plan (graph_ptr / edge_ptr / gcn_norm from the int64 edge_index, rebuilt EVERY step)
     -> forward (2 x GCNConv+LeakyReLU, [max, mean] pool, readout MLP)
     -> sqrt(MSE) loss (reference utils/utils_model.py:64)
     -> backward (all weight gradients)
-    -> [N > 1] RCCL all-reduce of the flat gradient buffer.
+    -> [N > 1] RCCL all-reduce of the flat gradient buffer
     -> Adam update (the reference's optimiser, model/networks.py:38).
-`value` times ALL of it (hipGraph replay of the captured step when capture succeeds); `fwd_bwd_only` reports the
-same step without the update, and the CPU baseline runs the same full step.
+
+What `value` is.  Consecutive steps run on DISTINCT batches: `--distinct-batches` (8) synthetic batches, each with its
+own step buffers (activations, gradients, slabs), are visited round-robin, so that more than 2 GB is touched between two
+uses of the same bytes -- nothing of a step is served from the 256 MiB Infinity Cache because an earlier step left it
+there.  Before the timed region the same rotation runs for `--sustain` (5) seconds (`sustained`: its own graphs/s), so
+the K timed steps run at the clocks the chip holds under load, not in a cold burst.  `value` = the K steps timed right
+behind it.  `burst` is the old figure: one batch replayed in place (cache resident), timed from idle.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C5|...]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-
-Prints ONE JSON line on rank 0.
+With --gpus N > 1 and no RANK in the environment this script starts its own N ranks (one per GPU, a child
+`python -m torch.distributed.run`), relays rank 0's JSON line and exits with the child's code; launched under an
+external torch.distributed.run it is one of the ranks.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -41,15 +44,61 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", help="BASELINE.json config: C3 (= configs[2], the metric's), C2, C5, C1; "
-                    "REAL / REAL40 = the reference's own graph sizes (57-117 atoms, F = 25) at B = 4096 / 40")
+                    "REAL / REAL40 = the reference's own graph sizes (57-117 atoms, F = 25) at B = 4096 / 40; "
+                    "RAGGED = C3 with n_g ~ U{24..36} (SURVEY 8d's variable-size variant)")
     ap.add_argument("--num-graphs", type=int, default=None, help="override graphs per GPU")
+    ap.add_argument("--distinct-batches", type=int, default=8, help="distinct resident batches (+ step buffers) visited round-robin")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the same rotation run right before the timed steps")
+    ap.add_argument("--combine", default="sse", choices=("sse", "mean"),
+                    help="N > 1: 'sse' = gradient of sqrt(MSE) over the concatenated batch of all ranks (the reference's "
+                         "semantics at batch N*B); 'mean' = mean of per-rank RMSE gradients (DDP convention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
+    ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
     return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 from a bare shell: start the ranks as a CHILD process before anything here touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without RANK in the environment: starting {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                      # relay; the record is the LAST line that parses as the bench's JSON
+        out = out.rstrip("\n")
+        try:
+            rec = json.loads(out)
+            if isinstance(rec, dict) and "metric" in rec:
+                line = out
+                continue
+        except ValueError:
+            pass
+        print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("the ranks exited 0 without a JSON line")
+        rc = 1
+    return rc
 
 
 class EntryTimer:
@@ -62,12 +111,16 @@ class EntryTimer:
                    "hcg_fused_layer_fwd": ("hcg_fused_layer_fwd_train",)}
 
     def __init__(self, lib, name):
+        import torch
+        self.torch = torch
         self.lib, self.name = lib, name
         self.names = (name,) + self.SAME_KERNEL.get(name, ())
         self.orig = {n: getattr(lib, n) for n in self.names}
         self.events, self.enabled = [], False
 
     def install(self):
+        torch = self.torch
+
         def make(orig):
             def wrapper(*a):
                 if not self.enabled:
@@ -86,14 +139,10 @@ class EntryTimer:
         for n in self.names:
             setattr(self.lib, n, self.orig[n])
 
-    def mean_ms(self, per_step_calls):
-        torch.cuda.synchronize()
+    def mean_ms(self):
+        self.torch.cuda.synchronize()
         ms = [s.elapsed_time(e) for s, e in self.events]
         return (sum(ms) / len(ms) if ms else float("nan")), len(ms)
-
-
-def log(msg):
-    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def usable_cpus() -> int:
@@ -117,27 +166,42 @@ def usable_cpus() -> int:
 
 def cpu_baseline(cfg_name, num_graphs, steps):
     """The reference CPU scatter path (oracle = torch-native restatement, validated bit-exact against
-    the reference's embeddings) timed on this box's host cores.  Checker / baseline only."""
+    the reference's embeddings) timed on this box's host cores.  Checker / baseline only.  Three figures
+    (BASELINE.md 3): all cores incl. Adam (`value`), all cores without the optimiser, one thread."""
+    import torch
     from hcatgnet_amd import synth
     from oracle import gcn_oracle
     import hcatgnet_amd as H
     cores = usable_cpus()
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads")
     sb = synth.make_config(cfg_name, num_graphs=num_graphs)
     cfg = synth.CONFIGS[cfg_name]
     model = H.make_network("GCN", H.default_options(embedding_dim=cfg["hidden"]), cfg["feat"])
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    p, opt = gcn_oracle.make_train_state(params)
-    ts = []
-    for i in range(3 + steps):
-        t0 = time.perf_counter()
-        gcn_oracle.train_step(p, opt, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
-        ts.append(time.perf_counter() - t0)
-        if i % 5 == 0:
-            log(f"cpu_baseline step {i}: {ts[-1] * 1e3:.1f} ms")
-    ts = sorted(ts[3:])
-    med = ts[len(ts) // 2]
+
+    def measure(threads, n_steps, with_opt, budget_s):
+        torch.set_num_threads(threads)
+        p, opt = gcn_oracle.make_train_state(params)
+        ts, t_begin = [], time.perf_counter()
+        for i in range(2 + n_steps):
+            t0 = time.perf_counter()
+            if with_opt:
+                gcn_oracle.train_step(p, opt, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
+            else:
+                opt.zero_grad()
+                out, _ = gcn_oracle.gcn_forward(p, sb.x, sb.edge_index, sb.batch, sb.num_graphs)
+                gcn_oracle.rmse_loss(out, sb.y).backward()
+            ts.append(time.perf_counter() - t0)
+            if i >= 4 and time.perf_counter() - t_begin > budget_s:      # bounded sample
+                break
+        ts = sorted(ts[2:])
+        return ts[len(ts) // 2], ts[0], len(ts)
+    log(f"cpu_baseline: {cores} threads, full step")
+    med, best, n_full = measure(cores, steps, True, 14.0)
+    log(f"cpu_baseline: {cores} threads, no optimiser")
+    med_noopt, _, n_noopt = measure(cores, max(6, steps // 3), False, 7.0)
+    log("cpu_baseline: 1 thread")
+    med_1t, _, n_1t = measure(1, 6, True, 10.0)
+    torch.set_num_threads(cores)
     model_name = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -147,59 +211,96 @@ def cpu_baseline(cfg_name, num_graphs, steps):
     except OSError:
         pass
     return {"value": sb.num_graphs / med, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed training steps (fwd + sqrt(MSE) + bwd + Adam; median, 3 warm-up) of the full {cfg_name} batch "
+            "sample": f"{n_full} timed training steps (fwd + sqrt(MSE) + bwd + Adam; median, 2 warm-up) of the full {cfg_name} batch "
                       f"({sb.num_graphs} graphs) with the torch CPU restatement of the reference's PyG scatter path, "
                       f"{cores} threads; PyG itself is not installable here",
-            "ms_per_step": med * 1e3, "cpu_model": model_name}
+            "ms_per_step": med * 1e3, "best_ms_per_step": best * 1e3, "cpu_model": model_name,
+            "without_optimizer": {"value": sb.num_graphs / med_noopt, "ms_per_step": med_noopt * 1e3, "cores": cores,
+                                  "steps": n_noopt},
+            "one_thread": {"value": sb.num_graphs / med_1t, "ms_per_step": med_1t * 1e3, "cores": 1, "steps": n_1t}}
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` from a bare shell: it starts its own ranks)")
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
     # rehearsal of the N > 1 control flow on a ONE-GPU box (tools/rehearse_multi_rank.sh): every rank on device 0,
     # gloo instead of RCCL (RCCL refuses two ranks on one device).  Never set by the driver; the numbers mean nothing.
     rehearsal = os.environ.get("HCG_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    if not rehearsal and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import hcatgnet_amd as H
     from hcatgnet_amd import _lib, algbytes, synth
     from hcatgnet_amd.ddp import DataParallelGCN
+    from hcatgnet_amd.train import FusedTrainStep
     lib = _lib.load()
+    # development A/B switches (tools/ab_env.sh): measurement tooling only, the product has no environment switches
+    if os.environ.get("HCG_NO_POOLBITS") == "1":
+        FusedTrainStep.POOLBITS = False
+    if os.environ.get("HCG_NO_PREMASK") == "1":
+        FusedTrainStep.PREMASK = False
     log(f"rank {rank}/{world}: library loaded")
 
     cfg_name = args.config
+    ragged_cfg = dict(nodes_jitter=6)                    # n_g ~ U{24..36}
+    if cfg_name == "RAGGED":
+        cfg_name, extra = "C3", ragged_cfg
+    else:
+        extra = {}
     cfg = synth.CONFIGS[cfg_name]
-    sb = synth.make_config(cfg_name, rank=rank, num_graphs=args.num_graphs)
-    x, ei, bvec, y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
-    N, E, B, F, D = x.shape[0], ei.shape[1], sb.num_graphs, cfg["feat"], cfg["hidden"]
+    NB = max(1, args.distinct_batches)
+    F, D = cfg["feat"], cfg["hidden"]
     opt = H.default_options(embedding_dim=D)
     model = H.make_network("GCN", opt, F).to(dev)
-    dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
-    y2 = y.unsqueeze(1)
 
-    from hcatgnet_amd.train import FusedTrainStep
+    class Resident:
+        """One synthetic batch in HBM (its own seed stream: base + 1000 * (rank + world * i))."""
 
-    def make_batch():      # a fresh Batch per step: its plan (graph_ptr / edge_ptr from the int64 inputs) is rebuilt every step
-        return H.Batch(x, ei, bvec, B, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges, edges_grouped=True)
+        def __init__(self, i, **kw):
+            sb = synth.make_config(cfg_name, rank=rank + world * i, num_graphs=args.num_graphs, **kw)
+            self.sb = sb
+            self.x, self.ei, self.bvec, self.y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
+            self.y2 = self.y.unsqueeze(1)
+            self.B, self.N, self.E = sb.num_graphs, self.x.shape[0], self.ei.shape[1]
 
-    fused_ok = (not args.forward_only) and FusedTrainStep.unsupported_reason(model, make_batch()) is None
-    # the training step of the reference's loop (utils/utils_model.py:60-68) WITH the Adam update; `fwdbwd` stops
-    # after the backward (gradients only), for the secondary "fwd+bwd only" figure
-    trainer = FusedTrainStep(model, optimizer_step=True) if fused_ok else None
+        def fresh(self):     # a fresh Batch per step: its plan (graph_ptr / edge_ptr from the int64 inputs) is rebuilt every step
+            sb = self.sb
+            return H.Batch(self.x, self.ei, self.bvec, self.B, y=self.y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
+                           edges_grouped=True)
+
+        def bytes_touched(self):
+            return self.x.nbytes + self.ei.nbytes + self.bvec.nbytes + self.y.nbytes
+
+    res = [Resident(i, **extra) for i in range(NB)]
+    r0 = res[0]
+    N, E, B = r0.N, r0.E, r0.B
+    fused_ok = (not args.forward_only) and FusedTrainStep.unsupported_reason(model, r0.fresh()) is None
+    # the training step of the reference's loop (utils/utils_model.py:60-68) WITH the Adam update, one trainer (= one set of
+    # step buffers) per resident batch; `fwdbwd` stops after the backward (gradients only: secondary figure, batch 0)
+    trainers = [FusedTrainStep(model, optimizer_step=True) for _ in res] if fused_ok else []
     fwdbwd = FusedTrainStep(model, optimizer_step=False) if fused_ok else None
+    dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
 
-    def autograd_step(with_opt=True):
+    def autograd_step(i=0, with_opt=True):
         model.optimizer.zero_grad(set_to_none=True)
-        out = model(make_batch())                        # plan build + forward
-        loss = torch.sqrt(model.loss(out, y2))
+        out = model(res[i].fresh())                      # plan build + forward
+        loss = torch.sqrt(model.loss(out, res[i].y2))
         loss.backward()
         if dp is not None:
             dp.reduce_gradients()
@@ -207,69 +308,103 @@ def main():
             model.optimizer.step()
         return loss
 
-    def forward_step():
+    def forward_step(i=0):
         with torch.no_grad():
-            return model(make_batch())
+            return model(res[i].fresh())
 
-    def eager_step(with_opt=True):
+    def eager_step(i=0, with_opt=True):
         if args.forward_only:
-            return forward_step()
+            return forward_step(i)
         if not fused_ok:
-            return autograd_step(with_opt)
-        return (trainer if with_opt else fwdbwd)(make_batch())
+            return autograd_step(i, with_opt)
+        return (trainers[i] if with_opt else fwdbwd)(res[i].fresh())
 
     replay = {}
 
     def capture_all():
         """Everything the step enqueues (plan build, forward, head with loss, backward, slab reduction, Adam) goes
-        into hipGraphs; the RCCL all-reduce stays an eager call between the backward graph and the update graph."""
+        into hipGraphs, one per resident batch; with N > 1 the RCCL all-reduce stays an eager call between the backward
+        graph and the (single-launch) update."""
         if args.forward_only or not fused_ok:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    forward_step() if args.forward_only else autograd_step(False)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            if not args.forward_only:
-                model.optimizer.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                forward_step() if args.forward_only else autograd_step(False)
-            grads = [] if args.forward_only else [p.grad for p in model.parameters()]
+            runs = []
+            for i in range(NB):
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        forward_step(i) if args.forward_only else autograd_step(i, False)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                if not args.forward_only:
+                    model.optimizer.zero_grad(set_to_none=True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    forward_step(i) if args.forward_only else autograd_step(i, False)
+                grads = [] if args.forward_only else [p.grad for p in model.parameters()]
 
-            def run(with_opt=True):
-                g.replay()
-                if dp is not None:
-                    dp.reduce_gradients(grads=grads)
-                if with_opt and not args.forward_only:
-                    model.optimizer.step()
-            replay["full"] = run
-            replay["fwdbwd"] = lambda: run(False)
+                def run(with_opt=True, g=g, grads=grads):
+                    g.replay()
+                    if args.forward_only:
+                        return
+                    for p, gr in zip(model.parameters(), grads):
+                        p.grad = gr
+                    if dp is not None:
+                        dp.reduce_gradients(grads=grads)
+                    if with_opt:
+                        model.optimizer.step()
+                runs.append(run)
+            replay["full"] = runs
+            replay["fwdbwd"] = lambda: runs[0](False)
             return
-        trainer.capture(make_batch)
-        fwdbwd.capture(make_batch)
-        replay["full"] = trainer.replay
+        for i, tr in enumerate(trainers):
+            tr.capture(res[i].fresh)
+        fwdbwd.capture(r0.fresh)
+        replay["full"] = [tr.replay for tr in trainers]
         replay["fwdbwd"] = fwdbwd.replay
 
-    def timed(k, fn):
+    def barrier():
         if world > 1:
             dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            fn()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
-        dt = time.perf_counter() - t0
+
+    def max_over_ranks(dt):
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    log(f"inputs resident: N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
+    def timed(k, fn, start=0):
+        """K calls fn(i), i = start, start + 1, ... (mod NB), bracketed by barrier + synchronize; MAX over ranks."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(k):
+            fn((start + j) % NB)
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def sustain(seconds, fn):
+        """The rotation for at least `seconds`: chunks of steps, one synchronize per chunk.  -> (steps, seconds, next index)"""
+        barrier()
+        torch.cuda.synchronize()
+        t0, n, chunk = time.perf_counter(), 0, 256
+        while True:
+            for j in range(chunk):
+                fn((n + j) % NB)
+            n += chunk
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:    # every rank must leave the loop after the same chunk
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            if el >= seconds:
+                return n, el, n % NB
+            if n % (chunk * 16) == 0:
+                log(f"sustained rotation: {n} steps, {el:.1f} s")
+
+    log(f"inputs resident: {NB} batches of N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
 
     def count_launching_calls():
         """Library entry points that enqueue kernels during ONE eager step (launches per step)."""
@@ -278,6 +413,7 @@ def main():
         counts, origs = {}, {}
         for n in names:
             origs[n] = getattr(lib, n)
+
             def wrap(*a, _n=n):
                 counts[_n] = counts.get(_n, 0) + 1
                 return origs[_n](*a)
@@ -289,8 +425,8 @@ def main():
             for n in names:
                 setattr(lib, n, origs[n])
         return counts
-    for _ in range(args.warmup):
-        eager_step()
+    for j in range(max(args.warmup, NB)):
+        eager_step(j % NB)
     torch.cuda.synchronize()
     log("warm-up done")
     launch_counts = count_launching_calls()
@@ -298,8 +434,10 @@ def main():
     launch_mode, graph_err = "eager", None
     if not args.no_graph:
         try:
-            if world > 1 and fused_ok:          # the exchange sits between backward and update: two graphs per step
-                trainer.grad_sync = fwdbwd.grad_sync = (lambda flat: None)
+            if world > 1 and fused_ok:          # the exchange sits between backward and update: the graph ends before it
+                for tr in trainers + [fwdbwd]:
+                    tr.grad_sync = (lambda flat: None)
+                    tr.combine = args.combine
             capture_all()                       # before RCCL comes up: no collective activity while a stream is capturing
             launch_mode = "hipgraph"
             log("step captured into hipGraphs")
@@ -308,22 +446,26 @@ def main():
             graph_err = f"{type(exc).__name__}: {exc}"
             log(f"graph capture failed, keeping eager launches: {graph_err}")
 
+    rccl_world = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-        dp = DataParallelGCN(model)           # broadcasts rank-0 weights (in place: the graphs see them)
+        rccl_world = dist.get_world_size()
+        if rccl_world != world:
+            raise SystemExit(f"bench.py: the process group reports world size {rccl_world}, expected {world}")
+        dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place: the graphs see them)
         if fused_ok:
-            trainer.grad_sync = dp.reduce_flat
-            fwdbwd.grad_sync = dp.reduce_flat
-        for _ in range(3):
-            eager_step()
-        log(f"RCCL process group up: world {world}")
+            for tr in trainers + [fwdbwd]:
+                dp.attach(tr)
+        for j in range(3):
+            eager_step(j % NB)
+        log(f"{'gloo (rehearsal)' if rehearsal else 'RCCL'} process group up: world {rccl_world}")
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
-    mid = sb.max_nodes > 32
+    mid = r0.sb.max_nodes > 32
     entry = args.roofline_entry or (("hcg_mid_layer_fwd" if mid else "hcg_fused_stack2_fwd") if args.forward_only
                                     else ("hcg_mid_layer_bwd" if mid else "hcg_fused_layer_bwd"))
     timer = EntryTimer(lib, entry)
@@ -331,39 +473,54 @@ def main():
     timer.enabled = True
     dt = timed(args.steps, eager_step)
     timer.enabled = False
-    k_ms, k_calls = timer.mean_ms(args.steps)
+    k_ms, k_calls = timer.mean_ms()
     timer.uninstall()
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
     dt_eager = timed(args.steps, eager_step)
-    log(f"timed eager (full step): {dt_eager / args.steps * 1e3:.3f} ms/step")
+    log(f"timed eager (full step, rotating batches): {dt_eager / args.steps * 1e3:.3f} ms/step")
     # distribution of single steps (median, p10 / p90): HIP events around every step of one more pass
     evs = []
-    for _ in range(args.steps):
+    for j in range(args.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        eager_step()
+        eager_step(j % NB)
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
     per_step = sorted(a.elapsed_time(b) for a, b in evs)
     pct = {f"p{q}": per_step[min(len(per_step) - 1, int(len(per_step) * q / 100))] for q in (10, 50, 90)}
-    dt_best, dt_fb, dt_graph = dt_eager, None, None
+
+    # ---- burst figure (round 1's headline): ONE batch replayed in place from an idle chip
+    dt_fb, dt_graph_burst = None, None
     if "full" in replay:
         for _ in range(max(3, args.warmup // 2)):
-            replay["full"]()
-        dt_graph = timed(args.steps, replay["full"])
-        log(f"timed hipGraph replay (full step): {dt_graph / args.steps * 1e3:.3f} ms/step")
-        if dt_graph <= dt_eager:
-            dt_best = dt_graph
-        else:   # the no-autograd step issues 6 launches from a host loop that runs ahead of the GPU: replay need not win
-            launch_mode = "eager"
+            replay["full"][0]()
+        dt_graph_burst = timed(args.steps, lambda i: replay["full"][0]())
+        log(f"burst, hipGraph replay of ONE batch in place: {dt_graph_burst / args.steps * 1e3:.3f} ms/step")
         if not args.forward_only:
             for _ in range(3):
                 replay["fwdbwd"]()
-            dt_fb = timed(args.steps, replay["fwdbwd"])
-            log(f"timed hipGraph replay (fwd+bwd only, no update): {dt_fb / args.steps * 1e3:.3f} ms/step")
+            dt_fb = timed(args.steps, lambda i: replay["fwdbwd"]())
+            log(f"burst, hipGraph replay (fwd+bwd only, no update): {dt_fb / args.steps * 1e3:.3f} ms/step")
     elif not args.forward_only:
-        dt_fb = timed(args.steps, lambda: eager_step(False))
+        dt_fb = timed(args.steps, lambda i: eager_step(0, False))
+    dt_eager_burst = timed(args.steps, lambda i: eager_step(0))
+
+    # ---- the headline: sustained rotation over distinct batches, then EXACTLY K steps right behind it
+    use_graph = "full" in replay
+    if use_graph:      # the no-autograd step issues 6 launches from a host loop that can run ahead of the GPU: take the faster
+        tg = timed(max(args.steps, 4 * NB), lambda i: replay["full"][i]())
+        te = timed(max(args.steps, 4 * NB), eager_step)
+        use_graph = tg <= te
+        log(f"rotation probe: hipGraph {tg / max(args.steps, 4 * NB) * 1e3:.4f} vs eager {te / max(args.steps, 4 * NB) * 1e3:.4f} ms/step")
+    launch_mode = "hipgraph" if use_graph else "eager"
+    step_fn = (lambda i: replay["full"][i]()) if use_graph else eager_step
+    sus_steps, sus_s, nxt = sustain(args.sustain, step_fn) if args.sustain > 0 else (0, 0.0, 0)
+    dt_best = timed(args.steps, step_fn, start=nxt)
+    log(f"sustained {sus_s:.2f} s / {sus_steps} steps = {sus_s / max(sus_steps, 1) * 1e3:.4f} ms/step; "
+        f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode})")
+    for tr in trainers:
+        tr.check_health()
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(v for k, v in bd.items() if not args.forward_only or k.endswith("_fwd") or k == "csr_build")
@@ -379,33 +536,78 @@ def main():
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950
     # correction of MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only valid for the config they were taken on
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-    if cfg_name in ("C2", "C3", "C4") and args.num_graphs is None and os.path.isfile(tpath):
+    if cfg_name in ("C2", "C3", "C4", "C5", "REAL") and not extra and args.num_graphs is None and os.path.isfile(tpath):
         try:
             tj = json.load(open(tpath))
-            prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd"}.get(entry)   # (forward traffic: re-profile after STACK2)
+            if "C3" in tj or "C5" in tj or "REAL" in tj:      # per-config sections; (round-1 files: flat, C3 only)
+                tj = tj.get(cfg_name if cfg_name in ("C5", "REAL") else "C3", {})
+            elif cfg_name in ("C5", "REAL"):
+                tj = {}
+            prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd", "hcg_mid_layer_bwd": "k_mid_layer_bwd",
+                      "hcg_fused_stack2_fwd": "k_fused_layer_fwd", "hcg_mid_layer_fwd": "k_mid_layer_fwd"}.get(entry)
             vals = [v["hbm_bytes"] for k, v in tj.items() if prefix and k.startswith(prefix)]
             traffic = sum(vals) / len(vals) if vals else None
-        except (OSError, ValueError, KeyError):
+            traffic_src = "profiles/traffic_latest.json: builder-run rocprofv3 PMC passes of this command, not measured in this run"
+        except (OSError, ValueError, KeyError, AttributeError):
             traffic = None
+
+    # ---- secondary: the ragged variant of the same workload (n_g ~ U{24..36}, "report both")
+    ragged = None
+    if world == 1 and fused_ok and not extra and cfg_name in ("C2", "C3", "C4") and not args.no_ragged and not args.forward_only:
+        try:
+            rr = [Resident(100 + i, **ragged_cfg) for i in range(NB)]
+            rtr = [FusedTrainStep(model, optimizer_step=True) for _ in rr]
+            for tr, r in zip(rtr, rr):
+                for _ in range(2):
+                    tr(r.fresh())
+                tr.capture(r.fresh)
+            rfn = lambda i: rtr[i].replay()
+            timed(4 * NB, rfn)
+            rdt = timed(max(args.steps, 200), rfn)
+            k = max(args.steps, 200)
+            gpt = lib.hcg_fused_graphs_per_tile(F, D, rr[0].sb.max_nodes)
+            ragged = {"value": rr[0].B * k / rdt, "unit": "graphs/s", "ms_per_step": rdt / k * 1e3, "steps": k,
+                      "graphs": rr[0].B, "nodes": rr[0].N, "edges": rr[0].E, "max_nodes": rr[0].sb.max_nodes,
+                      "kernel_family": "small-graph tiles" if gpt > 0 else "one graph per workgroup",
+                      "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, hipGraph replay"}
+            log(f"ragged variant: {rdt / k * 1e3:.4f} ms/step")
+            del rr, rtr
+        except Exception as exc:
+            ragged = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         ms_step = dt_best / args.steps * 1e3
+        touched = NB * (r0.bytes_touched() + (sum(t.nbytes for t in trainers[0]._bufs["cap"]["acts"] + trainers[0]._bufs["cap"]["dacts"])
+                                              if fused_ok else 0))
+        fwd_only_note = "plan/gcn_norm build + forward (conv stack, pool, readout) only" if args.forward_only else \
+            (f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
+             f"{'RCCL all-reduce (' + args.combine + '), ' if world > 1 else ''}Adam update")
         rec = {
             "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s" if not args.forward_only
                       else "molecular graphs/sec FORWARD ONLY (configs[1]; not the headline metric)",
             "value": world * B * args.steps / dt_best, "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg_name}: {B} synthetic graphs/GPU x {N / B:.0f} atoms x {E / B:.0f} directed edges x "
+            "config": {"workload": f"{'C2' if args.forward_only and cfg_name == 'C3' else args.config}: {B} synthetic graphs/GPU x "
+                                   f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
-                                   f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
-                                   f"{'RCCL all-reduce, ' if world > 1 else ''}Adam update; launch={launch_mode}",
+                                   f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
+            "rccl_world": rccl_world,
+            "distinct_batches": NB, "bytes_touched_between_reuse": touched,
+            "sustained_s": sus_s, "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3,
+                                                "value": world * B * sus_steps / sus_s if sus_s > 0 else None,
+                                                "note": "the same rotation, run right before the timed steps (one synchronize per 256 steps)"},
+            "burst": {"note": "ONE batch replayed in place from an idle chip (cache resident): round 1's headline figure",
+                      "hipgraph_ms_per_step": dt_graph_burst / args.steps * 1e3 if dt_graph_burst else None,
+                      "eager_ms_per_step": dt_eager_burst / args.steps * 1e3,
+                      "value": world * B * args.steps / min(x for x in (dt_graph_burst, dt_eager_burst) if x)},
+            "ragged": ragged,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": entry, "kernel_ms": k_ms, "kernel_launches_timed": k_calls,
                          "algorithmic_bytes_per_launch": entry_bytes},
             "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
@@ -413,14 +615,14 @@ def main():
                               "breakdown": bd},
             "fwd_bwd_only": None if dt_fb is None else {"value": world * B * args.steps / dt_fb, "unit": "graphs/s",
                                                         "ms_per_step": dt_fb / args.steps * 1e3,
-                                                        "note": "same step without the Adam update (gradients only)"},
+                                                        "note": "burst form, same step without the Adam update (gradients only)"},
             "optimizer": type(model.optimizer).__name__ + "(lr=0.01, eps=1e-9), inside the timed step",
-            "step_path": "FusedTrainStep (no autograd)" if fused_ok else "autograd",
+            "step_path": "forward only" if args.forward_only else ("FusedTrainStep (no autograd)" if fused_ok else "autograd"),
             "library_launching_calls_per_step": {"total": sum(launch_counts.values()), "by_entry_point": launch_counts},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "eager_step_ms_percentiles_hip_events": pct,
             "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3,
-            "hipgraph_ms_per_step": (dt_graph / args.steps * 1e3) if "full" in replay else None, "graph_capture_error": graph_err,
+            "graph_capture_error": graph_err,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg_name, args.num_graphs, args.cpu_steps)

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhcatgnet_hip.so")
 
 HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0, 1, 2, 4
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
+HCG_HEAD_MSE, HCG_HEAD_RMSE, HCG_HEAD_SSE = 0, 1, 2      # `rmse` argument of hcg_head_fwd_bwd_ex
+HCG_HEAD_SYNC_WORDS, HCG_HEAD_ERR_TIMEOUT = 520, 1
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
                16: "a graph exceeds the fused-kernel tile",
@@ -68,7 +70,10 @@ SIGNATURES = {
     "hcg_head_supported": (INT, [I64, I64]),
     "hcg_head_workspace_bytes": (SZ, [I64]),
     "hcg_head_fwd_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P]),
+    "hcg_head_fwd_bwd_ex": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P, P]),
     "hcg_head_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
+    "hcg_sse_finalize": (INT, [P, I64, P, P]),
+    "hcg_adam_step_dev_sse": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P, P]),
     "hcg_reduce_slabs_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P]),
     "hcg_adam_step_dev": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P]),
     "hcg_fused_reduce_grads": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
@@ -130,13 +135,22 @@ def stream_ptr():
 
 
 def require_gpu(*tensors):
+    """Every tensor on the GPU -- and on the CURRENT device: the library enqueues on the current device's stream, a
+    pointer into another GPU's memory would fault there."""
     global _gpu_ok
+    cur = None
     for t in tensors:
         if t is None:
             continue
         if not t.is_cuda:
             raise HcgError("hcatgnet_amd runs on MI355X (ROCm) tensors only; got a CPU tensor. "
                            "There is no CPU fallback: move the model and the batch to the GPU.")
+        if cur is None:
+            import torch
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise HcgError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                           "call torch.cuda.set_device (one process per GPU) before using hcatgnet_amd")
     if _gpu_ok is None:
         import torch
         _gpu_ok = bool(torch.cuda.is_available())

@@ -71,12 +71,18 @@ __device__ __forceinline__ void publish_partial(int* sync, int gen, float my_par
   }
 }
 
+// The poll is BOUNDED (MI355X_MICROARCH.md, Correctness boundaries: "bound every spin"): a workgroup that has waited
+// HEAD_SPIN_TICKS of the constant 100 MHz clock (s_memrealtime; 2 s -- an exchange takes microseconds) gives up, ORs
+// HCG_HEAD_ERR_TIMEOUT into sync[1] and returns NaN, so the launch ends and the loss it leaves is NaN instead of the
+// GPU hanging (a grid that is not co-resident, or two launches interleaving on ONE set of sync words from two streams).
+constexpr unsigned long long HEAD_SPIN_TICKS = 200000000ull;
 __device__ __forceinline__ float collect_partials(int* sync, int nblk, int gen, float* bcast) {
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(sync + 2);
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
     float s = 0.f;
     bool done;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     do {
       done = true;
       s = 0.f;
@@ -90,7 +96,14 @@ __device__ __forceinline__ float collect_partials(int* sync, int nblk, int gen, 
         }
       }
       done = __all(done);
-      if (!done) __builtin_amdgcn_s_sleep(2);
+      if (!done) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t_start > HEAD_SPIN_TICKS) {   // wave-uniform (scalar clock)
+          if (lane == 0) atomicOr(&sync[1], HCG_HEAD_ERR_TIMEOUT);
+          s = __builtin_nanf("");
+          break;
+        }
+      }
     } while (!done);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
                                                      float slope, int rmse, float* __restrict__ z, float* __restrict__ out,
                                                      float* __restrict__ loss, float* __restrict__ demb,
                                                      float* __restrict__ slabs, int* __restrict__ sync,
-                                                     int* __restrict__ step_counter) {
+                                                     int* __restrict__ step_counter, float* __restrict__ sse_tail) {
   __shared__ HeadLds L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -265,10 +278,14 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     if (threadIdx.x == 0) {
       const float mse = total_sse / ((float)B * (float)C);
       const float lv = rmse ? sqrtf(mse) : mse;
-      L.bcast[0] = rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);   // dloss/dout = scale * diff
+      // dloss/dout = scale * diff.  HCG_HEAD_SSE: scale 1 -- the gradients leave as those of SSE / 2 and the batch's SSE and
+      // element count go to `sse_tail`: ranks of a data-parallel job sum both and scale once, which reproduces the gradient
+      // of sqrt(MSE) over the CONCATENATED batch exactly (hcg_sse_finalize / hcg_adam_step_dev_sse)
+      L.bcast[0] = rmse == HCG_HEAD_SSE ? 1.0f : rmse ? 1.0f / ((float)B * (float)C * lv) : 2.0f / ((float)B * (float)C);
       if (blockIdx.x == 0) {
         loss[0] = lv;
         loss[1] = mse;
+        if (sse_tail) { sse_tail[0] = total_sse; sse_tail[1] = (float)B * (float)C; }
         if (step_counter) step_counter[0] += 1;        // this training step's number, for the update launched later
       }
     }
@@ -413,13 +430,26 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     slab[RD * RK + idx] = gscale * (((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx]);
 }
 
-int head_grid(int64_t B) {
-  int dev = 0, cus = MAXGRID;
+// Workgroups that are certainly co-resident: the grid-wide exchange needs every workgroup of the launch on a CU at the
+// same time.  One per CU at most (70 KB of LDS each), and only if the occupancy query admits one at all; the guide's
+// SGPR cap min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)) is >= 7 for any kernel, far above the 1 used here.
+int head_resident_cap() {
+  static int cap = -1;      // queried once per process (also keeps the query out of a stream capture)
+  if (cap >= 0) return cap;
+  int dev = 0, cus = MAXGRID, per_cu = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_head, HW * 64, 0) != hipSuccess) per_cu = 0;
   if (cus > MAXGRID) cus = MAXGRID;
+  cap = per_cu >= 1 ? cus : 0;
+  return cap;
+}
+
+int head_grid(int64_t B) {
+  int cus = head_resident_cap();
+  if (cus < 1) cus = 1;     // (hcg_head_fwd_bwd refuses to launch when the cap is 0)
   int grid = (int)((B + RT - 1) / RT);
   if (grid > cus) grid = cus;
   return grid < 1 ? 1 : grid;
@@ -436,14 +466,25 @@ extern "C" int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W
                                 const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse, float* z,
                                 float* out, float* loss, float* demb, void* workspace, size_t workspace_bytes,
                                 int32_t* sync, int32_t* step_counter, hcg_stream_t stream) {
+  if (rmse != 0 && rmse != 1) return HCG_ERR_INVALID_ARG;
+  return hcg_head_fwd_bwd_ex(emb, y, W0, b0, W1, b1, B, D, C, slope, rmse, z, out, loss, demb, workspace, workspace_bytes, sync,
+                             step_counter, nullptr, stream);
+}
+
+extern "C" int hcg_head_fwd_bwd_ex(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
+                                   const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse, float* z,
+                                   float* out, float* loss, float* demb, void* workspace, size_t workspace_bytes,
+                                   int32_t* sync, int32_t* step_counter, float* sse_tail, hcg_stream_t stream) {
   if (!hcg_head_supported(D, C)) return HCG_ERR_UNSUPPORTED;
+  if (rmse < 0 || rmse > HCG_HEAD_SSE || (rmse == HCG_HEAD_SSE && !sse_tail)) return HCG_ERR_INVALID_ARG;
+  if (head_resident_cap() < 1) return HCG_ERR_UNSUPPORTED;   // not even one workgroup per CU: the exchange cannot run
   if (B <= 0 || !emb || !y || !W0 || !b0 || !W1 || !b1 || !z || !out || !loss || !demb || !workspace || !sync)
     return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
   const int grid = head_grid(B);
   float* slabs = (float*)workspace;
   hipLaunchKernelGGL(k_head, dim3(grid), dim3(HW * 64), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C, slope,
-                     rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter);
+                     rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter, sse_tail);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }

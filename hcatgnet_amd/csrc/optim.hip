@@ -54,16 +54,26 @@ namespace {
 
 // step count and learning rate read from device memory (hipGraph-capturable).  Bias corrections in double
 // like torch's host computation.  The last workgroup to take a ticket publishes step + 1.
-__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// SSE: `g` = [n summed SSE/2-gradients | SSE | count] (data-parallel form of the head, hcg_head_fwd_bwd_ex): the
+// gradient of sqrt(MSE) over all ranks' graphs is g * 1 / (count * sqrt(SSE / count)); written back in place.
+template <bool SSE>
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float b1,
-                                                  float b2, float eps, int* __restrict__ step_dev) {
+                                                  float b2, float eps, int* __restrict__ step_dev, float* __restrict__ loss) {
   const int t = step_dev[0] + 1;
   const float lr = lr_dev[0];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float gs = 1.0f;
+  if (SSE) {
+    const float sse = g[n], cnt = g[n + 1], mse = sse / cnt, lv = sqrtf(mse);
+    gs = 1.0f / (cnt * lv);
+    if (i == 0) { loss[0] = lv; loss[1] = mse; }
+  }
   if (i < n) {
     const float bc1 = (float)(1.0 - hcg_powi((double)b1, t));
     const float bc2_sqrt = (float)sqrt(1.0 - hcg_powi((double)b2, t));
-    const float gi = g[i];
+    const float gi = g[i] * gs;
+    if (SSE) g[i] = gi;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi;
@@ -87,8 +97,34 @@ extern "C" int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg
                                  const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev,
                                  hcg_stream_t stream) {
   if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, lr_dev, beta1, beta2, eps, (int*)step_dev);
+  hipLaunchKernelGGL(k_adam_dev<false>, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param,
+                     const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, (int*)step_dev, nullptr);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+extern "C" int hcg_adam_step_dev_sse(float* param, float* flat, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                     const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, float* loss,
+                                     hcg_stream_t stream) {
+  if (n <= 0 || !param || !flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || !loss) return HCG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_adam_dev<true>, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, flat,
+                     exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, (int*)step_dev, loss);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_sse_finalize(float* __restrict__ g, int64_t n, float* __restrict__ loss) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float sse = g[n], cnt = g[n + 1], mse = sse / cnt, lv = sqrtf(mse);
+  if (i == 0) { loss[0] = lv; loss[1] = mse; }
+  if (i < n) g[i] *= 1.0f / (cnt * lv);
+}
+}  // namespace
+
+extern "C" int hcg_sse_finalize(float* flat, int64_t n, float* loss, hcg_stream_t stream) {
+  if (n <= 0 || !flat || !loss) return HCG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_sse_finalize, dim3((unsigned)hcg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, flat, n, loss);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }

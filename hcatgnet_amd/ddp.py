@@ -5,11 +5,15 @@ F_in = D = 64) over RCCL/xGMI (`torch.distributed` backend "nccl" is RCCL on ROC
 The reference has no distributed code at all (single process, scripts_experiments/train_GNN.py:29);
 this wrapper is build-defined.  Graphs never exchange messages across ranks (block-
 diagonal adjacency), so nothing else crosses GPUs: no graph partitioning, no halo, no activation
-collective.  Gradient semantics: every rank computes sqrt(MSE) over ITS graphs; `reduce_gradients`
-averages the per-rank gradients (DDP convention).  That equals the single-process gradient of the
-mean of per-rank RMSEs, not of the RMSE over the concatenated batch; `combine="sse"` instead
-reproduces the concatenated-batch gradient exactly by all-reducing sum-of-squared-error gradients
-and the SSE itself (one extra scalar in the same buffer).
+collective.  Gradient semantics, `combine=`:
+  "mean"  every rank computes sqrt(MSE) over ITS graphs; the per-rank gradients are averaged (DDP
+          convention) = the single-process gradient of the MEAN OF PER-RANK RMSEs;
+  "sse"   the fused head leaves the gradients of SSE / 2 and [SSE, count] behind the flat buffer; ONE
+          all-reduce(sum) of the n + 2 floats, then one scale 1 / (count * sqrt(SSE / count)) = the
+          gradient of sqrt(MSE) over the CONCATENATED batch of all ranks -- exactly what the reference's
+          single-device step (utils/utils_model.py:64-65) computes on that batch; ranks may hold different
+          numbers of graphs.  Fused trainer only (`attach` / `make_train_step`).
+Both are tested against the CPU oracle with two ranks (tests/test_gpu_ddp.py).
 """
 from __future__ import annotations
 
@@ -21,8 +25,11 @@ import torch.nn as nn
 
 
 class DataParallelGCN(nn.Module):
-    def __init__(self, module: nn.Module, process_group=None, force_collective: bool = False):
+    def __init__(self, module: nn.Module, process_group=None, force_collective: bool = False, combine: str = "mean"):
         super().__init__()
+        if combine not in ("mean", "sse"):
+            raise ValueError(f"combine must be 'mean' or 'sse', got {combine!r}")
+        self.combine = combine
         self.module = module
         self.process_group = process_group
         self.force_collective = force_collective   # run the collectives even at world size 1 (tests)
@@ -108,6 +115,25 @@ class DataParallelGCN(nn.Module):
                     flat.div_(ws)
         self._flat, self._inplace = flat, True
         return flat
+
+    def reduce_flat_sum(self, flat_ext: torch.Tensor) -> torch.Tensor:
+        """The `grad_sync` hook of the "sse" form: all-reduce(SUM) of [gradients | SSE | count], in place, no division
+        (the one scale that follows is computed from the summed SSE and count)."""
+        return self.reduce_flat(flat_ext, average=False)
+
+    def attach(self, step):
+        """Make a `train.FusedTrainStep` on this module data parallel with this wrapper's `combine` semantics."""
+        if step.model is not self.module:
+            raise ValueError("the trainer belongs to another module")
+        if self.combine == "sse" and not step.rmse:
+            raise ValueError("combine='sse' needs rmse=True")
+        step.combine = self.combine
+        step.grad_sync = self.reduce_flat_sum if self.combine == "sse" else self.reduce_flat
+        return step
+
+    def make_train_step(self, **kw):
+        from .train import FusedTrainStep
+        return self.attach(FusedTrainStep(self.module, **kw))
 
     def reduce_gradients(self, average: bool = True, grads=None) -> torch.Tensor:
         """All-reduce(sum) the flat gradient, divide by world size, re-attach the views as .grad."""

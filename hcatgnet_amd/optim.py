@@ -161,6 +161,31 @@ class FusedAdam(torch.optim.Optimizer):
                                              fl["step_dev"].data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam")
         return True
 
+    def step_sse(self, flat_ext: torch.Tensor, loss_buf: torch.Tensor):
+        """Data-parallel "sse" form (train.FusedTrainStep combine="sse"): `flat_ext` = [summed SSE/2-gradients | SSE |
+        count], the parameters' `.grad` being views of its first n floats.  ONE launch scales the gradients in place to
+        those of sqrt(MSE) over all ranks' graphs, stores that loss in `loss_buf[0:2]` and applies the update."""
+        if not self.capturable or len(self.param_groups) != 1:
+            raise _lib.HcgError("FusedAdam.step_sse needs the capturable mode and one parameter group")
+        group = self.param_groups[0]
+        ps = [p for p in group["params"] if p.requires_grad]
+        _lib.require_gpu(*ps)
+        fl = self._flat.get(0)
+        if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
+            with torch.no_grad():
+                fl = self._rebase(0, group)
+        if flat_ext.numel() != fl["n"] + 2 or flat_ext.dtype != torch.float32 or not flat_ext.is_contiguous():
+            raise _lib.HcgError("FusedAdam.step_sse: the flat buffer must hold n gradients + [SSE, count]")
+        self._make_dev_state(fl, group)
+        (b1, b2), eps, lr = group["betas"], float(group["eps"]), float(group["lr"])
+        if fl["lr_host"] != lr:
+            fl["lr_host"] = lr
+            fl["lr_dev"].fill_(lr)
+        lib = _lib.load()
+        _lib.check(lib.hcg_adam_step_dev_sse(fl["p"].data_ptr(), flat_ext.data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(),
+                                             fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps, fl["step_dev"].data_ptr(),
+                                             loss_buf.data_ptr(), _lib.stream_ptr()), "hcg_adam_step_dev_sse")
+
     @staticmethod
     def _grads_flat(grads) -> bool:
         g0, off = grads[0], 0

@@ -24,33 +24,12 @@ the autograd path with the same arithmetic contract.
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Optional
 
 import torch
 
 from . import _lib
 from . import functional as HF
-
-_SYNC_WORDS = {}
-
-
-# development switches (A/B measurements only): HCG_NO_POOLBITS=1 stores the pooled layer's activations as the plain
-# forms do, HCG_NO_PREMASK=1 leaves every activation derivative to the layer that owns it
-_POOLBITS = os.environ.get("HCG_NO_POOLBITS", "0") != "1"
-_PREMASK = os.environ.get("HCG_NO_PREMASK", "0") != "1"
-
-
-def _sync_words(dev: torch.device) -> torch.Tensor:
-    """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: one once-zeroed set per device (launches on one
-    device are stream-ordered in this package)."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    t = _SYNC_WORDS.get(key)
-    if t is None:
-        t = torch.zeros(520, dtype=torch.int32, device=dev)
-        _SYNC_WORDS[key] = t
-    return t
-
 
 class FusedTrainStep:
     """One training step of the reference's loop as 6 enqueued launches (small-graph tiles; n_conv + 4 in general), no autograd, no host sync.
@@ -60,16 +39,55 @@ class FusedTrainStep:
 
     `rmse=True` is the reference's `torch.sqrt(model.loss(...))`; `optimizer_step=False` stops after the backward
     (gradients in `model.parameters()[i].grad`, views of one flat buffer); `grad_sync` is called with the flat gradient
-    between backward and optimiser (data parallel: `DataParallelGCN.reduce_flat`).
+    between backward and optimiser (data parallel: `DataParallelGCN.attach(step)` sets it).
+
+    `combine` (data parallel, needs rmse): "mean" = every rank's own sqrt(MSE), gradients averaged (DDP convention);
+    "sse" = the head leaves the gradients of SSE / 2 plus [SSE, count] behind the flat buffer, `grad_sync` SUMS all of it
+    over the ranks and ONE scale 1 / (count * sqrt(SSE / count)) gives the gradient of sqrt(MSE) over the concatenated
+    batch of all ranks -- what the reference's step computes on one device (utils/utils_model.py:64-65); the loss returned
+    is then that global loss.
+
+    Every instance owns its exchange words for the head kernel's grid-wide sum (`check_health()` reports a timed-out
+    exchange): two trainers may run on two streams at once.
     """
 
-    def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None):
+    # development switches for A/B measurements (tools/ab_env.sh sets them from the environment; never set in product
+    # code): POOLBITS = False stores the pooled layer's activations as the plain forms do, PREMASK = False leaves every
+    # activation derivative to the layer that owns it
+    POOLBITS = True
+    PREMASK = True
+
+    def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None, combine: str = "mean"):
+        if combine not in ("mean", "sse"):
+            raise ValueError(f"combine must be 'mean' or 'sse', got {combine!r}")
+        if combine == "sse" and not rmse:
+            raise ValueError("combine='sse' reproduces sqrt(MSE) over the concatenated batch: it needs rmse=True")
         self.model, self.rmse, self.optimizer_step, self.grad_sync = model, rmse, optimizer_step, grad_sync
+        self.combine = combine
         if optimizer_step and hasattr(model.optimizer, "enable_capturable"):
             model.optimizer.enable_capturable()     # step count / lr in device memory: same launches eager and captured
         self._bufs = {}
         self._graph = None
-        self._graph_key = None
+        self._sync = {}
+        self._capturing_split = False
+
+    def _sync_words(self, dev: torch.device) -> torch.Tensor:
+        """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
+        share a set must be stream-ordered; a trainer issues its launches on one stream at a time)."""
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        t = self._sync.get(key)
+        if t is None:
+            t = self._sync[key] = torch.zeros(_lib.HCG_HEAD_SYNC_WORDS, dtype=torch.int32, device=dev)
+        return t
+
+    def check_health(self):
+        """Synchronising read of the head kernel's error word: raises if a grid-wide exchange timed out (the losses of
+        that step are NaN).  The words are re-zeroed so the trainer can be used again."""
+        for t in self._sync.values():
+            if int(t[1].item()) & _lib.HCG_HEAD_ERR_TIMEOUT:
+                t.zero_()
+                raise _lib.HcgError("hcg_head_fwd_bwd: the grid-wide exchange timed out (workgroups not co-resident, or "
+                                    "launches of two streams sharing one set of sync words); losses of that step are NaN")
 
     # ------------------------------------------------------------------ support check (host only)
     @staticmethod
@@ -120,6 +138,7 @@ class FusedTrainStep:
                    "z": torch.empty(capB, D, **f32), "out": torch.empty(capB, C, **f32), "loss": torch.empty(2, **f32),
                    "ws_head": torch.empty(hb, dtype=torch.uint8, device=dev), "ws": {}}
             self._bufs = {"cap": cap}
+            self._graph = None                          # a captured graph holds the old buffers' addresses
         b = self._bufs.get(key)
         if b is None:
             b = {"acts": [t[:N] for t in cap["acts"]], "dacts": [t[:N] for t in cap["dacts"]], "emb": cap["emb"][:B],
@@ -129,11 +148,15 @@ class FusedTrainStep:
         return b
 
     def _flat_grads(self, params, dev):
+        """ONE flat gradient buffer in parameter order (+ two floats behind it: [SSE, count] of the data-parallel "sse"
+        form); the parameters' `.grad` are (re-)attached as views of it."""
         n = sum(p.numel() for p in params)
         flat = getattr(self, "_flat", None)
         if flat is None or flat.numel() != n or flat.device != dev:
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            self._flat_ext = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+            flat = self._flat_ext[:n]
             self._flat = flat
+            self._graph = None
             off = 0
             for p in params:                      # .grad = view of the flat buffer, parameter order
                 p.grad = flat[off:off + p.numel()].view_as(p)
@@ -183,7 +206,7 @@ class FusedTrainStep:
         # ---- forward (conv stack + pooling).  Small-graph tiles: the pooled layer's activations stay on chip, two bits
         #      per element (sign, is-the-column-max) are all its backward needs of them
         poolbits = None
-        if gpts[-1] > 0 and _POOLBITS:
+        if gpts[-1] > 0 and self.POOLBITS:
             nb = lib.hcg_fused_poolbits_bytes(B, gpts[-1])
             poolbits = bufs["ws"].get("poolbits")
             if poolbits is None or poolbits.numel() < nb:
@@ -231,13 +254,17 @@ class FusedTrainStep:
             g = lambda prm: p(views[id(prm)])
             # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
             # advances the step number that launch reads
-            if self.optimizer_step and self.grad_sync is None and hasattr(opt, "fused_update_ready"):
+            if (self.optimizer_step and self.grad_sync is None and self.combine == "mean" and not self._capturing_split
+                    and hasattr(opt, "fused_update_ready")):
                 step_word = opt.fused_update_ready(flat)
-        rc = lib.hcg_head_fwd_bwd(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
-                                  p(HF._f32c(l1.bias)), B, D, C, slope, int(self.rmse), p(bufs["z"]), p(bufs["out"]),
-                                  p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
-                                  p(_sync_words(dev)), p(step_word), stream)
-        _lib.check(rc, "hcg_head_fwd_bwd")
+        sse = self.combine == "sse" and not _forward_only
+        mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
+        tail = self._flat_ext[flat.numel():] if sse else None
+        rc = lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
+                                     p(HF._f32c(l1.bias)), B, D, C, slope, mode, p(bufs["z"]), p(bufs["out"]),
+                                     p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
+                                     p(self._sync_words(dev)), p(step_word), p(tail), stream)
+        _lib.check(rc, "hcg_head_fwd_bwd_ex")
         if _forward_only:
             self.last_out = bufs["out"]
             return bufs["loss"][0]
@@ -263,7 +290,7 @@ class FusedTrainStep:
             last = l == n_conv - 1
             up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
             if small and last and poolbits is not None:
-                premasked = _PREMASK and l > 0
+                premasked = self.PREMASK and l > 0
                 rc = lib.hcg_fused_layer_bwd_poolbits(p(bufs["demb"]), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E,
                                                       p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
                                                       1 | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
@@ -272,7 +299,7 @@ class FusedTrainStep:
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
             elif small:
                 act = 0 if premasked else 1
-                premasked = _PREMASK and l > 0
+                premasked = self.PREMASK and l > 0
                 rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
                                              plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
                                              act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
@@ -281,7 +308,7 @@ class FusedTrainStep:
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
             else:
                 act = 0 if premasked else 1
-                premasked = _PREMASK and l > 0
+                premasked = self.PREMASK and l > 0
                 rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
                                            plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope,
                                            act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
@@ -297,12 +324,34 @@ class FusedTrainStep:
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
-            if self.grad_sync is not None:
-                self.grad_sync(flat)
-            if self.optimizer_step:
-                opt.step()
+            if not self._capturing_split:
+                self._exchange_and_update(bufs["loss"])
         self.last_out = bufs["out"]
         return bufs["loss"][0]
+
+    def _exchange_and_update(self, loss_buf):
+        """Behind the slab reduction: gradient exchange (data parallel), the "sse" scale, the optimiser."""
+        lib, opt, flat = _lib.load(), self.model.optimizer, self._flat
+        if self.combine == "sse":
+            ext = self._flat_ext
+            if self.grad_sync is not None:
+                self.grad_sync(ext)                          # SUM of [gradients | SSE | count] over the ranks
+            if self.optimizer_step and hasattr(opt, "step_sse"):
+                self._flat_grads([q for q in self.model.parameters() if q.requires_grad], flat.device)
+                opt.step_sse(ext, loss_buf)                  # scale + update, one launch
+            else:
+                _lib.check(lib.hcg_sse_finalize(_lib.ptr(ext), flat.numel(), _lib.ptr(loss_buf), _lib.stream_ptr()),
+                           "hcg_sse_finalize")
+                if self.optimizer_step:
+                    opt.step()
+            return
+        if self.grad_sync is not None:
+            self.grad_sync(flat)
+        if self.optimizer_step:
+            # the update reads the parameters' `.grad`: they must be views of THIS trainer's buffer (another trainer on
+            # the same model may have re-pointed them since)
+            self._flat_grads([q for q in self.model.parameters() if q.requires_grad], flat.device)
+            opt.step()
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, batch):
@@ -318,7 +367,18 @@ class FusedTrainStep:
                 raise _lib.HcgError("capture() with optimizer_step needs hcatgnet_amd.optim.FusedAdam")
             opt.enable_capturable()
         sync, do_opt = self.grad_sync, self.optimizer_step
-        get = batch if callable(batch) else (lambda: batch)
+
+        def get():
+            if callable(batch):
+                return batch()
+            # a fixed Batch object: drop its cached plan so that the plan build (graph_ptr / edge_ptr from the int64
+            # batch vector and edge_index) is enqueued -- and captured -- every time; replay() then follows whatever
+            # graph boundaries the tensors hold.  max_nodes / max_edges of `batch` act as capacities.
+            try:
+                batch._hcg_plan = None
+            except Exception:
+                pass
+            return batch
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -326,26 +386,44 @@ class FusedTrainStep:
                 self(get())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        split = sync is not None
         try:
             self.grad_sync = None
-            self.optimizer_step = do_opt and sync is None
+            self._capturing_split = split              # with an exchange, the graph ends after the slab reduction
             g_main = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_main):
                 loss = self(get())
         finally:
-            self.grad_sync, self.optimizer_step = sync, do_opt
-        self._graph = (g_main, loss)
+            self.grad_sync, self._capturing_split = sync, False
+        self._graph = (g_main, loss, split, self._graph_fingerprint())
         return self
 
+    def _graph_fingerprint(self):
+        """Addresses a captured graph has baked in and that later calls could replace: step buffers, flat gradient,
+        the optimiser's flat parameter / moment storages."""
+        cap = self._bufs.get("cap")
+        fp = [t.data_ptr() for t in cap["acts"] + cap["dacts"]] if cap else []
+        fp.append(self._flat.data_ptr() if getattr(self, "_flat", None) is not None else 0)
+        fl = getattr(self.model.optimizer, "_flat", {}).get(0) if self.optimizer_step else None
+        if fl is not None:
+            fp += [fl["p"].data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr()]
+        fp += [q.data_ptr() for q in self.model.parameters()]
+        return tuple(fp)
+
     def replay(self):
-        g_main, loss = self._graph
+        if self._graph is None:
+            raise _lib.HcgError("replay(): no captured step (never captured, or its buffers were re-allocated by a larger "
+                                "eager batch): call capture() again")
+        g_main, loss, split, fp = self._graph
+        if fp != self._graph_fingerprint():
+            self._graph = None
+            raise _lib.HcgError("replay(): parameter / optimiser / step buffers changed since capture() "
+                                "(load_state_dict, a larger eager batch): call capture() again")
         if self.optimizer_step:
             self.model.optimizer.sync_lr()
         g_main.replay()
-        if self.grad_sync is not None:               # exchange between the captured backward and the update:
-            self.grad_sync(self._flat)               # one collective on the flat gradient, then ONE eager launch
-            if self.optimizer_step:
-                self.model.optimizer.step()
+        if split:                                     # exchange between the captured backward and the update:
+            self._exchange_and_update(loss_buf=self._bufs["cap"]["loss"])   # one collective, then ONE eager launch
         return loss
 
 

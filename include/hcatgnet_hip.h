@@ -262,11 +262,16 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
  *   workspace          : gradient slabs (describe them with hcg_head_reduce_job, sum with hcg_reduce_slabs)
  *   sync               : HCG_HEAD_SYNC_WORDS int32 device words, all zero before the first launch ever and owned
  *                        by this entry point afterwards (state of the grid-wide exchange of the squared-error
- *                        partials; launches sharing it must be stream-ordered)
+ *                        partials).  Launches that share one set of words MUST be stream-ordered: give every stream
+ *                        (every trainer) its own set.  The exchange is bounded: a workgroup that has waited 2 s ORs
+ *                        HCG_HEAD_ERR_TIMEOUT into sync[1] and the launch ends with a NaN loss instead of hanging;
+ *                        after that the words must be re-zeroed before they are used again
  *   step_counter       : nullable; one int32 device word incremented by 1 per launch -- the number of the training
  *                        step, read later in the same step by hcg_reduce_slabs_adam
  * y is [B,C] like out.  D = 64, C <= 8 (hcg_head_supported). */
 #define HCG_HEAD_SYNC_WORDS 520
+#define HCG_HEAD_ERR_TIMEOUT 1 /* bit of sync[1] */
+#define HCG_HEAD_SSE 2         /* value of `rmse` for hcg_head_fwd_bwd_ex: see there */
 int hcg_head_supported(int64_t D, int64_t C);
 size_t hcg_head_workspace_bytes(int64_t B);
 int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
@@ -274,6 +279,19 @@ int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const fl
                      float* z, float* out, float* loss, float* demb,
                      void* workspace, size_t workspace_bytes, int32_t* sync, int32_t* step_counter /*nullable*/,
                      hcg_stream_t stream);
+
+/* The same launch with the data-parallel "sum of squared errors" form: rmse = HCG_HEAD_SSE leaves every gradient
+ * (demb and the slabs) as that of SSE / 2 -- dloss/dout = (out - y), no batch-dependent factor -- and stores the
+ * batch's SSE and its element count B * C in sse_tail[0..1] (the two floats behind the flat gradient buffer).  Ranks sum
+ * gradients, SSE and count (ONE all-reduce) and hcg_sse_finalize / hcg_adam_step_dev_sse scale by
+ * 1 / (count * sqrt(SSE / count)): the gradient of sqrt(MSE) over the concatenated batch of all ranks, which is what
+ * the reference's step computes on one device (utils/utils_model.py:64-65).  rmse = 0 / 1 as hcg_head_fwd_bwd
+ * (sse_tail nullable; written when given). */
+int hcg_head_fwd_bwd_ex(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
+                        const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
+                        float* z, float* out, float* loss, float* demb,
+                        void* workspace, size_t workspace_bytes, int32_t* sync, int32_t* step_counter /*nullable*/,
+                        float* sse_tail /*nullable unless rmse = HCG_HEAD_SSE*/, hcg_stream_t stream);
 
 /* ---- MSE loss (a12 / f2): loss[0] = mean((a - b)^2) over n elements, fixed-order reduction;
  *      backward: da = grad_loss[0] * 2 (a - b) / n, db = -da (either may be NULL). */
@@ -323,6 +341,14 @@ int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * `lr_dev[0]` = learning rate (the host rewrites it when a scheduler changes it). */
 int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, hcg_stream_t stream);
+
+/* Data-parallel SSE form (hcg_head_fwd_bwd_ex): `flat` = [n summed SSE/2-gradients | SSE | count].  Scales the n
+ * gradients in place by 1 / (count * L), L = sqrt(SSE / count), and stores loss[0] = L, loss[1] = SSE / count.
+ * hcg_adam_step_dev_sse does the same and applies hcg_adam_step_dev's update with the scaled gradient: one launch. */
+int hcg_sse_finalize(float* flat, int64_t n, float* loss, hcg_stream_t stream);
+int hcg_adam_step_dev_sse(float* param, float* flat, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, float* loss,
+                          hcg_stream_t stream);
 
 /* hcg_reduce_slabs with the Adam update fused in: every reduced gradient element is stored at its place in the flat
  * gradient buffer [grad_flat, grad_flat + n) -- each segment's dst must point into it -- and the parameter / moments

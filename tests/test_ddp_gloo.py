@@ -51,7 +51,11 @@ def _worker(rank, world, port, q):
         fb = torch.full((16641,), float(rank + 1))
         out = dp.reduce_flat(fb)
         ok_hook = out.data_ptr() == fb.data_ptr() and torch.allclose(fb, torch.full_like(fb, 1.5))
-        q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum, ok_hook))
+        # the "sse" form's hook: [gradients | SSE | count] is SUMMED over the ranks, never divided
+        ext = torch.full((16643,), float(rank + 1))
+        out2 = dp.reduce_flat_sum(ext)
+        ok_sse = out2.data_ptr() == ext.data_ptr() and torch.allclose(ext, torch.full_like(ext, 3.0))
+        q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum, ok_hook, ok_sse))
     finally:
         dist.destroy_process_group()
 

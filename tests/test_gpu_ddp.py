@@ -1,0 +1,264 @@
+"""Data-parallel step on the GPU: the REAL step -- fused forward / backward kernels, flat gradient buffer,
+exchange, update -- split over two ranks must reproduce the single-process gradient:
+  combine="mean"  the gradient of the MEAN OF PER-RANK sqrt(MSE)           (DDP convention)
+  combine="sse"   the gradient of sqrt(MSE) over the CONCATENATED batch    (the reference's single-device step,
+                                                                            utils/utils_model.py:64-65, at batch 2B)
+both against the CPU oracle's autograd (nothing in the reference pins gradients: the oracle is the checker).
+A one-GPU box cannot run two RCCL ranks on one device, so the two ranks of `test_two_ranks_*` share cuda:0 and
+exchange through gloo (the rehearsal `tools/rehearse_multi_rank.sh` uses too); the exchange code above the backend is
+the same.  Plus the robustness items of the trainer: capture on a fixed Batch object, two trainers on one model, two
+trainers on two streams, stale graphs."""
+import os
+import socket
+
+import pytest
+import torch
+
+from tests.helpers import rel_inf
+from tests.test_gpu_parity import H, oracle  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _halves(sb, H):
+    """Split a synthetic batch into two batches of whole graphs (first / second half)."""
+    from hcatgnet_amd.batch import collate
+    gl = sb.as_graph_list()
+    k = len(gl) // 2
+    return collate(gl[:k]), collate(gl[k:])
+
+
+def _oracle_of(oracle, params, b):
+    return oracle.train_step_grads(params, b.x, b.edge_index, b.batch, b.y, b.num_graphs, dtype=torch.float64)
+
+
+def _grads(m):
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+def test_sse_form_on_one_rank_equals_the_plain_step(H, oracle):
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=192)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    plain = FusedTrainStep(m, optimizer_step=False)
+    sse = FusedTrainStep(m, optimizer_step=False, combine="sse")
+    l0 = float(plain(sb.as_batch("cuda"))); g0 = _grads(m)
+    l1 = float(sse(sb.as_batch("cuda"))); g1 = _grads(m)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for k in g0:
+        assert rel_inf(g1[k], g0[k]) <= 2e-6, k
+    # ... and with the update: the same parameters after three steps
+    ma = H.make_network("GCN", H.default_options(), 64).cuda()
+    mb = H.make_network("GCN", H.default_options(), 64).cuda()
+    mb.load_state_dict(ma.state_dict())
+    sa, sb2 = FusedTrainStep(ma), FusedTrainStep(mb, combine="sse")
+    for _ in range(3):
+        la, lb = float(sa(sb.as_batch("cuda"))), float(sb2(sb.as_batch("cuda")))
+        assert abs(la - lb) <= 1e-5 * abs(la)
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert rel_inf(pb, pa) <= 1e-5
+
+
+def test_sse_halves_summed_by_hand_give_the_concatenated_batch_gradient(H, oracle):
+    """One process plays both ranks: half A's [gradients | SSE | count] is kept, half B's exchange hook adds it --
+    exactly what the all-reduce(sum) leaves on every rank -- and the one scale must give the oracle's gradient of
+    sqrt(MSE) over all graphs.  The halves have DIFFERENT numbers of graphs."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=96)
+    gl = sb.as_graph_list()
+    a, b = collate(gl[:40]), collate(gl[40:])
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    kept = {}
+    step_a = FusedTrainStep(m, optimizer_step=False, combine="sse", grad_sync=lambda ext: kept.__setitem__("a", ext.clone()))
+    step_a(a.to("cuda"))
+    step_b = FusedTrainStep(m, optimizer_step=False, combine="sse", grad_sync=lambda ext: ext.add_(kept["a"]))
+    loss = float(step_b(b.to("cuda")))
+    l_ref, _, _, g_ref = _oracle_of(oracle, params, collate(gl))
+    assert abs(loss - float(l_ref)) <= 1e-6 * abs(float(l_ref))
+    for k, p in m.named_parameters():
+        assert rel_inf(p.grad, g_ref[k]) <= 1e-5, k
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, combine, q):
+    """One rank of the two-rank job: its half of the batch through the real fused step, gloo exchange on cuda:0."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hcatgnet_amd as H
+        from hcatgnet_amd import synth
+        from hcatgnet_amd.batch import collate
+        from hcatgnet_amd.ddp import DataParallelGCN
+        sb = synth.make_config("C2", num_graphs=128)
+        gl = sb.as_graph_list()
+        mine = collate(gl[:64] if rank == 0 else gl[64:]).to("cuda")
+        torch.manual_seed(1234 + rank)                      # ranks start from DIFFERENT weights: the wrapper re-syncs them
+        m = H.make_network("GCN", H.default_options(global_seed=1234 + rank), 64).cuda()
+        dp = DataParallelGCN(m, combine=combine)
+        w0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        step = dp.make_train_step(optimizer_step=False)
+        loss = float(step(mine))
+        grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        # the same step captured (graph ends before the exchange) must give the same gradients
+        cap = dp.make_train_step(optimizer_step=False)
+        cap.grad_sync = lambda flat: None
+        cap.capture(mine)
+        dp.attach(cap)
+        loss_c = float(cap.replay())
+        grads_c = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        # and a full data-parallel training step keeps the ranks' weights identical
+        tr = dp.make_train_step()
+        for _ in range(2):
+            tr(mine)
+        w_after = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+        q.put((rank, w0, loss, grads, loss_c, grads_c, w_after))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("combine", ["mean", "sse"])
+def test_two_ranks_real_step_equals_the_single_process_gradient(H, oracle, combine):
+    import torch.multiprocessing as mp
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, combine, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, w0, l0, g0, lc0, gc0, wa0), (_, w1, l1, g1, lc1, gc1, wa1) = res
+    for k in w0:                                            # rank 0's weights were broadcast
+        assert torch.equal(w0[k], w1[k]), k
+    sb = synth.make_config("C2", num_graphs=128)
+    gl = sb.as_graph_list()
+    a, b, whole = collate(gl[:64]), collate(gl[64:]), collate(gl)
+    if combine == "sse":        # gradient of sqrt(MSE) over the concatenated batch; every rank reports that loss
+        l_ref, _, _, g_ref = _oracle_of(oracle, w0, whole)
+        assert abs(l0 - float(l_ref)) <= 1e-6 * abs(float(l_ref)) and abs(l1 - float(l_ref)) <= 1e-6 * abs(float(l_ref))
+    else:                       # gradient of the mean of the two ranks' own sqrt(MSE)
+        la, _, _, ga = _oracle_of(oracle, w0, a)
+        lb, _, _, gb = _oracle_of(oracle, w0, b)
+        g_ref = {k: 0.5 * (ga[k] + gb[k]) for k in ga}
+        assert abs(l0 - float(la)) <= 1e-6 * abs(float(la)) and abs(l1 - float(lb)) <= 1e-6 * abs(float(lb))
+    for k in g_ref:
+        # 1e-6 of the gradient's scale for the small tensors; weight gradients sum ~4e3 node terms in fp32 (<= 1e-5)
+        tol = 1e-6 if g_ref[k].numel() <= 64 else 1e-5
+        for g in (g0, g1, gc0, gc1):
+            assert rel_inf(g[k], g_ref[k]) <= tol, (k, rel_inf(g[k], g_ref[k]))
+        assert torch.equal(g0[k], g1[k]), k                 # both ranks hold the SAME bits after the exchange
+    assert abs(lc0 - l0) <= 1e-6 * abs(l0) and abs(lc1 - l1) <= 1e-6 * abs(l1)
+    assert torch.equal(wa0, wa1)                            # two full DP steps: weights stay bitwise in sync
+
+
+def test_capture_on_a_fixed_batch_object_follows_new_graph_boundaries(H, oracle):
+    """capture(batch) with a Batch OBJECT must capture the plan build too.  Capture on one ragged batch, copy a
+    differently partitioned batch of the same N / E / B into the tensors, replay: the result must be the second batch's."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=64, nodes=26, nodes_jitter=5, seed=5)
+    gl = sb.as_graph_list()
+    first = collate(gl)
+    second = collate(gl[::-1])                              # same graphs, reversed order: same N / E / B, other boundaries
+    assert first.num_nodes == second.num_nodes and not torch.equal(first.batch, second.batch)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    dev = first.to("cuda")
+    step = FusedTrainStep(m, optimizer_step=False)
+    step.capture(dev)
+    l1 = float(step.replay())
+    ref1 = _oracle_of(oracle, params, first)
+    assert abs(l1 - float(ref1[0])) <= 1e-5 * abs(float(ref1[0]))
+    for name in ("x", "edge_index", "batch", "y"):
+        getattr(dev, name).copy_(getattr(second, name).to("cuda"))
+    l2 = float(step.replay())
+    ref2 = _oracle_of(oracle, params, second)
+    assert abs(l2 - float(ref2[0])) <= 1e-5 * abs(float(ref2[0]))
+    for k, p in m.named_parameters():
+        assert rel_inf(p.grad, ref2[3][k]) <= 1e-5, k
+
+
+def test_two_trainers_on_one_model_interleaved_use_their_own_gradients(H):
+    """`replay()` / the eager exchange branch must update from THIS trainer's flat buffer even when another
+    trainer on the same model ran last (it re-points the parameters' .grad)."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sa, sb = synth.make_config("C2", num_graphs=128), synth.make_config("C2", num_graphs=128, seed=77)
+    ba, bb = sa.as_batch("cuda"), sb.as_batch("cuda")
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    nothing = lambda flat: None                             # an exchange hook: reduction and update are separate launches
+    ta = FusedTrainStep(m, grad_sync=nothing)
+    tb = FusedTrainStep(m, grad_sync=nothing)
+    ta.capture(lambda: ba)                                  # (each capture runs two warm-up steps on m)
+    tb.capture(lambda: bb)
+    ref = H.make_network("GCN", H.default_options(), 64).cuda()
+    ref.load_state_dict(m.state_dict())
+    ref.optimizer.load_state_dict(m.optimizer.state_dict())
+    one = FusedTrainStep(ref)
+    want = [float(one(b)) for b in (ba, bb, ba, bb)]
+    got = [float(ta.replay()), float(tb(bb)), float(ta.replay()), float(tb.replay())]
+    for u, v in zip(want, got):
+        assert abs(u - v) <= 1e-5 * abs(u), (want, got)
+    for pa, pb in zip(m.parameters(), ref.parameters()):
+        assert rel_inf(pa, pb) <= 1e-5
+
+
+def test_two_trainers_on_two_streams_do_not_share_exchange_words(H):
+    """every trainer owns its sync words, so two head launches in flight on two streams neither hang
+    nor mix their partial sums: the interleaved losses equal the single-stream ones."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sa, sb = synth.make_config("C2", num_graphs=4096), synth.make_config("C2", num_graphs=4096, seed=3)
+    ba, bb = sa.as_batch("cuda"), sb.as_batch("cuda")
+    ma = H.make_network("GCN", H.default_options(), 64).cuda()
+    mb = H.make_network("GCN", H.default_options(), 64).cuda()
+    ta, tb = FusedTrainStep(ma, optimizer_step=False), FusedTrainStep(mb, optimizer_step=False)
+    la, lb = float(ta(ba)), float(tb(bb))                   # single stream
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            xa = ta(ba)
+        with torch.cuda.stream(s2):
+            xb = tb(bb)
+        got.append((xa, xb))
+    torch.cuda.synchronize()
+    ta.check_health(); tb.check_health()
+    assert ta._sync_words(torch.device("cuda", 0)).data_ptr() != tb._sync_words(torch.device("cuda", 0)).data_ptr()
+    assert abs(float(got[-1][0]) - la) <= 1e-6 * abs(la) and abs(float(got[-1][1]) - lb) <= 1e-6 * abs(lb)
+
+
+def test_replay_refuses_a_stale_graph(H):
+    from hcatgnet_amd import _lib, synth
+    from hcatgnet_amd.train import FusedTrainStep
+    small, big = synth.make_config("C2", num_graphs=64), synth.make_config("C2", num_graphs=256)
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    step = FusedTrainStep(m)
+    bs = small.as_batch("cuda")
+    step.capture(lambda: bs)
+    step.replay()
+    step(big.as_batch("cuda"))                              # a larger eager batch re-allocates the step buffers
+    with pytest.raises(_lib.HcgError):
+        step.replay()
+    step.capture(lambda: bs)
+    step.replay()
+    m.optimizer.load_state_dict(m.optimizer.state_dict())   # new flat moment storages
+    with pytest.raises(_lib.HcgError):
+        step.replay()

@@ -20,7 +20,6 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
     """out / loss / demb / weight gradients of hcg_head_fwd_bwd vs torch fp64 autograd of
     sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes workgroups loop over several tiles."""
     from hcatgnet_amd import _lib
-    from hcatgnet_amd.train import _sync_words
     lib = _lib.load()
     g = torch.Generator().manual_seed(7 * B + C)
     emb = torch.randn(B, 128, generator=g); W0 = torch.randn(64, 128, generator=g) * 0.1; b0 = torch.randn(64, generator=g) * 0.1
@@ -30,7 +29,7 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
     demb = torch.empty(B, 128, device="cuda")
     wsb = lib.hcg_head_workspace_bytes(B)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    sync = _sync_words(torch.device("cuda", torch.cuda.current_device()))
+    sync = torch.zeros(_lib.HCG_HEAD_SYNC_WORDS, dtype=torch.int32, device="cuda")    # this caller's own exchange words
     grads = [torch.empty_like(t) for t in d[2:]]
     p = _lib.ptr
     for rep in range(2):        # twice: the exchange words must be reusable launch after launch
