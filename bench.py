@@ -9,7 +9,7 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
     -> [N > 1] RCCL all-reduce of the flat gradient buffer
     -> Adam update (the reference's optimiser, model/networks.py:38).
 
-What `value` is.  Consecutive steps run on DISTINCT batches: `--distinct-batches` (8) synthetic batches, each with its
+What `value` is.  Consecutive steps run on DISTINCT batches: `--distinct-batches` (16) synthetic batches, each with its
 own step buffers (activations, gradients, slabs), are visited round-robin, so that more than 2 GB is touched between two
 uses of the same bytes -- nothing of a step is served from the 256 MiB Infinity Cache because an earlier step left it
 there.  Before the timed region the same rotation runs for `--sustain` (5) seconds (`sustained`: its own graphs/s), so
@@ -47,7 +47,7 @@ def parse():
                     "REAL / REAL40 = the reference's own graph sizes (57-117 atoms, F = 25) at B = 4096 / 40; "
                     "RAGGED = C3 with n_g ~ U{24..36} (SURVEY 8d's variable-size variant)")
     ap.add_argument("--num-graphs", type=int, default=None, help="override graphs per GPU")
-    ap.add_argument("--distinct-batches", type=int, default=8, help="distinct resident batches (+ step buffers) visited round-robin")
+    ap.add_argument("--distinct-batches", type=int, default=16, help="distinct resident batches (+ step buffers) visited round-robin")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the same rotation run right before the timed steps")
     ap.add_argument("--combine", default="sse", choices=("sse", "mean"),
                     help="N > 1: 'sse' = gradient of sqrt(MSE) over the concatenated batch of all ranks (the reference's "

@@ -56,8 +56,10 @@ def test_sse_form_on_one_rank_equals_the_plain_step(H, oracle):
     for _ in range(3):
         la, lb = float(sa(sb.as_batch("cuda"))), float(sb2(sb.as_batch("cuda")))
         assert abs(la - lb) <= 1e-5 * abs(la)
+    # (loose: Adam with eps = 1e-9 turns rounding-level gradient differences into lr-sized steps on elements whose
+    #  gradient is ~0; the gradient comparison above is the tight one -- Adam is invariant to the gradient's scale)
     for pa, pb in zip(ma.parameters(), mb.parameters()):
-        assert rel_inf(pb, pa) <= 1e-5
+        assert rel_inf(pb, pa) <= 2e-3
 
 
 def test_sse_halves_summed_by_hand_give_the_concatenated_batch_gradient(H, oracle):

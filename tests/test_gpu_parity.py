@@ -136,7 +136,16 @@ def test_forward_matches_reference_golden_vectors(H, oracle, path):
         out, emb = m(H.Batch(g["x"].cuda(), g["edge_index"].cuda(), g["batch"].cuda(), g["num_graphs"]), True)
     # default kernel selection (these 56-184-atom graphs: one graph per workgroup, csrc/mid.hip): the north_star bound
     assert rel_inf(emb, g["ref_emb"]) <= TOL
-    assert elementwise_ok(emb, g["ref_emb"], rtol=TOL, floor=0.05 * float(g["ref_emb"].abs().max()))
+    # elementwise at the SURVEY 8d bound (1e-5 of each value, floor 1e-3), judged against the fp64 oracle and anchored on
+    # the reference's OWN numbers (its embeddings.csv, fp32 arithmetic) measured the same way: a pooled mean that cancels
+    # to ~1e-3 carries ~1e-7 of fp32 rounding in ANY summation order (tests/test_gpu_elementwise.py states the gate)
+    p64 = {k: v.double() for k, v in g["params"].items()}
+    _, emb64 = oracle.gcn_forward(p64, g["x"].double(), g["edge_index"], g["batch"], g["num_graphs"])
+    bound = TOL * emb64.abs().clamp_min(1e-3)
+    ex_hip = ((emb.double().cpu() - emb64).abs() / bound)
+    ex_ref = ((g["ref_emb"].double() - emb64).abs() / bound)
+    assert int((ex_hip > 1).sum()) <= int((ex_ref > 1).sum()) + 2
+    assert float(ex_hip.max()) <= max(1.0, 1.5 * float(ex_ref.max()))
     assert (out[:, 0].cpu() - g["ref_pred"]).abs().max().item() <= 5e-5
     # any-shape kernels: they add every node's messages in the reference's own edge order, which also holds the much
     # tighter ELEMENTWISE bound (1e-5 of each value, floor 1e-3) on pooled means that cancel to ~1e-3
