@@ -63,6 +63,7 @@ SIGNATURES = {
     "hcg_adam_step": (INT, [P, P, P, P, I64, F32, F32, F32, F32, I64, P]),
     "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
     "hcg_mse_bwd": (INT, [P, P, P, I64, P, P, P]),
+    "hcg_loss_fwd_bwd": (INT, [P, P, I64, INT, P, P, P, P]),
     "hcg_readout2_supported": (INT, [I64, I64]),
     "hcg_readout2_workspace_bytes": (SZ, [I64]),
     "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),

@@ -99,8 +99,8 @@ class FusedTrainStep:
         if model.n_convolutions + 1 > 4:
             return "more than 3 conv layers"
         lib = _lib.load()
-        if not lib.hcg_head_supported(model.embedding_dim, model._n_classes):
-            return "head shape (embedding_dim must be 64, n_classes <= 8)"
+        # (heads the one-launch kernel does not cover -- embedding_dim 128 -- run as five launches of the any-shape
+        #  kernels inside the same no-autograd step)
         if type(model.loss).__name__ != "MSELoss":
             return "loss other than MSE"
         if not all(q.requires_grad for q in model.parameters()):
@@ -146,6 +146,20 @@ class FusedTrainStep:
                  "ws_head": cap["ws_head"], "ws_head_bytes": lib.hcg_head_workspace_bytes(B), "ws": cap["ws"]}
             self._bufs = {"cap": cap, key: b}          # views of the current shape (one live shape at a time)
         return b
+
+    def _head_buffers(self, bufs, B, D, C, dev):
+        """Scratch of the any-shape head (five launches): allocated once per capacity."""
+        lib = _lib.load()
+        hb = bufs["ws"].get("head_generic")
+        if hb is None or hb["B"] < B:
+            f32 = dict(dtype=torch.float32, device=dev)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            hb = {"B": B, "dout": torch.empty(B, C, **f32), "dz": torch.empty(B, D, **f32),
+                  "dz_ws1": torch.empty(B, C, **f32), "dz_ws0": torch.empty(B, D, **f32),
+                  "ws1": torch.empty(max(lib.hcg_linear_workspace_bytes(B, D, C), 256), **u8),
+                  "ws0": torch.empty(max(lib.hcg_linear_workspace_bytes(B, 2 * D, D), 256), **u8)}
+            bufs["ws"]["head_generic"] = hb
+        return hb
 
     def _flat_grads(self, params, dev):
         """ONE flat gradient buffer in parameter order (+ two floats behind it: [SSE, count] of the data-parallel "sse"
@@ -260,23 +274,44 @@ class FusedTrainStep:
         sse = self.combine == "sse" and not _forward_only
         mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
         tail = self._flat_ext[flat.numel():] if sse else None
-        rc = lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
-                                     p(HF._f32c(l1.bias)), B, D, C, slope, mode, p(bufs["z"]), p(bufs["out"]),
-                                     p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]), bufs["ws_head_bytes"],
-                                     p(self._sync_words(dev)), p(step_word), p(tail), stream)
-        _lib.check(rc, "hcg_head_fwd_bwd_ex")
-        if _forward_only:
-            self.last_out = bufs["out"]
-            return bufs["loss"][0]
+        fused_head = bool(lib.hcg_head_supported(D, C))
+        W0, b0, W1, b1 = HF._f32c(l0.weight), HF._f32c(l0.bias), HF._f32c(l1.weight), HF._f32c(l1.bias)
         jb = lib.hcg_reduce_job_bytes()
         jobs = ctypes.create_string_buffer(jb * 4)
         jaddr = ctypes.addressof(jobs)
-        _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
-                                           g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
+        njobs = 0
+        if fused_head:
+            rc = lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(W0), p(b0), p(W1), p(b1), B, D, C, slope, mode, p(bufs["z"]),
+                                         p(bufs["out"]), p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]),
+                                         bufs["ws_head_bytes"], p(self._sync_words(dev)), p(step_word), p(tail), stream)
+            _lib.check(rc, "hcg_head_fwd_bwd_ex")
+            if _forward_only:
+                self.last_out = bufs["out"]
+                return bufs["loss"][0]
+            _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
+                                               g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
+            njobs = 1
+        else:
+            # any-shape head (embedding_dim 128): Linear + LeakyReLU, Linear, loss with its gradient, two Linear backwards
+            # that write straight into the flat gradient buffer (reference model/gcn.py:70-71, utils/utils_model.py:64-65)
+            hb = self._head_buffers(bufs, B, D, C, dev)
+            z, out = bufs["z"], bufs["out"]
+            _lib.check(lib.hcg_linear_fwd(p(emb), p(W0), p(b0), p(z), B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, stream), "hcg_linear_fwd")
+            _lib.check(lib.hcg_linear_fwd(p(z), p(W1), p(b1), p(out), B, D, C, _lib.HCG_ACT_NONE, slope, stream), "hcg_linear_fwd")
+            _lib.check(lib.hcg_loss_fwd_bwd(p(out), p(y2), B * C, mode, p(bufs["loss"]), p(hb["dout"]), p(tail), stream),
+                       "hcg_loss_fwd_bwd")
+            if _forward_only:
+                self.last_out = bufs["out"]
+                return bufs["loss"][0]
+            _lib.check(lib.hcg_linear_bwd(p(hb["dout"]), p(out), p(z), p(W1), p(hb["dz"]), g(l1.weight), g(l1.bias), p(hb["dz_ws1"]),
+                                          B, D, C, _lib.HCG_ACT_NONE, slope, p(hb["ws1"]), hb["ws1"].numel(), stream), "hcg_linear_bwd")
+            _lib.check(lib.hcg_linear_bwd(p(hb["dz"]), p(z), p(emb), p(W0), p(bufs["demb"]), g(l0.weight), g(l0.bias), p(hb["dz_ws0"]),
+                                          B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, p(hb["ws0"]), hb["ws0"].numel(), stream), "hcg_linear_bwd")
+            step_word = None          # the head's gradients are not slabs: reduction and update stay two launches
         # ---- conv stack backward, last layer first
         # a fused-tile layer can hand its dx down already multiplied by the activation derivative of the layer below
         # (it holds those rows anyway, for dW); that layer then never reads its own output: one tensor less per step
-        njobs, dh, premasked = 1, None, False
+        dh, premasked = None, False
         for l in reversed(range(n_conv)):
             inp = x if l == 0 else acts[l - 1]
             Fl = inp.shape[1]
@@ -313,8 +348,11 @@ class FusedTrainStep:
                                            plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope,
                                            act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_mid_layer_bwd")
-                _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, 0, g(convs[l].lin.weight), g(convs[l].bias),
-                                                  jaddr + njobs * jb), "hcg_mid_reduce_job")
+                for half in range(D // 64):      # one slab set (= one job) per 64-column half
+                    if half > 0:
+                        njobs += 1
+                    _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, half, g(convs[l].lin.weight),
+                                                      g(convs[l].bias), jaddr + njobs * jb), "hcg_mid_reduce_job")
             njobs += 1
             dh = dx
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam

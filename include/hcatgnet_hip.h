@@ -299,6 +299,12 @@ int hcg_mse_fwd(const float* a, const float* b, int64_t n, float* loss, hcg_stre
 int hcg_mse_bwd(const float* a, const float* b, const float* grad_loss, int64_t n,
                 float* da /*nullable*/, float* db /*nullable*/, hcg_stream_t stream);
 
+/* Loss AND its gradient in one launch, for heads the fused kernel does not cover (other widths): mode 0 = MSE,
+ * 1 = sqrt(MSE) (the reference's step, utils/utils_model.py:64), HCG_HEAD_SSE = unscaled da = a - b with [SSE, n] stored
+ * in sse_tail (see hcg_head_fwd_bwd_ex).  loss[0] = the loss, loss[1] = MSE; da [n] = d loss / d a. */
+int hcg_loss_fwd_bwd(const float* a, const float* b, int64_t n, int mode, float* loss, float* da,
+                     float* sse_tail /*nullable unless mode = HCG_HEAD_SSE*/, hcg_stream_t stream);
+
 /* ---- batched slab reduction: ONE launch for all pending gradient reductions of a backward pass.
  * hcg_fused_layer_bwd and hcg_readout2_bwd_partial leave per-workgroup slabs in their workspaces;
  * hcg_fused_reduce_job / hcg_readout2_reduce_job describe them (host-side, no launch), hcg_reduce_slabs

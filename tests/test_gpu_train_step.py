@@ -438,3 +438,36 @@ def test_fused_train_step_random_batches(H, oracle, seed, n_conv):
     assert rel_inf(step.last_out, o_out.detach(), floor=1.0) <= TOL
     for k, v in m.named_parameters():
         assert rel_inf(v.grad, p64[k].grad) <= 2 * TOL, k
+
+
+@pytest.mark.parametrize("combine", ["mean", "sse"])
+def test_fused_train_step_embedding_dim_128(H, oracle, combine):
+    """BASELINE configs[4] (C5: 200-node graphs, 128-d): the no-autograd step with the any-shape head (five launches) and
+    the one-graph-per-workgroup conv kernels, two 64-column halves per layer; loss and every gradient vs the oracle."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C5", num_graphs=24)
+    m = H.make_network("GCN", H.default_options(embedding_dim=128), 128).cuda()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.05)
+    assert FusedTrainStep.unsupported_reason(m, sb.as_batch("cuda")) is None
+    step = FusedTrainStep(m, optimizer_step=False, combine=combine)
+    loss = step(sb.as_batch("cuda"))
+    l_ref, out_ref, _, g_ref = _oracle_grads(oracle, m, sb)
+    assert abs(float(loss) - float(l_ref)) <= TOL * abs(float(l_ref))
+    assert rel_inf(step.last_out, out_ref, floor=1.0) <= TOL
+    for name, prm in m.named_parameters():
+        assert rel_inf(prm.grad, g_ref[name]) <= TOL, name
+    # with the update, captured: three replays follow three eager steps of a twin
+    twin = H.make_network("GCN", H.default_options(embedding_dim=128), 128).cuda()
+    twin.load_state_dict(m.state_dict())
+    a, b = FusedTrainStep(m, combine=combine), FusedTrainStep(twin, combine=combine)
+    batch = sb.as_batch("cuda")
+    a.capture(lambda: batch)
+    for _ in range(2):
+        b(batch)
+    for _ in range(3):
+        la, lb = float(a.replay()), float(b(batch))
+        assert abs(la - lb) <= 1e-5 * abs(lb)
