@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
+    ap.add_argument("--no-plan-overlap", action="store_true",
+                    help="captured step: build the step's own plan in front of its forward instead of the next batch's beside it")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
@@ -284,6 +286,18 @@ def main():
             return H.Batch(self.x, self.ei, self.bvec, self.B, y=self.y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
                            edges_grouped=True)
 
+        def make_plan(self):
+            """A persistent plan for this batch: `planned()` batches carry it, `plan.rebuild` re-derives it in place."""
+            sb = self.sb
+            self.plan = H.BatchPlan.build(self.ei, self.bvec, self.N, num_graphs=self.B, mode="blocked", validate=False,
+                                          max_nodes=sb.max_nodes, max_edges=sb.max_edges)
+            return self.plan
+
+        def planned(self):
+            b = self.fresh()
+            b._hcg_plan = self.plan
+            return b
+
         def bytes_touched(self):
             return self.x.nbytes + self.ei.nbytes + self.bvec.nbytes + self.y.nbytes
 
@@ -356,8 +370,16 @@ def main():
             replay["full"] = runs
             replay["fwdbwd"] = lambda: runs[0](False)
             return
+        # every step still derives ONE plan (graph_ptr / edge_ptr / validation from the int64 inputs) -- the NEXT batch's, on a
+        # forked branch of the graph beside this step's kernels, as a pipelined loader would; `--no-plan-overlap` puts
+        # the step's own plan build back in front of its forward
+        for r in res:
+            r.make_plan()
         for i, tr in enumerate(trainers):
-            tr.capture(res[i].fresh)
+            if args.no_plan_overlap:
+                tr.capture(res[i].fresh)
+            else:
+                tr.capture(res[i].planned, prefetch=res[(i + 1) % NB].plan.rebuild)
         fwdbwd.capture(r0.fresh)
         replay["full"] = [tr.replay for tr in trainers]
         replay["fwdbwd"] = fwdbwd.replay
@@ -593,7 +615,8 @@ def main():
             "config": {"workload": f"{'C2' if args.forward_only and cfg_name == 'C3' else args.config}: {B} synthetic graphs/GPU x "
                                    f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
-                                   f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}",
+                                   f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
+                                   f"{'' if (launch_mode != 'hipgraph' or args.no_plan_overlap or not fused_ok) else ', plan build of the NEXT batch on a forked graph branch'}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "rccl_world": rccl_world,

@@ -54,3 +54,14 @@ int hcg_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
 // out[d] = sum_m src[m, d]  (deterministic two-stage); partials >= colsum_partial_floats
 size_t hcg_colsum_partial_floats(int64_t M, int64_t D);
 int hcg_colsum(const float* src, float* out, int64_t M, int64_t D, float* partials, hipStream_t stream);
+
+// ---- one-graph-per-wave kernels (wave.hip), selected inside the hcg_mid_* entry points (mid.hip) ----------
+int hcg_w64_applicable(int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges);
+int hcg_w64_bwd_grid(int64_t B);
+int hcg_w64_fwd_launch(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
+                       const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t B, int64_t F, float slope, int apply_act,
+                       float* out, float* emb, int32_t* status, hipStream_t stream);
+int hcg_w64_bwd_launch(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
+                       const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
+                       const int32_t* edge_ptr, int64_t B, int64_t F, float slope, int apply_act, float* dx,
+                       float* partials, int32_t* status, hipStream_t stream);

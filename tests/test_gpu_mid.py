@@ -28,7 +28,10 @@ def _near_ties(a, batch, B, hi=2e-5):
 
 # seeds chosen so that the batch has no near-tie in the max pooling (checked below)
 @pytest.mark.parametrize("nodes,jitter,feat,extra,deg,seed", [(87, 30, 25, 5, 4, 12), (150, 34, 32, 8, 4, 9), (60, 27, 64, 4, 4, 15),
-                                                              (40, 7, 40, 3, 4, 10), (100, 92, 25, 6, 6, 12), (33, 0, 7, 1, 3, 10)])
+                                                              (40, 7, 40, 3, 4, 10), (100, 92, 25, 6, 6, 12), (33, 0, 7, 1, 3, 10),
+                                                              # graphs up to 64 nodes: one graph per WAVE (csrc/wave.hip)
+                                                              (30, 6, 64, 3, 4, 25), (50, 14, 32, 3, 4, 20), (58, 6, 25, 4, 4, 12),
+                                                              (36, 0, 64, 3, 4, 21)])
 def test_mid_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, extra, deg, seed):
     """Forward, pooled epilogue, both backward variants (pooled gradient + dx, dout without dx) and the scalar /
     vector staging paths of mid.hip, on ragged batches (graphs from 8 to 192 nodes side by side)."""
@@ -64,17 +67,18 @@ def test_mid_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, e
     assert torch.equal(out_f, out_2) and torch.equal(emb_f, emb_2) and all(torch.equal(g_f[k], g_2[k]) for k in g_f)
 
 
-def test_mid_input_gradient_and_edge_cases(H, oracle):
+@pytest.mark.parametrize("nbig", [150, 50])      # 150: one graph per workgroup (mid.hip); 50: one graph per wave (wave.hip)
+def test_mid_input_gradient_and_edge_cases(H, oracle, nbig):
     """dx of the first layer (explain-style callers), multi-edges, explicit self loops, an isolated node, a
-    one-node graph and an empty graph slot next to a 150-node graph."""
+    one-node graph and an empty graph slot next to a 150-node (50-node) graph."""
     from hcatgnet_amd import synth
     g = torch.Generator().manual_seed(4)
-    big = synth.make_batch(num_graphs=1, nodes=150, extra_bonds=6, max_degree=4, feat=25, seed=2)
+    big = synth.make_batch(num_graphs=1, nodes=nbig, extra_bonds=6, max_degree=4, feat=25, seed=2)
     xs = [big.x, torch.randn(1, 25, generator=g), torch.randn(5, 25, generator=g)]
     e_small = torch.tensor([[0, 1, 1, 2, 2, 2, 3], [1, 0, 2, 1, 2, 1, 3]], dtype=torch.int64)   # multi-edge, two self loops; node 4 isolated
     x = torch.cat(xs)
-    ei = torch.cat([big.edge_index, e_small + 151], 1)
-    bv = torch.cat([torch.zeros(150, dtype=torch.int64), torch.ones(1, dtype=torch.int64), torch.full((5,), 3, dtype=torch.int64)])
+    ei = torch.cat([big.edge_index, e_small + nbig + 1], 1)
+    bv = torch.cat([torch.zeros(nbig, dtype=torch.int64), torch.ones(1, dtype=torch.int64), torch.full((5,), 3, dtype=torch.int64)])
     B = 5                                              # graphs 2 and 4 are empty slots
     y = torch.randn(B, generator=g)
     params = _rand_params(25, 64, seed=37)

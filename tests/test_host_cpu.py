@@ -121,7 +121,7 @@ def test_algorithmic_bytes_match_survey_numbers():
 
 def test_fused_train_step_support_check_is_host_only():
     """`FusedTrainStep.unsupported_reason` decides on the host (no GPU needed) whether a model / batch can take the
-    no-autograd step: small-graph tiles up to 32 nodes, one-graph-per-workgroup kernels up to 224 nodes, D = 64 head."""
+    no-autograd step: small-graph tiles up to 32 nodes, one-graph-per-workgroup kernels up to 224 nodes, D = 64 or 128."""
     import hcatgnet_amd as H
     from hcatgnet_amd.train import FusedTrainStep
     m = H.make_network("GCN", H.default_options(), 25)
@@ -132,7 +132,9 @@ def test_fused_train_step_support_check_is_host_only():
     assert "shape" in FusedTrainStep.unsupported_reason(m, mk(max_nodes=300, max_edges=700, edges_grouped=True))
     assert "metadata" in FusedTrainStep.unsupported_reason(m, mk())
     assert "targets" in FusedTrainStep.unsupported_reason(m, H.Batch(x, ei, bv, 1, max_nodes=30, max_edges=64, edges_grouped=True))
-    wide = H.make_network("GCN", H.default_options(embedding_dim=128), 25)
-    assert "head" in FusedTrainStep.unsupported_reason(wide)
+    wide = H.make_network("GCN", H.default_options(embedding_dim=128), 25)       # 128-d: any-shape head inside the same step
+    assert FusedTrainStep.unsupported_reason(wide, mk(max_nodes=200, max_edges=424, edges_grouped=True)) is None
+    odd = H.make_network("GCN", H.default_options(embedding_dim=96), 25)         # no conv kernel family covers D = 96
+    assert "shape" in FusedTrainStep.unsupported_reason(odd, mk(max_nodes=30, max_edges=64, edges_grouped=True))
     deep = H.make_network("GCN", H.default_options(readout_layers=3), 25)
     assert "readout" in FusedTrainStep.unsupported_reason(deep)
