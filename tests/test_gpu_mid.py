@@ -85,7 +85,7 @@ def test_mid_input_gradient_and_edge_cases(H, oracle, nbig):
     m = _model_from_params(H, params)
     xd = x.cuda().requires_grad_(True)
     plan = H.BatchPlan.build(ei.cuda(), bv.cuda(), x.shape[0], num_graphs=B, mode="blocked")     # validate: fills max_nodes / max_edges
-    assert plan.max_nodes == 150 and plan.max_edges == big.edge_index.shape[1]
+    assert plan.max_nodes == nbig and plan.max_edges == big.edge_index.shape[1]
     out = m(x=xd, edge_index=ei.cuda(), batch_index=bv.cuda(), plan=plan)
     torch.sqrt(m.loss(out, y.cuda().unsqueeze(1))).backward()
     o_loss, o_out, o_emb, o_grads, o_dx = oracle.train_step_grads(params, x, ei, bv, y, B, x_requires_grad=True)
