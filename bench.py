@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
-    ap.add_argument("--no-plan-overlap", action="store_true",
-                    help="captured step: build the step's own plan in front of its forward instead of the next batch's beside it")
+    ap.add_argument("--plan-overlap", action="store_true",
+                    help="captured step: build the NEXT batch's plan on a forked branch of the graph instead of the step's own in "
+                         "front of its forward (measured SLOWER on ROCm 7.2: a forked hipGraph branch costs more than the 4 us launch it hides)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
@@ -370,13 +371,12 @@ def main():
             replay["full"] = runs
             replay["fwdbwd"] = lambda: runs[0](False)
             return
-        # every step still derives ONE plan (graph_ptr / edge_ptr / validation from the int64 inputs) -- the NEXT batch's, on a
-        # forked branch of the graph beside this step's kernels, as a pipelined loader would; `--no-plan-overlap` puts
-        # the step's own plan build back in front of its forward
+        # every step derives ONE plan (graph_ptr / edge_ptr / validation from the int64 inputs): its own, in front of its forward;
+        # with --plan-overlap the NEXT batch's, on a forked branch of the graph beside this step's kernels
         for r in res:
             r.make_plan()
         for i, tr in enumerate(trainers):
-            if args.no_plan_overlap:
+            if not args.plan_overlap:
                 tr.capture(res[i].fresh)
             else:
                 tr.capture(res[i].planned, prefetch=res[(i + 1) % NB].plan.rebuild)
@@ -616,7 +616,7 @@ def main():
                                    f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
                                    f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
-                                   f"{'' if (launch_mode != 'hipgraph' or args.no_plan_overlap or not fused_ok) else ', plan build of the NEXT batch on a forked graph branch'}",
+                                   f"{'' if (launch_mode != 'hipgraph' or not args.plan_overlap or not fused_ok) else ', plan build of the NEXT batch on a forked graph branch'}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "rccl_world": rccl_world,

@@ -473,6 +473,10 @@ class FusedTrainStep:
         g_main.replay()
         if split:                                     # exchange between the captured backward and the update:
             self._exchange_and_update(loss_buf=self._bufs["cap"]["loss"])   # one collective, then ONE eager launch
+        elif not self.optimizer_step:
+            # gradients-only step: the parameters' `.grad` must be THIS trainer's buffer (another trainer on the same model
+            # may have re-pointed them since the capture)
+            self._flat_grads([q for q in self.model.parameters() if q.requires_grad], self._flat.device)
         return loss
 
 
