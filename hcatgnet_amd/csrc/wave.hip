@@ -28,8 +28,8 @@ constexpr int W_SMALL = 65 * 4 + 12 + 3 * 64 * 4 + WE * 2;   // rowptr (padded t
 __host__ __device__ constexpr size_t w_wave_bytes(int tiles) { return (size_t)tiles * WN * HS * 4 + W_SMALL; }
 
 struct WLds {
-  float* t0;              // [64][HS]  forward: X -> H' ; backward: dY' -> X
-  float* t1;              // [64][HS]  backward only: dH
+  float* t0;              // [64][HS]  forward: X -> H' ; backward: dY' -> dH
+  float* t1;              // (unused: one tile per wave)
   int* rowptr;            // [65]
   int* cursor;            // [64]  row sizes, then fill cursors
   int* degin;             // [64]  in-degree (transpose CSR: rows are sources)
@@ -141,16 +141,53 @@ __device__ __forceinline__ void w_build_csr(const WLds& L, const WGraph& gi, con
     }
   }
   wave_sync();
-  if (lane < gi.n) {                                // insertion sort of this lane's (short) row: fixed summation order
-    const int kb = L.rowptr[lane], ke = L.rowptr[lane + 1];
-    for (int a = kb + 1; a < ke; ++a) {
-      const unsigned short key = L.col[a];
-      int b = a - 1;
-      while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
-      L.col[b + 1] = key;
+  {   // every row sorted by id: fixed summation order whatever order the LDS atomics ran in.  Rows of <= 4 entries (all
+      // of them in molecular graphs) through a register network, longer ones by insertion.
+    const int kb = lane < gi.n ? L.rowptr[lane] : 0, ke = lane < gi.n ? L.rowptr[lane + 1] : 0;
+    const int len = ke - kb;
+    if (len > 1 && len <= 4) {
+      unsigned a0 = L.col[kb], a1 = L.col[kb + 1], a2 = len > 2 ? L.col[kb + 2] : 0xffffu, a3 = len > 3 ? L.col[kb + 3] : 0xffffu;
+      unsigned t;
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      L.col[kb] = (unsigned short)a0;
+      L.col[kb + 1] = (unsigned short)a1;
+      if (len > 2) L.col[kb + 2] = (unsigned short)a2;
+      if (len > 3) L.col[kb + 3] = (unsigned short)a3;
+    } else if (len > 4) {
+      for (int a = kb + 1; a < ke; ++a) {
+        const unsigned short key = L.col[a];
+        int b = a - 1;
+        while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
+        L.col[b + 1] = key;
+      }
     }
   }
   wave_sync();
+}
+
+// acc = t[row] + sum_{k in [kb, ke)} t[col[k]] for this lane's (row, 4q..4q+3) slot: the first four neighbours' indices and
+// rows are requested together (independent LDS reads instead of a chain of dependent ones), longer rows loop on
+__device__ __forceinline__ float4 w_row_sum(const float* t, const unsigned short* col, int row, int kb, int ke, int q) {
+  float4 acc = *reinterpret_cast<const float4*>(t + row * HS + 4 * q);
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? col[kb + j] : row;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(t + c[j] * HS + 4 * q);
+    if (kb + j < ke) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  }
+  for (int k = kb + 4; __any(k < ke); ++k) {
+    if (k < ke) {
+      const float4 v = *reinterpret_cast<const float4*>(t + col[k] * HS + 4 * q);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  return acc;
 }
 
 // rows [nbase, nbase + n) of a row-major [*, F] matrix -> t[row][0 .. KPAD), zero padded past F and up to `rows` rows.
@@ -181,6 +218,30 @@ __device__ __forceinline__ void w_stage_rows(float* t, const float* __restrict__
     }
   }
 }
+
+// the wide form in two phases, so that a graph's first rows can be requested a graph ahead: load() only issues global
+// loads (8 float4 per lane = rows [base, base + 512 / KPAD * 4)), write() only touches LDS
+template <int KPAD>
+struct WRowsAhead {
+  static constexpr int PER_ROW = KPAD / 4, RPP = 64 / PER_ROW, ROWS = 8 * RPP;
+  float4 v[8];
+  __device__ __forceinline__ void load(const float* __restrict__ g, int F, int nbase, int n, int base, int lane) {
+    const int c4 = lane % PER_ROW, r0 = lane / PER_ROW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = base + j * RPP + r0;
+      v[j] = *reinterpret_cast<const float4*>(g + (size_t)(nbase + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + 4 * c4);
+    }
+  }
+  __device__ __forceinline__ void write(float* t, int n, int rows, int base, int lane) const {
+    const int c4 = lane % PER_ROW, r0 = lane / PER_ROW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = base + j * RPP + r0;
+      if (row < rows) *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = row < n ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
 
 // like stage_weight_split (split_mfma.h) for a thread count that need not divide the image
 template <bool TRANS, int NT, int ROWS, int K>
@@ -245,12 +306,26 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
   const float slope_eff = apply_act ? slope : 1.0f;
   __syncthreads();
 
+  const bool wide = F == KPAD && ((uintptr_t)x % 16 == 0);   // whole float4 rows: the first rows of a graph are requested a graph ahead
+  WRowsAhead<KPAD> ahead;
+  if (wide && g < B) ahead.load(x, F, gi.nbase, gi.n, 0, lane);
+
   for (; g < B; g += stride) {
     const WGraph gc = gi;
     const int rows = gc.nblk * 32;
-    w_stage_rows<KPAD>(L.t0, x, F, gc.nbase, gc.n, rows, lane);
+    if (wide) {
+      ahead.write(L.t0, gc.n, rows, 0, lane);
+      for (int base = WRowsAhead<KPAD>::ROWS; base < rows; base += WRowsAhead<KPAD>::ROWS) {
+        WRowsAhead<KPAD> more;
+        more.load(x, F, gc.nbase, gc.n, base, lane);
+        more.write(L.t0, gc.n, rows, base, lane);
+      }
+    } else {
+      w_stage_rows<KPAD>(L.t0, x, F, gc.nbase, gc.n, rows, lane);
+    }
     w_build_csr<false>(L, gc, er, lane, status);
-    if (g + stride < B) {                                // the NEXT graph's scalars and edges: in flight for the whole graph
+    const bool have_next = g + stride < B;
+    if (have_next) {                                     // the NEXT graph's scalars and edges: in flight for the whole graph
       gi = w_graph(g + stride, B, graph_ptr, edge_ptr, lane, status);
       er.load(gi, ei, E, lane);
     }
@@ -272,6 +347,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
       }
     }
     wave_sync();
+    if (wide && have_next) ahead.load(x, F, gi.nbase, gi.n, 0, lane);   // lands while this graph is aggregated and stored
 
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -279,14 +355,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
       const int row = pass * 4 + r4;
       const bool valid = row < gc.n;
       const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-      float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
-      for (int k = kb; __any(k < ke); ++k) {
-        if (k < ke) {
-          const int c = L.col[k];
-          const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-      }
+      const float4 acc = w_row_sum(L.t0, L.col, row, kb, ke, q);
       const float di = L.dinv[row];
       float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
       y.x = fmaxf(y.x, slope_eff * y.x); y.y = fmaxf(y.y, slope_eff * y.y);
@@ -322,6 +391,10 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
 // backward of one layer (same contract as k_mid_layer_bwd, D = 64):
 //   dY = dA (.) leaky'(A)            dA = dout, or (POOLG) the pooled-gradient expansion (ties of the max split evenly)
 //   db += colsum dY ;  dH = Ahat^T dY ;  dW += dH^T x ;  dx = dH W  (NEEDS_DX)
+// ONE LDS tile per wave (as many waves per CU as the forward): dY' -> tile; the transpose segmented sum of EVERY row is
+// taken into registers before the first dH row is written back over the tile; x never goes through LDS -- the dW
+// contraction reads it as the B operand straight from global memory (per k-step 8 coalesced 128-byte row segments per
+// lane-half), and so does the premask of dx.
 // =====================================================================================================
 template <int KPAD, bool NEEDS_DX, bool POOLG, int NW>
 __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
@@ -332,8 +405,8 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const WLds L = w_carve(smem + (size_t)wave * w_wave_bytes(2), 2);
-  short* wtl = reinterpret_cast<short*>(smem + (size_t)NW * w_wave_bytes(2));
+  const WLds L = w_carve(smem + (size_t)wave * w_wave_bytes(1), 1);
+  short* wtl = reinterpret_cast<short*>(smem + (size_t)NW * w_wave_bytes(1));
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
   constexpr int NBF = KPAD / 32;
   constexpr int ld = DD + WPAD, plane = KPAD * ld;
@@ -361,6 +434,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
 #pragma unroll
       for (int i = 0; i < 16; ++i) dw[mb][nb][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int fcol0 = r < F ? r : F - 1, fcol1 = 32 + r < F ? 32 + r : F - 1;   // this lane's x columns (clamped: dW columns >= F are dropped)
 
   for (; g < B; g += stride) {
     const WGraph gc = gi;
@@ -371,20 +445,30 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
       er.load(gi, ei, E, lane);
     }
 
-    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero).  Lane slot: row group r4 (rows r4 + 4 j), columns 4q..
+    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> tile (rows >= n zero).  Lane slot: row group r4 (rows r4 + 4 j), columns 4q..
     float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
     if (POOLG) {
       const size_t eb = (size_t)g * 2 * DD + 4 * q;
       gmx = *reinterpret_cast<const float4*>(emb + eb);
-      const float4 dmx = *reinterpret_cast<const float4*>(demb + eb);
       dmean = *reinterpret_cast<const float4*>(demb + eb + DD);
       const float cntf = (float)(gc.n > 0 ? gc.n : 1);
       dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
+    }
+    float4 av[16];                                       // this lane slot's rows of the layer output (<= 64 rows / 4)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = r4 + 4 * j;
+      if (need_a && 4 * j < rows)                        // (wave-uniform guards: no per-lane branch around a load)
+        av[j] = *reinterpret_cast<const float4*>(a_out + (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q);
+      else
+        av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (POOLG) {
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = 0; j < rows / 4; ++j) {               // first pass over the graph's output rows: ties of the column max
-        const int row = r4 + 4 * j;
-        const float4 a = *reinterpret_cast<const float4*>(a_out + (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q);
-        if (row < gc.n) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (r4 + 4 * j < gc.n) {
+          const float4 a = av[j];
           ties.x += (a.x == gmx.x); ties.y += (a.y == gmx.y); ties.z += (a.z == gmx.z); ties.w += (a.w == gmx.w);
         }
       }
@@ -392,29 +476,20 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
                          ties.z + __shfl_xor(ties.z, 16, 64), ties.w + __shfl_xor(ties.w, 16, 64));
       ties = make_float4(ties.x + __shfl_xor(ties.x, 32, 64), ties.y + __shfl_xor(ties.y, 32, 64),
                          ties.z + __shfl_xor(ties.z, 32, 64), ties.w + __shfl_xor(ties.w, 32, 64));
+      const float4 dmx = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + 4 * q);
       share = make_float4(dmx.x / fmaxf(ties.x, 1.f), dmx.y / fmaxf(ties.y, 1.f), dmx.z / fmaxf(ties.z, 1.f), dmx.w / fmaxf(ties.w, 1.f));
     }
-    for (int j0 = 0; j0 < rows / 4; j0 += 8) {           // 8 rows per lane slot in flight
-      float4 av[8], dv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int row = r4 + 4 * (j0 + j);
-        const size_t at = (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q;
-        av[j] = need_a ? *reinterpret_cast<const float4*>(a_out + at) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dv[j] = POOLG ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dout + at);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int row = r4 + 4 * (j0 + j);
+    for (int j = 0; j < 16; ++j) {
+      const int row = r4 + 4 * j;
+      if (4 * j < rows) {                                // wave-uniform
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!POOLG) d = *reinterpret_cast<const float4*>(dout + (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q);
         if (row < gc.n) {
           const float4 a = av[j];
-          if (POOLG) {
+          if (POOLG)
             d = make_float4(dmean.x + (a.x == gmx.x ? share.x : 0.f), dmean.y + (a.y == gmx.y ? share.y : 0.f),
                             dmean.z + (a.z == gmx.z ? share.z : 0.f), dmean.w + (a.w == gmx.w ? share.w : 0.f));
-          } else {
-            d = dv[j];
-          }
           if (act_here) {
             d.x *= hcg_leaky_grad(a.x, slope); d.y *= hcg_leaky_grad(a.y, slope);
             d.z *= hcg_leaky_grad(a.z, slope); d.w *= hcg_leaky_grad(a.w, slope);
@@ -422,59 +497,70 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
           dbacc.x += d.x; dbacc.y += d.y; dbacc.z += d.z; dbacc.w += d.w;
           const float di = L.dinv[row];
           d = make_float4(di * d.x, di * d.y, di * d.z, di * d.w);
+        } else {
+          d = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (row < rows) *reinterpret_cast<float4*>(L.t0 + row * HS + 4 * q) = d;
+        *reinterpret_cast<float4*>(L.t0 + row * HS + 4 * q) = d;
       }
     }
     wave_sync();
 
-    // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1
-    for (int pass = 0; pass < rows / 4; ++pass) {
-      const int row = pass * 4 + r4;
-      const bool valid = row < gc.n;
-      const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-      float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
-      for (int k = kb; __any(k < ke); ++k) {
-        if (k < ke) {
-          const int c = L.col[k];
-          const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+    // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}): every row into registers (av is dead),
+    //         then back over the tile
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = r4 + 4 * j;
+      if (4 * j < rows) {
+        const bool valid = row < gc.n;
+        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
+        const float4 acc = w_row_sum(L.t0, L.col, row, kb, ke, q);
+        const float di = L.dinv[row];
+        av[j] = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
       }
-      const float di = L.dinv[row];
-      *reinterpret_cast<float4*>(L.t1 + row * HS + 4 * q) = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
     }
     wave_sync();
-
-    // ---- 3. x -> t0
-    w_stage_rows<KPAD>(L.t0, x, F, gc.nbase, gc.n, rows, lane);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (4 * j < rows) *reinterpret_cast<float4*>(L.t0 + (r4 + 4 * j) * HS + 4 * q) = av[j];
     wave_sync();
 
-    // ---- 4. dW[mb][nb] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
+    // ---- 3. dW[mb][nb] += dH^T x over the graph's nodes (K = nodes, 16 per step): A read down the columns of the dH tile,
+    //         B = x straight from global memory (rows >= n: any finite value, their dH rows are zero)
+    const float* xg = x + (size_t)gc.nbase * F;
+    const int nlast = gc.n > 0 ? gc.n - 1 : 0;
     for (int ks = 0; ks < gc.nblk * 2; ++ks) {
+      float bv0[8], bv1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int node = 16 * ks + 8 * h + j;
+        const float* xr = xg + (size_t)(node < gc.n ? node : nlast) * F;
+        bv0[j] = xr[fcol0];
+        if (NBF > 1) bv1[j] = xr[fcol1];
+      }
       Split3 A[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         float avv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) avv[j] = L.t1[(16 * ks + 8 * h + j) * HS + mb * 32 + r];
+        for (int j = 0; j < 8; ++j) avv[j] = L.t0[(16 * ks + 8 * h + j) * HS + mb * 32 + r];
         A[mb] = split3(avv);
       }
-#pragma unroll
-      for (int nb = 0; nb < NBF; ++nb) {
-        float bvv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bvv[j] = L.t0[(16 * ks + 8 * h + j) * HS + nb * 32 + r];
-        const Split3 Bx = split3(bvv);
-        mfma_split(dw[0][nb], A[0], Bx.p1, Bx.p2, Bx.p3);
-        mfma_split(dw[1][nb], A[1], Bx.p1, Bx.p2, Bx.p3);
+      {
+        const Split3 Bx = split3(bv0);
+        mfma_split(dw[0][0], A[0], Bx.p1, Bx.p2, Bx.p3);
+        mfma_split(dw[1][0], A[1], Bx.p1, Bx.p2, Bx.p3);
+      }
+      if (NBF > 1) {
+        const Split3 Bx = split3(bv1);
+        mfma_split(dw[0][NBF - 1], A[0], Bx.p1, Bx.p2, Bx.p3);
+        mfma_split(dw[1][NBF - 1], A[1], Bx.p1, Bx.p2, Bx.p3);
       }
     }
 
-    // ---- 5. dx = dH W, one 32-row block at a time
+    // ---- 4. dx = dH W, one 32-row block at a time (premask: times leaky'(x), x read where the result is stored)
     if (NEEDS_DX) {
       for (int mb = 0; mb < gc.nblk; ++mb) {
-        const float* blk = L.t1 + mb * 32 * HS;
+        const float* blk = L.t0 + mb * 32 * HS;
         f32x16 dxa[NBF];
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb)
@@ -503,29 +589,29 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
             for (int nb = 0; nb < NBF; ++nb) {
               const int f = nb * 32 + r;
               if (f < F) {
-                const float v = premask ? dxa[nb][i] * hcg_leaky_grad(L.t0[row * HS + nb * 32 + r], slope) : dxa[nb][i];
-                dx[(size_t)(gc.nbase + row) * F + f] = v;
+                const size_t at = (size_t)(gc.nbase + row) * F + f;
+                dx[at] = premask ? dxa[nb][i] * hcg_leaky_grad(x[at], slope) : dxa[nb][i];
               }
             }
           }
         }
       }
     }
-    wave_sync();   // t0 / t1 / the CSR are free for the next graph
+    wave_sync();   // the tile / the CSR are free for the next graph
   }
 
   // ---- combine the waves of this workgroup in a fixed order and publish one slab: dW [64][KPAD] | db [64]
   constexpr int SLABF = DD * KPAD + DD;
-  static_assert(w_wave_bytes(2) >= SLABF * sizeof(float), "a wave's slab must fit in its own tiles");
+  static_assert(w_wave_bytes(1) >= SLABF * sizeof(float), "a wave's slab must fit in its own tile");
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dw[mb][nb]);
   dbacc.x += __shfl_xor(dbacc.x, 16, 64); dbacc.y += __shfl_xor(dbacc.y, 16, 64); dbacc.z += __shfl_xor(dbacc.z, 16, 64); dbacc.w += __shfl_xor(dbacc.w, 16, 64);
   dbacc.x += __shfl_xor(dbacc.x, 32, 64); dbacc.y += __shfl_xor(dbacc.y, 32, 64); dbacc.z += __shfl_xor(dbacc.z, 32, 64); dbacc.w += __shfl_xor(dbacc.w, 32, 64);
-  __syncthreads();                                     // every wave is done with its tiles
+  __syncthreads();                                     // every wave is done with its tile
   {
-    float* mine = reinterpret_cast<float*>(smem + (size_t)wave * w_wave_bytes(2));
+    float* mine = reinterpret_cast<float*>(smem + (size_t)wave * w_wave_bytes(1));
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -539,7 +625,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
   for (int idx = threadIdx.x; idx < SLABF; idx += NW * 64) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += reinterpret_cast<const float*>(smem + (size_t)w * w_wave_bytes(2))[idx];
+    for (int w = 0; w < NW; ++w) s += reinterpret_cast<const float*>(smem + (size_t)w * w_wave_bytes(1))[idx];
     slab[idx] = s;
   }
 }
@@ -566,7 +652,7 @@ hipError_t w_allow_big_lds() {
   return st;
 }
 
-constexpr int NW_FWD = 7, NW_BWD = 4, NW_BWD_DX = 3;   // waves per workgroup: 160 KB of LDS / (tiles of a wave + weight image)
+constexpr int NW_FWD = 7, NW_BWD = 8, NW_BWD_DX = 7;   // waves per workgroup: 160 KB of LDS / (one tile per wave + the weight image)
 
 }  // namespace
 
@@ -607,7 +693,7 @@ int hcg_w64_bwd_launch(const float* dout, const float* demb, const float* emb, c
   const dim3 grid(gsz);
 #define LAUNCH_W_BWD(KP, DX, PG, NWV)                                                                                   \
   do {                                                                                                                  \
-    const size_t lds = (size_t)NWV * w_wave_bytes(2) + (DX ? (size_t)3 * KP * (DD + WPAD) * 2 : 0);                     \
+    const size_t lds = (size_t)NWV * w_wave_bytes(1) + (DX ? (size_t)3 * KP * (DD + WPAD) * 2 : 0);                     \
     hipError_t e = w_allow_big_lds<k_w64_layer_bwd<KP, DX, PG, NWV>>();                                                 \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                         \
     hipLaunchKernelGGL((k_w64_layer_bwd<KP, DX, PG, NWV>), grid, dim3(NWV * 64), lds, stream, dout, demb, emb, out, x,  \

@@ -56,7 +56,7 @@ def test_mid_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, e
     assert rel_inf(emb_f, emb_g) <= 2e-6 and rel_inf(out_f, out_g, floor=1.0) <= 2e-6
     for k, ref in o_grads.items():
         assert rel_inf(g_f[k], ref) <= (TOL_DW if k.endswith("weight") else TOL), k
-        assert rel_inf(g_f[k], g_g[k]) <= TOL, k
+        assert rel_inf(g_f[k], g_g[k]) <= (TOL_DW if k.endswith("weight") else TOL), k
     _, _, acts = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
     with torch.no_grad():
         h = m.conv1(batch.x, plan, apply_act=True, fused=True)
@@ -173,7 +173,7 @@ def test_mid_wide_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, fe
     assert rel_inf(emb_f, emb_g) <= 2e-6 and rel_inf(out_f, out_g, floor=1.0) <= 2e-6
     for k, ref in o_grads.items():
         assert rel_inf(g_f[k], ref) <= (TOL_DW if k.endswith("weight") else TOL), k
-        assert rel_inf(g_f[k], g_g[k]) <= TOL, k
+        assert rel_inf(g_f[k], g_g[k]) <= (TOL_DW if k.endswith("weight") else TOL), k
     with torch.no_grad():
         h = m.conv1(batch.x, plan, apply_act=True, fused=True)
     assert rel_inf(h, acts0[0]) <= TOL
