@@ -54,9 +54,13 @@ def test_mid_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, feat, e
     o_loss, o_out, o_emb, o_grads = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs)
     assert rel_inf(emb_f, o_emb) <= TOL and rel_inf(out_f, o_out, floor=1.0) <= TOL
     assert rel_inf(emb_f, emb_g) <= 2e-6 and rel_inf(out_f, out_g, floor=1.0) <= 2e-6
+    # gradients that sum thousands of cancelling node terms (weights AND conv biases: db = sum over ~8e3 nodes) are judged
+    # against the fp64 oracle at 1e-5 (1e-4 for weights) -- two fp32 summation orders differ from EACH OTHER by
+    # more than either differs from the truth -- and against the fp32 oracle / the any-shape path at the weight bound
+    _, _, _, g64 = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs, dtype=torch.float64)
     for k, ref in o_grads.items():
-        assert rel_inf(g_f[k], ref) <= (TOL_DW if k.endswith("weight") else TOL), k
-        assert rel_inf(g_f[k], g_g[k]) <= (TOL_DW if k.endswith("weight") else TOL), k
+        assert rel_inf(g_f[k], g64[k]) <= (TOL_DW if k.endswith("weight") else TOL), k
+        assert rel_inf(g_f[k], ref) <= TOL_DW and rel_inf(g_f[k], g_g[k]) <= TOL_DW, k
     _, _, acts = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
     with torch.no_grad():
         h = m.conv1(batch.x, plan, apply_act=True, fused=True)
