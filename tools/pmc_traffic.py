@@ -2,7 +2,8 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: counters are in KiB-units of 64-B
 requests; FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced streaming reads -> doubled.
-Writes profiles/<tag>_traffic.json.  Dev tool (runs here on the merged gpurun_out/ CSVs)."""
+Writes profiles/<tag>_traffic.json.  With a 4th argument SECTION (C3 / C5 / REAL ...) the result becomes that section of a
+per-workload file (bench.py reads the section of the config it runs).  Dev tool."""
 import csv, glob, json, os, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 def load(d, name):
@@ -24,4 +25,8 @@ for k in sorted(fe, key=lambda k: -(fe[k] + wr.get(k, 0))):
     res[k] = {"launches": n[k], "fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "hbm_bytes": fetch_b + write_b,
               "FETCH_SIZE_raw_KiB": fe[k], "WRITE_SIZE_raw_KiB": wr.get(k, 0.0)}
     print(f"{k:45s} n={n[k]:4d} fetch {fetch_b/1e6:8.2f} MB (raw {fe[k]/1e3:7.2f} MKiB) write {write_b/1e6:8.2f} MB total {(fetch_b+write_b)/1e6:8.2f} MB")
+if len(sys.argv) > 4:
+    allsec = json.load(open(out)) if os.path.isfile(out) else {}
+    allsec[sys.argv[4]] = res
+    res = allsec
 json.dump(res, open(out, "w"), indent=1)
