@@ -177,16 +177,51 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
     }
   }
   __syncthreads();
-  for (int i = tid; i < gi.n; i += MT) {          // insertion sort of each (short) row: fixed summation order
-    const int kb = L.rowptr[i], ke = L.rowptr[i + 1];
-    for (int a = kb + 1; a < ke; ++a) {
-      const unsigned short key = L.col[a];
-      int b = a - 1;
-      while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
-      L.col[b + 1] = key;
+  for (int i = tid; i < gi.n; i += MT) {          // every row sorted by id: fixed summation order
+    const int kb = L.rowptr[i], ke = L.rowptr[i + 1], len = ke - kb;
+    if (len > 1 && len <= 4) {                      // (every row of a molecular graph) a register network: no dependent LDS chain
+      unsigned a0 = L.col[kb], a1 = L.col[kb + 1], a2 = len > 2 ? L.col[kb + 2] : 0xffffu, a3 = len > 3 ? L.col[kb + 3] : 0xffffu;
+      unsigned t;
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      L.col[kb] = (unsigned short)a0;
+      L.col[kb + 1] = (unsigned short)a1;
+      if (len > 2) L.col[kb + 2] = (unsigned short)a2;
+      if (len > 3) L.col[kb + 3] = (unsigned short)a3;
+    } else if (len > 4) {
+      for (int a = kb + 1; a < ke; ++a) {
+        const unsigned short key = L.col[a];
+        int b = a - 1;
+        while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
+        L.col[b + 1] = key;
+      }
     }
   }
   __syncthreads();
+}
+
+// acc = t[row] + sum_{k in [kb, ke)} t[col[k]] for this lane's (row, 4q..4q+3) slot: the first four neighbours' indices and
+// rows are requested together (independent LDS reads instead of a chain of dependent ones), longer rows loop on
+__device__ __forceinline__ float4 mid_row_sum(const float* t, const unsigned short* col, int row, int kb, int ke, int q) {
+  float4 acc = *reinterpret_cast<const float4*>(t + row * HS + 4 * q);
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? col[kb + j] : row;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(t + c[j] * HS + 4 * q);
+    if (kb + j < ke) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  }
+  for (int k = kb + 4; __any(k < ke); ++k) {
+    if (k < ke) {
+      const float4 v = *reinterpret_cast<const float4*>(t + col[k] * HS + 4 * q);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  return acc;
 }
 
 // Stage columns [c0, c0 + KPAD) of rows [nbase, nbase + n) of a row-major [Nrows, F] matrix into t[row][0..KPAD) (zero
@@ -329,14 +364,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         const int row = u * 16 + pass * 4 + r4;
         const bool valid = row < gcur.n;
         const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-        float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
-        for (int k = kb; __any(k < ke); ++k) {
-          if (k < ke) {
-            const int c = L.col[k];
-            const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          }
-        }
+        const float4 acc = mid_row_sum(L.t0, L.col, row, kb, ke, q);
         const float di = L.dinv[row];
         float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
         if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
@@ -512,14 +540,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
         const int row = u * 16 + pass * 4 + r4;
         const bool valid = row < gi.n;
         const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-        float4 acc = *reinterpret_cast<const float4*>(L.t0 + row * HS + 4 * q);
-        for (int k = kb; __any(k < ke); ++k) {
-          if (k < ke) {
-            const int c = L.col[k];
-            const float4 v = *reinterpret_cast<const float4*>(L.t0 + c * HS + 4 * q);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          }
-        }
+        const float4 acc = mid_row_sum(L.t0, L.col, row, kb, ke, q);
         const float di = L.dinv[row];
         *reinterpret_cast<float4*>(L.t1 + row * HS + 4 * q) = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
       }
