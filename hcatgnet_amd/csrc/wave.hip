@@ -76,6 +76,19 @@ __device__ __forceinline__ WGraph w_graph(int g, int B, const int32_t* __restric
   return gi;
 }
 
+// the graph's scalars pinned into SGPRs: every guard built from them is then a scalar branch (carried through the graph
+// loop as a struct the compiler otherwise keeps them in VGPRs and turns `if (4 * j < rows)` around a load into a
+// per-lane branch with its own s_waitcnt vmcnt(0))
+__device__ __forceinline__ WGraph w_uniform(const WGraph& a) {
+  WGraph u;
+  u.nbase = __builtin_amdgcn_readfirstlane(a.nbase);
+  u.n = __builtin_amdgcn_readfirstlane(a.n);
+  u.ebase = __builtin_amdgcn_readfirstlane(a.ebase);
+  u.ne = __builtin_amdgcn_readfirstlane(a.ne);
+  u.nblk = __builtin_amdgcn_readfirstlane(a.nblk);
+  return u;
+}
+
 struct WEdges {   // loads only (unconditional, clamped): consumed one graph later
   long long s[WEPT], d[WEPT];
   __device__ __forceinline__ void load(const WGraph& gi, const int64_t* __restrict__ ei, int64_t E, int lane) {
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
   if (wide && g < B) ahead.load(x, F, gi.nbase, gi.n, 0, lane);
 
   for (; g < B; g += stride) {
-    const WGraph gc = gi;
+    const WGraph gc = w_uniform(gi);
     const int rows = gc.nblk * 32;
     if (wide) {
       ahead.write(L.t0, gc.n, rows, 0, lane);
@@ -437,8 +450,31 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
   const int fcol0 = r < F ? r : F - 1, fcol1 = 32 + r < F ? 32 + r : F - 1;   // this lane's x columns (clamped: dW columns >= F are dropped)
 
   for (; g < B; g += stride) {
-    const WGraph gc = gi;
+    const WGraph gc = w_uniform(gi);
     const int rows = gc.nblk * 32;
+    const int nlast = gc.n > 0 ? gc.n - 1 : 0;
+    // this graph's rows of the layer output / upstream gradient are requested FIRST: they land while the CSR is built
+    float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx, dmx = gmx;
+    if (POOLG) {
+      const size_t eb = (size_t)g * 2 * DD + 4 * q;
+      gmx = *reinterpret_cast<const float4*>(emb + eb);
+      dmx = *reinterpret_cast<const float4*>(demb + eb);
+      dmean = *reinterpret_cast<const float4*>(demb + eb + DD);
+    }
+    float4 av[16];                                       // this lane slot's rows (<= 64 rows / 4): layer output, or (no
+#pragma unroll                                           // activation derivative needed) the upstream gradient itself
+    for (int j = 0; j < 16; ++j) av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const float* src = (need_a ? a_out : dout) + (size_t)gc.nbase * DD + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)                        // rows 0..31: unconditional, clamped (min, not a branch)
+        av[j] = *reinterpret_cast<const float4*>(src + (size_t)min(r4 + 4 * j, nlast) * DD);
+      if (rows > 32) {                                   // ONE scalar branch around the second row block's loads
+#pragma unroll
+        for (int j = 8; j < 16; ++j)
+          av[j] = *reinterpret_cast<const float4*>(src + (size_t)min(r4 + 4 * j, nlast) * DD);
+      }
+    }
     w_build_csr<true>(L, gc, er, lane, status);
     if (g + stride < B) {
       gi = w_graph(g + stride, B, graph_ptr, edge_ptr, lane, status);
@@ -446,22 +482,9 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
     }
 
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> tile (rows >= n zero).  Lane slot: row group r4 (rows r4 + 4 j), columns 4q..
-    float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
     if (POOLG) {
-      const size_t eb = (size_t)g * 2 * DD + 4 * q;
-      gmx = *reinterpret_cast<const float4*>(emb + eb);
-      dmean = *reinterpret_cast<const float4*>(demb + eb + DD);
       const float cntf = (float)(gc.n > 0 ? gc.n : 1);
       dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
-    }
-    float4 av[16];                                       // this lane slot's rows of the layer output (<= 64 rows / 4)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = r4 + 4 * j;
-      if (need_a && 4 * j < rows)                        // (wave-uniform guards: no per-lane branch around a load)
-        av[j] = *reinterpret_cast<const float4*>(a_out + (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q);
-      else
-        av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (POOLG) {
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -476,7 +499,6 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
                          ties.z + __shfl_xor(ties.z, 16, 64), ties.w + __shfl_xor(ties.w, 16, 64));
       ties = make_float4(ties.x + __shfl_xor(ties.x, 32, 64), ties.y + __shfl_xor(ties.y, 32, 64),
                          ties.z + __shfl_xor(ties.z, 32, 64), ties.w + __shfl_xor(ties.w, 32, 64));
-      const float4 dmx = *reinterpret_cast<const float4*>(demb + (size_t)g * 2 * DD + 4 * q);
       share = make_float4(dmx.x / fmaxf(ties.x, 1.f), dmx.y / fmaxf(ties.y, 1.f), dmx.z / fmaxf(ties.z, 1.f), dmx.w / fmaxf(ties.w, 1.f));
     }
 #pragma unroll
@@ -484,7 +506,10 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
       const int row = r4 + 4 * j;
       if (4 * j < rows) {                                // wave-uniform
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!POOLG) d = *reinterpret_cast<const float4*>(dout + (size_t)(gc.nbase + (row < gc.n ? row : (gc.n > 0 ? gc.n - 1 : 0))) * DD + 4 * q);
+        if (!POOLG) {
+          d = av[j];                                     // (no activation derivative: av IS the upstream gradient)
+          if (need_a) d = *reinterpret_cast<const float4*>(dout + (size_t)(gc.nbase + min(row, nlast)) * DD + 4 * q);
+        }
         if (row < gc.n) {
           const float4 a = av[j];
           if (POOLG)
@@ -504,6 +529,17 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
       }
     }
     wave_sync();
+
+    // x operand of the dW contraction, k-step 0: requested here, a whole segmented-sum phase ahead of its use
+    const float* xg = x + (size_t)gc.nbase * F;
+    float bv0[8], bv1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int node = 8 * h + j;
+      const float* xr = xg + (size_t)(node < gc.n ? node : nlast) * F;
+      bv0[j] = xr[fcol0];
+      bv1[j] = NBF > 1 ? xr[fcol1] : 0.f;
+    }
 
     // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}): every row into registers (av is dead),
     //         then back over the tile
@@ -526,16 +562,16 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
 
     // ---- 3. dW[mb][nb] += dH^T x over the graph's nodes (K = nodes, 16 per step): A read down the columns of the dH tile,
     //         B = x straight from global memory (rows >= n: any finite value, their dH rows are zero)
-    const float* xg = x + (size_t)gc.nbase * F;
-    const int nlast = gc.n > 0 ? gc.n - 1 : 0;
     for (int ks = 0; ks < gc.nblk * 2; ++ks) {
-      float bv0[8], bv1[8];
+      const Split3 B0 = split3(bv0), B1 = split3(bv1);
+      if (ks + 1 < gc.nblk * 2) {                        // next k-step's x rows: in flight during this k-step's MFMAs
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int node = 16 * ks + 8 * h + j;
-        const float* xr = xg + (size_t)(node < gc.n ? node : nlast) * F;
-        bv0[j] = xr[fcol0];
-        if (NBF > 1) bv1[j] = xr[fcol1];
+        for (int j = 0; j < 8; ++j) {
+          const int node = 16 * (ks + 1) + 8 * h + j;
+          const float* xr = xg + (size_t)(node < gc.n ? node : nlast) * F;
+          bv0[j] = xr[fcol0];
+          bv1[j] = NBF > 1 ? xr[fcol1] : 0.f;
+        }
       }
       Split3 A[2];
 #pragma unroll
@@ -545,15 +581,11 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
         for (int j = 0; j < 8; ++j) avv[j] = L.t0[(16 * ks + 8 * h + j) * HS + mb * 32 + r];
         A[mb] = split3(avv);
       }
-      {
-        const Split3 Bx = split3(bv0);
-        mfma_split(dw[0][0], A[0], Bx.p1, Bx.p2, Bx.p3);
-        mfma_split(dw[1][0], A[1], Bx.p1, Bx.p2, Bx.p3);
-      }
+      mfma_split(dw[0][0], A[0], B0.p1, B0.p2, B0.p3);
+      mfma_split(dw[1][0], A[1], B0.p1, B0.p2, B0.p3);
       if (NBF > 1) {
-        const Split3 Bx = split3(bv1);
-        mfma_split(dw[0][NBF - 1], A[0], Bx.p1, Bx.p2, Bx.p3);
-        mfma_split(dw[1][NBF - 1], A[1], Bx.p1, Bx.p2, Bx.p3);
+        mfma_split(dw[0][NBF - 1], A[0], B1.p1, B1.p2, B1.p3);
+        mfma_split(dw[1][NBF - 1], A[1], B1.p1, B1.p2, B1.p3);
       }
     }
 
