@@ -611,8 +611,25 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
                        *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
           }
         }
+        // premask: times leaky'(x).  The x values of the block are requested TOGETHER, unconditionally (clamped), behind
+        // one kernel-uniform branch: a load inside the per-lane `row < n` guard below is a serialised memory round trip
+        float xm[NBF][16];
+        if (premask) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float* xr = xg + (size_t)min(mb * 32 + krow(i, h), nlast) * F;
+            xm[0][i] = xr[fcol0];
+            if (NBF > 1) xm[NBF - 1][i] = xr[fcol1];
+          }
+        }
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
+        if (premask) {
+#pragma unroll
+          for (int nb = 0; nb < NBF; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dxa[nb][i] *= hcg_leaky_grad(xm[nb][i], slope);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = mb * 32 + krow(i, h);
@@ -620,10 +637,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
 #pragma unroll
             for (int nb = 0; nb < NBF; ++nb) {
               const int f = nb * 32 + r;
-              if (f < F) {
-                const size_t at = (size_t)(gc.nbase + row) * F + f;
-                dx[at] = premask ? dxa[nb][i] * hcg_leaky_grad(x[at], slope) : dxa[nb][i];
-              }
+              if (f < F) dx[(size_t)(gc.nbase + row) * F + f] = dxa[nb][i];
             }
           }
         }
