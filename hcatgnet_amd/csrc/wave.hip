@@ -182,25 +182,30 @@ __device__ __forceinline__ void w_build_csr(const WLds& L, const WGraph& gi, con
   wave_sync();
 }
 
-// acc = t[row] + sum_{k in [kb, ke)} t[col[k]] for this lane's (row, 4q..4q+3) slot: the first four neighbours' indices and
-// rows are requested together (independent LDS reads instead of a chain of dependent ones), longer rows loop on
-__device__ __forceinline__ float4 w_row_sum(const float* t, const unsigned short* col, int row, int kb, int ke, int q) {
+// acc = t[row] + sum_{k in [kb, ke)} t[col[k]] for this lane's (row, 4q..4q+3) slot.  Head: the row itself and its first
+// four neighbours, requested together (independent LDS reads, straight-line code: several rows' chains interleave when
+// the caller unrolls).  Tail: rows with more than four entries (none in molecular graphs) loop on, behind ONE wave-uniform
+// branch per group of rows.
+__device__ __forceinline__ float4 w_row_sum_head(const float* t, const unsigned short* col, int row, int kb, int ke, int q) {
   float4 acc = *reinterpret_cast<const float4*>(t + row * HS + 4 * q);
   int c[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? col[kb + j] : row;
+  for (int j = 0; j < 4; ++j) c[j] = col[min(kb + j, WE - 1)];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 v = *reinterpret_cast<const float4*>(t + c[j] * HS + 4 * q);
-    if (kb + j < ke) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    const float4 v = *reinterpret_cast<const float4*>(t + (kb + j < ke ? c[j] : row) * HS + 4 * q);
+    const float m = kb + j < ke ? 1.f : 0.f;
+    acc.x = fmaf(m, v.x, acc.x); acc.y = fmaf(m, v.y, acc.y); acc.z = fmaf(m, v.z, acc.z); acc.w = fmaf(m, v.w, acc.w);
   }
+  return acc;
+}
+__device__ __forceinline__ void w_row_sum_tail(float4& acc, const float* t, const unsigned short* col, int kb, int ke, int q) {
   for (int k = kb + 4; __any(k < ke); ++k) {
     if (k < ke) {
       const float4 v = *reinterpret_cast<const float4*>(t + col[k] * HS + 4 * q);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  return acc;
 }
 
 // rows [nbase, nbase + n) of a row-major [*, F] matrix -> t[row][0 .. KPAD), zero padded past F and up to `rows` rows.
@@ -364,20 +369,35 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
 
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pass = 0; pass < rows / 4; ++pass) {
-      const int row = pass * 4 + r4;
-      const bool valid = row < gc.n;
-      const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-      const float4 acc = w_row_sum(L.t0, L.col, row, kb, ke, q);
-      const float di = L.dinv[row];
-      float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
-      y.x = fmaxf(y.x, slope_eff * y.x); y.y = fmaxf(y.y, slope_eff * y.y);
-      y.z = fmaxf(y.z, slope_eff * y.z); y.w = fmaxf(y.w, slope_eff * y.w);
-      if (valid) {
-        *reinterpret_cast<float4*>(out + (size_t)(gc.nbase + row) * DD + 4 * q) = y;
-        if (POOL) {
-          pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
-          psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
+    for (int pass0 = 0; pass0 < rows / 4; pass0 += 4) {   // four independent rows per lane slot at a time (rows is 32 or 64)
+      int kb[4], ke[4];
+      float4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (pass0 + u) * 4 + r4;
+        kb[u] = L.rowptr[row];
+        ke[u] = row < gc.n ? L.rowptr[row + 1] : kb[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = w_row_sum_head(L.t0, L.col, (pass0 + u) * 4 + r4, kb[u], ke[u], q);
+      if (__any(ke[0] - kb[0] > 4 || ke[1] - kb[1] > 4 || ke[2] - kb[2] > 4 || ke[3] - kb[3] > 4)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w_row_sum_tail(acc[u], L.t0, L.col, kb[u], ke[u], q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (pass0 + u) * 4 + r4;
+        const bool valid = row < gc.n;
+        const float di = L.dinv[row];
+        float4 y = make_float4(fmaf(di, acc[u].x, bq.x), fmaf(di, acc[u].y, bq.y), fmaf(di, acc[u].z, bq.z), fmaf(di, acc[u].w, bq.w));
+        y.x = fmaxf(y.x, slope_eff * y.x); y.y = fmaxf(y.y, slope_eff * y.y);
+        y.z = fmaxf(y.z, slope_eff * y.z); y.w = fmaxf(y.w, slope_eff * y.w);
+        if (valid) {
+          *reinterpret_cast<float4*>(out + (size_t)(gc.nbase + row) * DD + 4 * q) = y;
+          if (POOL) {
+            pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
+            psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
+          }
         }
       }
     }
@@ -544,12 +564,12 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
     // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}): every row into registers (av is dead),
     //         then back over the tile
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = r4 + 4 * j;
-      if (4 * j < rows) {
-        const bool valid = row < gc.n;
-        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-        const float4 acc = w_row_sum(L.t0, L.col, row, kb, ke, q);
+    for (int j = 0; j < 16; ++j) {                       // (one row per lane slot at a time: interleaving two or four rows'
+      if (4 * j < rows) {                                //  chains here spills 30-145 registers next to the dW accumulators)
+        const int row = r4 + 4 * j;
+        const int kb = L.rowptr[row], ke = row < gc.n ? L.rowptr[row + 1] : kb;
+        float4 acc = w_row_sum_head(L.t0, L.col, row, kb, ke, q);
+        if (__any(ke - kb > 4)) w_row_sum_tail(acc, L.t0, L.col, kb, ke, q);
         const float di = L.dinv[row];
         av[j] = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
       }
@@ -611,34 +631,24 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
                        *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
           }
         }
-        // premask: times leaky'(x).  The x values of the block are requested TOGETHER, unconditionally (clamped), behind
-        // one kernel-uniform branch: a load inside the per-lane `row < n` guard below is a serialised memory round trip
-        float xm[NBF][16];
-        if (premask) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float* xr = xg + (size_t)min(mb * 32 + krow(i, h), nlast) * F;
-            xm[0][i] = xr[fcol0];
-            if (NBF > 1) xm[NBF - 1][i] = xr[fcol1];
-          }
-        }
+        // premask: times leaky'(x).  The x values of a 32-column block are requested TOGETHER, unconditionally (clamped),
+        // behind one kernel-uniform branch: a load inside the per-lane `row < n` guard is a serialised memory round trip
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
-        if (premask) {
 #pragma unroll
-          for (int nb = 0; nb < NBF; ++nb)
+        for (int nb = 0; nb < NBF; ++nb) {
+          const int f = nb * 32 + r, fc = nb == 0 ? fcol0 : fcol1;
+          if (premask) {
+            float xm[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dxa[nb][i] *= hcg_leaky_grad(xm[nb][i], slope);
-        }
+            for (int i = 0; i < 16; ++i) xm[i] = xg[(size_t)min(mb * 32 + krow(i, h), nlast) * F + fc];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = mb * 32 + krow(i, h);
-          if (row < gc.n) {
+            for (int i = 0; i < 16; ++i) dxa[nb][i] *= hcg_leaky_grad(xm[i], slope);
+          }
 #pragma unroll
-            for (int nb = 0; nb < NBF; ++nb) {
-              const int f = nb * 32 + r;
-              if (f < F) dx[(size_t)(gc.nbase + row) * F + f] = dxa[nb][i];
-            }
+          for (int i = 0; i < 16; ++i) {
+            const int row = mb * 32 + krow(i, h);
+            if (row < gc.n && f < F) dx[(size_t)(gc.nbase + row) * F + f] = dxa[nb][i];
           }
         }
       }
