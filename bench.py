@@ -261,7 +261,7 @@ def main():
     log(f"rank {rank}/{world}: library loaded")
 
     cfg_name = args.config
-    ragged_cfg = dict(nodes_jitter=6)                    # n_g ~ U{24..36}
+    ragged_cfg = dict(nodes_jitter=6, group_by_size=True)   # n_g ~ U{24..36}; the loader groups the graphs of a batch by size class
     if cfg_name == "RAGGED":
         cfg_name, extra = "C3", ragged_cfg
     else:
@@ -285,7 +285,7 @@ def main():
         def fresh(self):     # a fresh Batch per step: its plan (graph_ptr / edge_ptr from the int64 inputs) is rebuilt every step
             sb = self.sb
             return H.Batch(self.x, self.ei, self.bvec, self.B, y=self.y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
-                           edges_grouped=True)
+                           edges_grouped=True, n_small=sb.n_small)
 
         def make_plan(self):
             """A persistent plan for this batch: `planned()` batches carry it, `plan.rebuild` re-derives it in place."""
@@ -592,7 +592,8 @@ def main():
             gpt = lib.hcg_fused_graphs_per_tile(F, D, rr[0].sb.max_nodes)
             ragged = {"value": rr[0].B * k / rdt, "unit": "graphs/s", "ms_per_step": rdt / k * 1e3, "steps": k,
                       "graphs": rr[0].B, "nodes": rr[0].N, "edges": rr[0].E, "max_nodes": rr[0].sb.max_nodes,
-                      "kernel_family": "small-graph tiles" if gpt > 0 else "one graph per workgroup",
+                      "kernel_family": "small-graph tiles" if gpt > 0 else ("size-grouped batch: tiles for graphs <= 32 nodes + one graph per wave"
+                                                                           if rr[0].sb.n_small else "one graph per wave / workgroup"),
                       "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, hipGraph replay"}
             log(f"ragged variant: {rdt / k * 1e3:.4f} ms/step")
             del rr, rtr

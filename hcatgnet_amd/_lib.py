@@ -58,6 +58,7 @@ SIGNATURES = {
     "hcg_fused_reduce_job": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
     "hcg_readout2_bwd_partial": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, SZ, P]),
     "hcg_readout2_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
+    "hcg_reduce_job_append": (INT, [P, P]),
     "hcg_reduce_slabs": (INT, [P, INT, P]),
     "hcg_collate": (INT, [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P]),
     "hcg_adam_step": (INT, [P, P, P, P, I64, F32, F32, F32, F32, I64, P]),

@@ -38,12 +38,15 @@ class Batch:
 
     def __init__(self, x, edge_index, batch, num_graphs: int, edge_attr=None, y=None, idx=None, ptr=None,
                  edge_ptr=None, max_nodes: Optional[int] = None, max_edges: Optional[int] = None,
-                 edges_grouped: bool = False):
+                 edges_grouped: bool = False, n_small: Optional[int] = None):
         self.x, self.edge_index, self.batch = x, edge_index, batch
         self.edge_attr, self.y, self.idx, self.ptr, self.edge_ptr = edge_attr, y, idx, ptr, edge_ptr
         self.num_graphs = int(num_graphs)
         self.max_nodes, self.max_edges = max_nodes, max_edges
         self.edges_grouped = edges_grouped      # True when produced by `collate` (per-graph edge blocks)
+        # size-grouped batches (`collate(..., group_by_size=True)`): the first `n_small` graphs have <= SMALL_NODES nodes,
+        # the others more -- the fused trainer then runs each group through its own kernel family
+        self.n_small = n_small
         self._hcg_plan = None                   # BatchPlan cache (built on first forward)
 
     @property
@@ -56,16 +59,26 @@ class Batch:
             t = getattr(self, f, None)
             kw[f] = t.to(device, non_blocking=non_blocking) if torch.is_tensor(t) else t
         out = Batch(kw["x"], kw["edge_index"], kw["batch"], self.num_graphs, kw["edge_attr"], kw["y"], kw["idx"],
-                    kw["ptr"], kw["edge_ptr"], self.max_nodes, self.max_edges, self.edges_grouped)
+                    kw["ptr"], kw["edge_ptr"], self.max_nodes, self.max_edges, self.edges_grouped, self.n_small)
         if self._hcg_plan is not None and self.x.device == out.x.device:
             out._hcg_plan = self._hcg_plan
         return out
 
 
-def collate(graphs: Sequence[Data]) -> Batch:
-    """PyG-equivalent collation of a list of graphs into one block-diagonal batch."""
+SMALL_NODES = 32      # graphs up to here run in the small-graph tiles (csrc/fused.hip)
+
+
+def collate(graphs: Sequence[Data], group_by_size: bool = False) -> Batch:
+    """PyG-equivalent collation of a list of graphs into one block-diagonal batch.
+    `group_by_size`: the graphs with <= SMALL_NODES nodes first, the larger ones behind them (a stable partition; the
+    order of the graphs inside a batch is arbitrary -- the reference shuffles it every epoch, call_methods.py:46 -- and
+    y / idx move with their graphs).  `Batch.n_small` then says where the second group starts."""
     if len(graphs) == 0:
         raise ValueError("cannot collate an empty list of graphs")
+    n_small = None
+    if group_by_size:
+        graphs = [g for g in graphs if g.num_nodes <= SMALL_NODES] + [g for g in graphs if g.num_nodes > SMALL_NODES]
+        n_small = sum(1 for g in graphs if g.num_nodes <= SMALL_NODES)
     n = [g.num_nodes for g in graphs]
     e = [g.num_edges for g in graphs]
     dev = graphs[0].x.device
@@ -86,7 +99,7 @@ def collate(graphs: Sequence[Data]) -> Batch:
         return torch.cat([torch.as_tensor(v).reshape(-1) for v in vals], 0)
 
     return Batch(x, edge_index, batch, len(graphs), edge_attr, cat_scalar("y"), cat_scalar("idx"), ptr.to(dev),
-                 eptr.to(dev), max(n), max(e), edges_grouped=True)
+                 eptr.to(dev), max(n), max(e), edges_grouped=True, n_small=n_small)
 
 
 class DataLoader:

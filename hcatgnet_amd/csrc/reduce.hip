@@ -141,3 +141,18 @@ extern "C" int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs,
 }
 
 extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }
+
+// Two backward launches of ONE layer over two groups of graphs (size-grouped batches: small-graph tiles + one graph per
+// wave) leave their slabs back to back in one workspace: `more` is appended to `job` -- same slab geometry, same
+// destinations, slabs contiguous -- so that the layer's gradient is ONE fixed-order sum over all of them.
+extern "C" int hcg_reduce_job_append(hcg_reduce_job* job, const hcg_reduce_job* more) {
+  if (!job || !more || job->slab_floats != more->slab_floats || job->nseg != more->nseg) return HCG_ERR_INVALID_ARG;
+  if (more->slabs != job->slabs + (size_t)job->nslabs * job->slab_floats) return HCG_ERR_INVALID_ARG;
+  for (int g = 0; g < job->nseg; ++g) {
+    const hcg_reduce_seg &a = job->seg[g], &b = more->seg[g];
+    if (a.begin != b.begin || a.count != b.count || a.row_in != b.row_in || a.row_out != b.row_out || a.dst != b.dst)
+      return HCG_ERR_INVALID_ARG;
+  }
+  job->nslabs += more->nslabs;
+  return HCG_OK;
+}

@@ -459,8 +459,8 @@ class _FusedModelFn(torch.autograd.Function):
         # every backward kernel leaves per-workgroup slabs; ONE batched launch reduces them all at the end
         import ctypes
         jb = lib.hcg_reduce_job_bytes()
-        batched = n_conv + 1 <= 4
-        jobs = ctypes.create_string_buffer(jb * 4) if batched else None
+        batched = n_conv + 1 <= 8
+        jobs = ctypes.create_string_buffer(jb * 8) if batched else None
         jaddr = ctypes.addressof(jobs) if batched else 0
         keep = []                                   # workspaces must outlive the batched reduction's enqueue
         # All weight gradients are views of ONE flat buffer laid out in nn.Module parameter order

@@ -82,10 +82,11 @@ class SynthBatch:
     num_graphs: int
     max_nodes: int
     max_edges: int
+    n_small: Optional[int] = None     # size-grouped batch: the first n_small graphs have <= 32 nodes (batch.collate)
 
     def as_batch(self, device=None) -> Batch:
         b = Batch(self.x, self.edge_index, self.batch, self.num_graphs, y=self.y, max_nodes=self.max_nodes,
-                  max_edges=self.max_edges, edges_grouped=True)
+                  max_edges=self.max_edges, edges_grouped=True, n_small=self.n_small)
         return b.to(device) if device is not None else b
 
     def as_graph_list(self):
@@ -108,13 +109,19 @@ class SynthBatch:
 
 
 def make_batch(num_graphs: int, nodes: int, extra_bonds: int, max_degree: int, feat: int, seed: int = BASE_SEED,
-               rank: int = 0, nodes_jitter: int = 0, **_unused) -> SynthBatch:
-    """`nodes_jitter` j > 0 draws n_g ~ U{nodes-j .. nodes+j} (the SURVEY's variable-size variant)."""
+               rank: int = 0, nodes_jitter: int = 0, group_by_size: bool = False, **_unused) -> SynthBatch:
+    """`nodes_jitter` j > 0 draws n_g ~ U{nodes-j .. nodes+j} (the SURVEY's variable-size variant).
+    `group_by_size`: the graphs with <= 32 nodes first (what `batch.collate(..., group_by_size=True)` emits)."""
     rng = np.random.default_rng(seed + 1000 * rank)
     n = np.full(num_graphs, nodes, np.int64)
     if nodes_jitter:
         n = rng.integers(nodes - nodes_jitter, nodes + nodes_jitter + 1, num_graphs)
     bi, bj = _random_bonds(rng, n, extra_bonds, max_degree)
+    n_small = None
+    if group_by_size:
+        order = np.argsort(n > 32, kind="stable")
+        n, bi, bj = n[order], bi[order], bj[order]
+        n_small = int((n <= 32).sum())
     ptr = np.zeros(num_graphs + 1, np.int64)
     ptr[1:] = np.cumsum(n)
     present = bi >= 0
@@ -129,7 +136,7 @@ def make_batch(num_graphs: int, nodes: int, extra_bonds: int, max_degree: int, f
     batch = np.repeat(np.arange(num_graphs), n)
     edges_per_graph = 2 * present.sum(1)
     return SynthBatch(torch.from_numpy(x), torch.from_numpy(np.stack([src, dst])), torch.from_numpy(batch),
-                      torch.from_numpy(y), num_graphs, int(n.max()), int(edges_per_graph.max()))
+                      torch.from_numpy(y), num_graphs, int(n.max()), int(edges_per_graph.max()), n_small)
 
 
 def make_config(name: str, rank: int = 0, num_graphs: Optional[int] = None, **kw) -> SynthBatch:

@@ -119,6 +119,129 @@ class FusedTrainStep:
                     return "graph / layer shape outside the fused kernels (small-graph tiles and one-graph-per-workgroup)"
         return None
 
+    # ------------------------------------------------------------------ size-grouped batches: two kernel families per layer
+    def _size_groups(self, batch, plan, convs, D, C, n_conv):
+        """-> n_small when the batch is size-grouped (`collate(..., group_by_size=True)`: the first n_small graphs have <= 32
+        nodes, the others 33 .. 64) and both groups are non-empty: the small graphs then run in the small-graph tiles, the
+        larger ones one graph per wave, instead of everything on the slower family."""
+        ns = getattr(batch, "n_small", None)
+        lib = _lib.load()
+        if (ns is None or not (0 < ns < plan.B) or n_conv != 2 or D != 64 or not lib.hcg_head_supported(D, C)
+                or plan.max_nodes is None or plan.max_nodes <= 32 or plan.max_edges is None):
+            return None
+        for c in convs:
+            if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, 32) <= 0:
+                return None
+            if not HF.mid_supported(plan, c.in_channels, c.out_channels):
+                return None
+        return int(ns)
+
+    def _routed_step(self, batch, plan, bufs, x, y2, convs, l0, l1, n_small, _forward_only):
+        """The step of `__call__` for a size-grouped batch: graphs [0, n_small) through csrc/fused.hip (one graph per
+        32-row tile), graphs [n_small, B) through the hcg_mid_* entry points (one graph per wave, csrc/wave.hip) -- every
+        launch gets the sub-range of graph_ptr / edge_ptr / emb / demb it owns; node rows are absolute, so x, the
+        activations and dx need no offsets.  Both groups' slabs of a layer sit back to back and are ONE reduction job."""
+        lib, model = _lib.load(), self.model
+        p = _lib.ptr
+        N, F, B, D, C = x.shape[0], x.shape[1], plan.B, model.embedding_dim, model._n_classes
+        dev, stream, slope = x.device, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        mxn, mxe = plan.max_nodes, plan.max_edges
+        Bs, Bb = n_small, B - n_small
+        gp, ep = plan.graph_ptr, plan.edge_ptr
+        gp_b, ep_b = gp.data_ptr() + 4 * Bs, ep.data_ptr() + 4 * Bs
+        acts, emb, demb = bufs["acts"], bufs["emb"], bufs["demb"]
+        emb_b, demb_b = emb.data_ptr() + 4 * 2 * D * Bs, demb.data_ptr() + 4 * 2 * D * Bs
+        W = [HF._f32c(c.lin.weight) for c in convs]
+        bs = [HF._f32c(c.bias) for c in convs]
+        gpt = int(lib.hcg_fused_graphs_per_tile(F, D, 32))
+        # ---- forward: tiles (both layers + pooling in one launch, pooled layer kept on chip as 2 bits / element), then waves
+        nb = lib.hcg_fused_poolbits_bytes(Bs, gpt)
+        poolbits = bufs["ws"].get("poolbits_r")
+        if poolbits is None or poolbits.numel() < nb:
+            poolbits = bufs["ws"]["poolbits_r"] = torch.empty(int(nb * 1.25), dtype=torch.uint8, device=dev)
+        _lib.check(lib.hcg_fused_stack2_fwd_train(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, p(gp), p(ep),
+                                                  N, Bs, F, D, gpt, slope, 1, p(acts[0]), p(emb), p(poolbits), p(plan.status), stream),
+                   "hcg_fused_stack2_fwd_train")
+        _lib.check(lib.hcg_mid_layer_fwd(p(x), p(W[0]), p(bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, F, D, mxn, mxe,
+                                         slope, 1, p(acts[0]), None, p(plan.status), stream), "hcg_mid_layer_fwd")
+        _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, D, D, mxn, mxe,
+                                         slope, 1, p(acts[1]), emb_b, p(plan.status), stream), "hcg_mid_layer_fwd")
+        # ---- head over all graphs
+        opt = model.optimizer
+        step_word, flat, g = None, None, None
+        if not _forward_only:
+            params = [q for q in model.parameters() if q.requires_grad]
+            flat = self._flat_grads(params, dev)
+            views, off = {}, 0
+            for q in params:
+                views[id(q)] = flat[off:off + q.numel()]
+                off += q.numel()
+            g = lambda prm: p(views[id(prm)])
+            if (self.optimizer_step and self.grad_sync is None and self.combine == "mean" and not self._capturing_split
+                    and hasattr(opt, "fused_update_ready")):
+                step_word = opt.fused_update_ready(flat)
+        sse = self.combine == "sse" and not _forward_only
+        mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
+        tail = self._flat_ext[flat.numel():] if sse else None
+        _lib.check(lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
+                                           p(HF._f32c(l1.bias)), B, D, C, slope, mode, p(bufs["z"]), p(bufs["out"]), p(bufs["loss"]),
+                                           p(demb), p(bufs["ws_head"]), bufs["ws_head_bytes"], p(self._sync_words(dev)),
+                                           p(step_word), p(tail), stream), "hcg_head_fwd_bwd_ex")
+        self.last_out = bufs["out"]
+        if _forward_only:
+            return bufs["loss"][0]
+        jb = lib.hcg_reduce_job_bytes()
+        jobs = ctypes.create_string_buffer(jb * 8)
+        tmp = ctypes.create_string_buffer(jb)
+        jaddr, taddr = ctypes.addressof(jobs), ctypes.addressof(tmp)
+        _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
+                                           g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
+        njobs = 1
+        # ---- conv stack backward, last layer first; each layer: tiles on the small graphs, waves on the others
+        premask = bool(self.PREMASK)
+        dx = bufs["dacts"][0]
+        for l in (1, 0):
+            inp = x if l == 0 else acts[0]
+            Fl = inp.shape[1]
+            ws_a = lib.hcg_fused_workspace_bytes(Bs, Fl, D, gpt)
+            ws_b = lib.hcg_mid_workspace_bytes(Bb, Fl, D, mxn, mxe)
+            off_b = ws_a - 256                                  # = the tile launch's slabs, exactly (the query pads by 256)
+            ws = bufs["ws"].get(("r", l))
+            if ws is None or ws.numel() < off_b + ws_b:
+                ws = bufs["ws"][("r", l)] = torch.empty(int((off_b + ws_b) * 1.25), dtype=torch.uint8, device=dev)
+            wsb_ptr = ws.data_ptr() + off_b
+            if l == 1:
+                flags = 1 | (2 if premask else 0)
+                _lib.check(lib.hcg_fused_layer_bwd_poolbits(p(demb), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(gp),
+                                                            p(ep), N, Bs, Fl, D, gpt, slope, flags, p(dx), p(plan.status), p(ws),
+                                                            off_b, stream), "hcg_fused_layer_bwd_poolbits")
+                _lib.check(lib.hcg_mid_layer_bwd(None, demb_b, emb_b, p(acts[1]), p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b,
+                                                 ep_b, N, Bb, Fl, D, mxn, mxe, slope, flags, p(dx), p(plan.status), wsb_ptr, ws_b,
+                                                 stream), "hcg_mid_layer_bwd")
+            else:
+                act = 0 if premask else 1
+                a_out = p(acts[0]) if act else None
+                _lib.check(lib.hcg_fused_layer_bwd(p(dx), None, None, a_out, p(inp), p(W[l]), p(plan.edge_index), plan.E, p(gp), p(ep),
+                                                   N, Bs, Fl, D, gpt, slope, act, None, p(plan.status), p(ws), off_b, stream),
+                           "hcg_fused_layer_bwd")
+                _lib.check(lib.hcg_mid_layer_bwd(p(dx), None, None, a_out, p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b, ep_b, N,
+                                                 Bb, Fl, D, mxn, mxe, slope, act, None, p(plan.status), wsb_ptr, ws_b, stream),
+                           "hcg_mid_layer_bwd")
+            _lib.check(lib.hcg_fused_reduce_job(p(ws), off_b, N, Bs, Fl, D, gpt, g(convs[l].lin.weight), g(convs[l].bias),
+                                                jaddr + njobs * jb), "hcg_fused_reduce_job")
+            _lib.check(lib.hcg_mid_reduce_job(wsb_ptr, ws_b, Bb, Fl, D, mxn, mxe, 0, g(convs[l].lin.weight), g(convs[l].bias), taddr),
+                       "hcg_mid_reduce_job")
+            _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
+            njobs += 1
+        if step_word is not None:
+            if not opt.step_with_reduction(jaddr, njobs, flat):
+                raise _lib.HcgError("optimizer state changed between head launch and update")
+        else:
+            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+            if not self._capturing_split:
+                self._exchange_and_update(bufs["loss"])
+        return bufs["loss"][0]
+
     # ------------------------------------------------------------------ the step
     def _buffers(self, key, N, B, F, D, C, n_conv, dev):
         """Step buffers: allocated for the largest (N, B) seen so far and handed out as views -- the variable-size
@@ -213,6 +336,9 @@ class FusedTrainStep:
                 raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused kernels")
         mxn, mxe = plan.max_nodes, plan.max_edges
         bufs = self._buffers((N, B, F, plan.E), N, B, F, D, C, n_conv, dev)
+        n_small = self._size_groups(batch, plan, convs, D, C, n_conv)
+        if n_small is not None:
+            return self._routed_step(batch, plan, bufs, x, y2, convs, l0, l1, n_small, _forward_only)
         acts, emb = bufs["acts"], bufs["emb"]
         p = _lib.ptr
         W = [HF._f32c(c.lin.weight) for c in convs]
@@ -277,7 +403,7 @@ class FusedTrainStep:
         fused_head = bool(lib.hcg_head_supported(D, C))
         W0, b0, W1, b1 = HF._f32c(l0.weight), HF._f32c(l0.bias), HF._f32c(l1.weight), HF._f32c(l1.bias)
         jb = lib.hcg_reduce_job_bytes()
-        jobs = ctypes.create_string_buffer(jb * 4)
+        jobs = ctypes.create_string_buffer(jb * 8)
         jaddr = ctypes.addressof(jobs)
         njobs = 0
         if fused_head:

@@ -309,7 +309,7 @@ int hcg_loss_fwd_bwd(const float* a, const float* b, int64_t n, int mode, float*
  * hcg_fused_layer_bwd and hcg_readout2_bwd_partial leave per-workgroup slabs in their workspaces;
  * hcg_fused_reduce_job / hcg_readout2_reduce_job describe them (host-side, no launch), hcg_reduce_slabs
  * sums up to HCG_REDUCE_MAX_JOBS of them in a fixed order. */
-#define HCG_REDUCE_MAX_JOBS 4
+#define HCG_REDUCE_MAX_JOBS 8
 #define HCG_REDUCE_MAX_SEGS 4
 typedef struct hcg_reduce_seg {
   int32_t begin, count;      /* element range of the slab */
@@ -334,6 +334,8 @@ int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B,
                        int64_t max_nodes, int64_t max_edges, int half, float* dW, float* db, hcg_reduce_job* job_host);
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+/* `more` (same slab geometry and destinations, slabs directly behind `job`'s) becomes part of `job`: one fixed-order sum */
+int hcg_reduce_job_append(hcg_reduce_job* job_host, const hcg_reduce_job* more_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
 
 /* ---- Adam update (f2) over one contiguous fp32 segment: torch.optim.Adam's rule (amsgrad / weight_decay /

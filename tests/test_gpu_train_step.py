@@ -471,3 +471,48 @@ def test_fused_train_step_embedding_dim_128(H, oracle, combine):
     for _ in range(3):
         la, lb = float(a.replay()), float(b(batch))
         assert abs(la - lb) <= 1e-5 * abs(lb)
+
+
+@pytest.mark.parametrize("feat,seed", [(64, 3), (25, 4)])
+def test_size_grouped_batch_runs_two_kernel_families(H, oracle, feat, seed):
+    """A ragged batch (n_g ~ U{24..36}) collated with group_by_size: graphs <= 32 nodes through the small-graph tiles, the
+    others one graph per wave, slabs of both in ONE reduction job per layer.  Loss / outputs / every gradient vs the
+    oracle, equal (to rounding) to the ungrouped route of the same batch, and the captured step replays it."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=300, nodes_jitter=6, group_by_size=True, seed=seed)
+    if feat != 64:
+        sb.x = sb.x[:, :feat].contiguous()
+    assert 0 < sb.n_small < sb.num_graphs and sb.max_nodes > 32
+    m = H.make_network("GCN", H.default_options(), feat).cuda()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.05)
+    step = FusedTrainStep(m, optimizer_step=False)
+    batch = sb.as_batch("cuda")
+    assert step._size_groups(batch, m._plan_for(batch, batch.x, batch.edge_index, batch.batch, None),
+                             [m.conv1] + list(m.conv_layers), 64, 1, 2) == sb.n_small
+    loss = float(step(batch))
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    l_ref, out_ref, _, g_ref = _oracle_grads(oracle, m, sb)
+    assert abs(loss - float(l_ref)) <= TOL * abs(float(l_ref))
+    assert rel_inf(step.last_out, out_ref, floor=1.0) <= TOL
+    for name in grads:
+        assert rel_inf(grads[name], g_ref[name]) <= TOL, name
+    plain = sb.as_batch("cuda")
+    plain.n_small = None                                   # the same batch, everything one graph per wave
+    loss2 = float(step(plain))
+    assert abs(loss2 - loss) <= 2e-6 * abs(loss)
+    for name, prm in m.named_parameters():
+        assert rel_inf(prm.grad, grads[name]) <= TOL, name
+    full = FusedTrainStep(m)
+    twin = H.make_network("GCN", H.default_options(), feat).cuda()
+    twin.load_state_dict(m.state_dict())
+    eager = FusedTrainStep(twin)
+    full.capture(lambda: batch)
+    for _ in range(2):
+        eager(batch)
+    for _ in range(3):
+        la, lb = float(full.replay()), float(eager(batch))
+        assert abs(la - lb) <= 1e-5 * abs(lb)
