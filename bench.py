@@ -56,9 +56,10 @@ def parse():
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
-    ap.add_argument("--plan-overlap", action="store_true",
-                    help="captured step: build the NEXT batch's plan on a forked branch of the graph instead of the step's own in "
-                         "front of its forward (measured SLOWER on ROCm 7.2: a forked hipGraph branch costs more than the 4 us launch it hides)")
+    ap.add_argument("--plan-overlap", default="none", choices=("none", "fused", "fork"),
+                    help="captured step: 'none' = the step's own plan build in front of its forward; 'fused' = every step derives "
+                         "the NEXT batch's plan inside its last launch (slab reduction + Adam); 'fork' = on a forked branch of the "
+                         "graph (measured SLOWER on ROCm 7.2)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
@@ -376,10 +377,12 @@ def main():
         for r in res:
             r.make_plan()
         for i, tr in enumerate(trainers):
-            if not args.plan_overlap:
+            if args.plan_overlap == "none":
                 tr.capture(res[i].fresh)
-            else:
+            elif args.plan_overlap == "fork":
                 tr.capture(res[i].planned, prefetch=res[(i + 1) % NB].plan.rebuild)
+            else:           # "fused": the step's last launch (slab reduction + Adam) also derives the next batch's plan
+                tr.capture(res[i].planned, next_plan=res[(i + 1) % NB].plan)
         fwdbwd.capture(r0.fresh)
         replay["full"] = [tr.replay for tr in trainers]
         replay["fwdbwd"] = fwdbwd.replay
@@ -617,7 +620,7 @@ def main():
                                    f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
                                    f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
-                                   f"{'' if (launch_mode != 'hipgraph' or not args.plan_overlap or not fused_ok) else ', plan build of the NEXT batch on a forked graph branch'}",
+                                   f"{'' if (launch_mode != 'hipgraph' or args.plan_overlap == 'none' or not fused_ok) else ', plan build of the NEXT batch ' + ('inside the last launch of the step' if args.plan_overlap == 'fused' else 'on a forked graph branch')}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "rccl_world": rccl_world,

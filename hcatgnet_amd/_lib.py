@@ -78,6 +78,7 @@ SIGNATURES = {
     "hcg_adam_step_dev_sse": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P, P]),
     "hcg_reduce_slabs_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P]),
     "hcg_adam_step_dev": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P]),
+    "hcg_reduce_slabs_adam_plan": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P, P, I64, I64, I64, P, P, P, P]),
     "hcg_fused_reduce_grads": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
 }
 

@@ -12,6 +12,7 @@
 //            + Batch collate): one wavefront per graph, edges staged in LDS, lane-per-node stable
 //            counting sort -- no device-wide sort, no atomics.
 #include "common.h"
+#include "ptrs.h"
 #include <hipcub/hipcub.hpp>
 
 namespace {
@@ -107,43 +108,7 @@ __global__ __launch_bounds__(256) void k_dinv(const int32_t* __restrict__ rowptr
 __global__ __launch_bounds__(256) void k_ptrs(const int64_t* __restrict__ ei, const int64_t* __restrict__ batch,
                                               int64_t N, int64_t E, int64_t B, int32_t* __restrict__ graph_ptr,
                                               int32_t* __restrict__ edge_ptr, int32_t* __restrict__ status) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int st = 0;
-  int64_t prev = -1, cur = B, pos;
-  int32_t* dst;
-  if (tid <= N) {
-    const int64_t i = tid;
-    pos = i; dst = graph_ptr;
-    if (i > 0) prev = batch[i - 1];
-    if (i < N) {
-      cur = batch[i];
-      if (cur < 0 || cur >= B) st |= HCG_STATUS_BATCH_RANGE;
-      if (i > 0 && cur < prev) st |= HCG_STATUS_BATCH_UNSORTED;
-    }
-  } else if (tid <= N + 1 + E) {
-    const int64_t e = tid - (N + 1);
-    pos = e; dst = edge_ptr;
-    if (e > 0) {
-      int64_t s = ei[e - 1];
-      if (s < 0 || s >= N) s = 0;  // range errors are flagged by the thread that owns the edge
-      prev = batch[s];
-    }
-    if (e < E) {
-      int64_t s = ei[e], d = ei[E + e];
-      if (s < 0 || s >= N || d < 0 || d >= N) { st |= HCG_STATUS_INDEX_RANGE; s = 0; d = 0; }
-      cur = batch[s];
-      if (batch[d] != cur) st |= HCG_STATUS_EDGE_UNGROUPED;
-      if (e > 0 && cur < prev) st |= HCG_STATUS_EDGE_UNGROUPED;
-    }
-  } else {
-    return;
-  }
-  if (st) atomicOr(status, st);
-  if (prev < -1) prev = -1;
-  if (prev > B) prev = B;
-  if (cur < 0) cur = 0;
-  if (cur > B) cur = B;
-  for (int64_t g = prev + 1; g <= cur; ++g) dst[g] = (int32_t)pos;
+  hcg_ptrs_thread((int64_t)blockIdx.x * blockDim.x + threadIdx.x, ei, batch, N, E, B, graph_ptr, edge_ptr, status);
 }
 
 constexpr int GE_LDS_EDGES = 2048;  // edges of one graph staged in LDS (16 KiB); larger graphs re-read global

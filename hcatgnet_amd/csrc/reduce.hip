@@ -4,6 +4,7 @@
 // segments that are written (with optional row compaction KPAD -> F) to their gradient tensors.
 // Every output element is summed over the slabs in a fixed order: bitwise reproducible.
 #include "common.h"
+#include "ptrs.h"
 
 namespace {
 
@@ -42,8 +43,25 @@ struct AdamArgs {
   float b1, b2, eps;
 };
 
-template <bool ADAM>
-__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
+// PLAN: row `njobs` of the grid derives the pointers of the NEXT batch's plan (hcg_ptrs_thread) beside the reduction -- the
+// one launch of the next step that depends on nothing of this step, folded into this step's last launch.
+struct PlanArgs {
+  const int64_t* ei;
+  const int64_t* batch;
+  int64_t N, E, B;
+  int32_t* graph_ptr;
+  int32_t* edge_ptr;
+  int32_t* status;
+};
+
+template <bool ADAM, bool PLAN = false>
+__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, PlanArgs P = PlanArgs{}) {
+  if (PLAN && (int)blockIdx.y == jobs.njobs) {        // block-uniform
+    const int64_t total = P.N + P.E + 2, stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride)
+      hcg_ptrs_thread(t, P.ei, P.batch, P.N, P.E, P.B, P.graph_ptr, P.edge_ptr, P.status);
+    return;
+  }
   __shared__ float part[RS][RO];
   const hcg_reduce_job& J = jobs.job[blockIdx.y];
   const int o = threadIdx.x % RO, sl = threadIdx.x / RO;
@@ -100,7 +118,8 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A) {
 
 }  // namespace
 
-static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamArgs* adam, int64_t n_flat, hipStream_t stream) {
+static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamArgs* adam, int64_t n_flat, hipStream_t stream,
+                         const PlanArgs* plan = nullptr) {
   if (njobs < 0 || njobs > HCG_REDUCE_MAX_JOBS || (njobs > 0 && !jobs_host)) return HCG_ERR_INVALID_ARG;
   if (njobs == 0) return adam ? HCG_ERR_INVALID_ARG : HCG_OK;
   Jobs jobs;
@@ -121,9 +140,10 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
     if (J.slab_floats > max_floats) max_floats = J.slab_floats;
   }
   for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
-  const dim3 grid((max_floats + RO - 1) / RO, njobs);
-  if (adam) hipLaunchKernelGGL(k_reduce_jobs<true>, grid, dim3(256), 0, stream, jobs, *adam);
-  else hipLaunchKernelGGL(k_reduce_jobs<false>, grid, dim3(256), 0, stream, jobs, AdamArgs{});
+  const dim3 grid((max_floats + RO - 1) / RO, njobs + (plan ? 1 : 0));
+  if (plan && adam) hipLaunchKernelGGL((k_reduce_jobs<true, true>), grid, dim3(256), 0, stream, jobs, *adam, *plan);
+  else if (adam) hipLaunchKernelGGL((k_reduce_jobs<true, false>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{});
+  else hipLaunchKernelGGL((k_reduce_jobs<false, false>), grid, dim3(256), 0, stream, jobs, AdamArgs{}, PlanArgs{});
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
@@ -138,6 +158,21 @@ extern "C" int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs,
   if (n <= 0 || !grad_flat || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
   AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
   return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream);
+}
+
+// hcg_reduce_slabs_adam + the pointers-only plan (HCG_PLAN_BLOCKED | HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS) of the NEXT
+// batch in the same launch
+extern "C" int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
+                                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
+                                          float beta2, float eps, const int32_t* step_dev, const int64_t* next_edge_index,
+                                          const int64_t* next_batch, int64_t N, int64_t E, int64_t B, int32_t* next_graph_ptr,
+                                          int32_t* next_edge_ptr, int32_t* next_status, hcg_stream_t stream) {
+  if (n <= 0 || !grad_flat || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
+  if (N < 0 || E < 0 || B < 0 || !next_batch || !next_graph_ptr || !next_edge_ptr || !next_status || (E > 0 && !next_edge_index))
+    return HCG_ERR_INVALID_ARG;
+  AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
+  PlanArgs pl{next_edge_index, next_batch, N, E, B, next_graph_ptr, next_edge_ptr, next_status};
+  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, &pl);
 }
 
 extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }

@@ -129,12 +129,13 @@ class FusedAdam(torch.optim.Optimizer):
         self._make_dev_state(fl, group)
         return fl["step_dev"]
 
-    def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor) -> bool:
+    def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor, next_plan=None) -> bool:
         """The backward's slab reduction and this optimiser's update as ONE launch (hcg_reduce_slabs_adam): `jobs_addr`
         = host address of the hcg_reduce_job array whose segments write `flat_grad` (the buffer the parameters'
         `.grad` are views of, in parameter order).  The step word returned by `fused_update_ready` must have been
         advanced earlier in this step (the head kernel does).  Returns False -- nothing launched -- when the
-        preconditions do not hold; the caller then issues the two launches."""
+        preconditions do not hold; the caller then issues the two launches.  `next_plan` (a pointers-only blocked
+        `BatchPlan` of the NEXT batch): its graph_ptr / edge_ptr are re-derived by the same launch."""
         if not self.capturable or len(self.param_groups) != 1:
             return False
         group = self.param_groups[0]
@@ -156,6 +157,16 @@ class FusedAdam(torch.optim.Optimizer):
             fl["lr_host"] = lr
             fl["lr_dev"].fill_(lr)
         lib = _lib.load()
+        if next_plan is not None:
+            np_ = next_plan
+            if np_.mode != "blocked" or np_.has_csr or not np_.shared_status:
+                raise _lib.HcgError("next_plan must be a pointers-only blocked plan built with validate=False")
+            _lib.check(lib.hcg_reduce_slabs_adam_plan(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
+                                                      fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
+                                                      fl["step_dev"].data_ptr(), np_.edge_index.data_ptr(), np_.batch.data_ptr(),
+                                                      np_.N, np_.E, np_.B, np_.graph_ptr.data_ptr(), np_.edge_ptr.data_ptr(),
+                                                      np_.status.data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam_plan")
+            return True
         _lib.check(lib.hcg_reduce_slabs_adam(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
                                              fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
                                              fl["step_dev"].data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam")

@@ -70,6 +70,10 @@ class FusedTrainStep:
         self._graph = None
         self._sync = {}
         self._capturing_split = False
+        # pipelined loaders: a pointers-only `BatchPlan` of the NEXT batch (built once with validate=False); the step's last
+        # launch (slab reduction + Adam) re-derives its graph_ptr / edge_ptr from the tensors' current contents, so the next
+        # step -- on a batch object that carries that plan (`batch._hcg_plan = plan`) -- starts without a plan launch
+        self.next_plan = None
 
     def _sync_words(self, dev: torch.device) -> torch.Tensor:
         """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
@@ -234,7 +238,7 @@ class FusedTrainStep:
             _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
             njobs += 1
         if step_word is not None:
-            if not opt.step_with_reduction(jaddr, njobs, flat):
+            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan):
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
@@ -484,7 +488,7 @@ class FusedTrainStep:
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
         #      are one launch (the update reads each gradient element as it is produced)
         if step_word is not None:
-            if not opt.step_with_reduction(jaddr, njobs, flat):    # (same preconditions as fused_update_ready)
+            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan):    # (same preconditions as fused_update_ready)
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
@@ -518,7 +522,7 @@ class FusedTrainStep:
             opt.step()
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, batch, prefetch=None):
+    def capture(self, batch, prefetch=None, next_plan=None):
         """Capture the step on `batch`'s tensors into a hipGraph; `replay()` re-runs it on whatever those tensors
         hold then (copy the next batch into them, or re-collate in place).  `batch` may be a callable returning the
         batch: whatever it enqueues (a device collate, the plan build of a fresh `Batch`) is captured too.  The optimiser switches to its
@@ -527,7 +531,10 @@ class FusedTrainStep:
         collective and the (single-launch) update eagerly behind it.
         `prefetch`: a callable whose launches are captured on a FORKED branch of the graph (forks at the start of the
         step, joins at its end): work for the NEXT step that does not depend on this one -- the next batch's plan build
-        (`BatchPlan.rebuild`), a device collate -- runs beside this step instead of in front of the next."""
+        (`BatchPlan.rebuild`), a device collate -- runs beside this step instead of in front of the next.
+        `next_plan`: sets `self.next_plan` (see `__init__`) for the captured step."""
+        if next_plan is not None:
+            self.next_plan = next_plan
         opt = self.model.optimizer
         if self.optimizer_step:
             if not hasattr(opt, "enable_capturable"):

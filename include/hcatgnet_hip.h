@@ -368,6 +368,15 @@ int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs, const floa
                           float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
                           float eps, const int32_t* step_dev, hcg_stream_t stream);
 
+/* The same launch also derives the pointers-only plan of the NEXT batch (what hcg_plan_build does with
+ * HCG_PLAN_BLOCKED | HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS: graph_ptr, edge_ptr, validation flags ORed into `status`):
+ * the one launch of the next step that depends on nothing of this one rides in this step's last launch. */
+int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
+                               float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
+                               float eps, const int32_t* step_dev, const int64_t* next_edge_index, const int64_t* next_batch,
+                               int64_t N, int64_t E, int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr,
+                               int32_t* next_status, hcg_stream_t stream);
+
 /* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),
  * node_ptr_all / edge_ptr_all [G+1] (int64), y_all [G], idx_all [G].  `ids` [B] selects graphs (device).

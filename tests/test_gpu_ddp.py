@@ -309,3 +309,43 @@ def test_plan_of_the_next_batch_on_a_forked_graph_branch(H, oracle):
     assert abs(loss - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
     for k, p in m.named_parameters():
         assert rel_inf(p.grad, ref[3][k]) <= 1e-5, k
+
+
+def test_next_batch_plan_inside_the_last_launch_of_the_step(H, oracle):
+    """capture(..., next_plan=plan): the slab reduction + Adam launch of a step also derives graph_ptr / edge_ptr of the NEXT
+    batch; the next step starts on a batch that carries that plan and launches no plan kernel.  Two trainers ping-pong over
+    two ragged batches; one batch gets new contents (other graph boundaries) between replays."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_config("C2", num_graphs=96, nodes=24, nodes_jitter=8, seed=11)
+    gl = sb.as_graph_list()
+    a, b = collate(gl[:48]).to("cuda"), collate(gl[48:]).to("cuda")
+    m = H.make_network("GCN", H.default_options(), 64).cuda()
+
+    def plan_of(bt):
+        return H.BatchPlan.build(bt.edge_index, bt.batch, bt.x.shape[0], num_graphs=bt.num_graphs, mode="blocked", validate=False,
+                                 max_nodes=32, max_edges=bt.max_edges + 16)
+    pa, pb = plan_of(a), plan_of(b)
+
+    def carrying(bt, pl):
+        def get():
+            bt._hcg_plan = pl
+            return bt
+        return get
+    ta, tb = FusedTrainStep(m), FusedTrainStep(m)
+    ta.capture(carrying(a, pa), next_plan=pb)
+    tb.capture(carrying(b, pb), next_plan=pa)
+
+    def check(step, bt_cpu):
+        params = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        loss = float(step.replay())
+        ref = _oracle_of(oracle, params, bt_cpu)
+        assert abs(loss - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+    check(ta, collate(gl[:48])); check(tb, collate(gl[48:])); check(ta, collate(gl[:48]))
+    a2 = collate(gl[:48][::-1])                             # new contents for batch a: same sizes, other graph boundaries
+    for name in ("x", "edge_index", "batch", "y"):
+        getattr(a, name).copy_(getattr(a2, name).to("cuda"))
+    check(tb, collate(gl[48:]))                             # ... tb's last launch re-derives a's plan
+    check(ta, a2)
+    assert int(pa.status[0].item()) == 0
