@@ -140,7 +140,10 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
     if (J.slab_floats > max_floats) max_floats = J.slab_floats;
   }
   for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
-  const dim3 grid((max_floats + RO - 1) / RO, njobs + (plan ? 1 : 0));
+  // (plan row: one thread per node / edge as k_ptrs runs it -- fewer, looping blocks serialise its dependent loads: +3 us)
+  unsigned gx = (max_floats + RO - 1) / RO;
+  if (plan) { const unsigned px = (unsigned)hcg_cdiv(plan->N + plan->E + 2, 256); if (px > gx) gx = px; }
+  const dim3 grid(gx, njobs + (plan ? 1 : 0));
   if (plan && adam) hipLaunchKernelGGL((k_reduce_jobs<true, true>), grid, dim3(256), 0, stream, jobs, *adam, *plan);
   else if (adam) hipLaunchKernelGGL((k_reduce_jobs<true, false>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{});
   else hipLaunchKernelGGL((k_reduce_jobs<false, false>), grid, dim3(256), 0, stream, jobs, AdamArgs{}, PlanArgs{});
