@@ -56,10 +56,10 @@ def parse():
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
-    ap.add_argument("--plan-overlap", default="none", choices=("none", "fused", "fork"),
+    ap.add_argument("--plan-overlap", default="fused", choices=("none", "fused", "fork"),
                     help="captured step: 'none' = the step's own plan build in front of its forward; 'fused' = every step derives "
-                         "the NEXT batch's plan inside its last launch (slab reduction + Adam); 'fork' = on a forked branch of the "
-                         "graph (measured SLOWER on ROCm 7.2)")
+                         "the NEXT batch's plan inside its last launch (slab reduction + Adam; -2.5 % at C3); 'fork' = on a forked "
+                         "branch of the graph (measured SLOWER on ROCm 7.2)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")

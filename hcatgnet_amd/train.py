@@ -242,6 +242,8 @@ class FusedTrainStep:
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+            if self.next_plan is not None:
+                self.next_plan.rebuild()                   # (no fused update to ride in: its own launch)
             if not self._capturing_split:
                 self._exchange_and_update(bufs["loss"])
         return bufs["loss"][0]
@@ -492,6 +494,8 @@ class FusedTrainStep:
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+            if self.next_plan is not None:
+                self.next_plan.rebuild()                   # (no fused update to ride in: its own launch)
             if not self._capturing_split:
                 self._exchange_and_update(bufs["loss"])
         self.last_out = bufs["out"]
