@@ -574,6 +574,8 @@ def main():
                       "hcg_fused_stack2_fwd": "k_fused_layer_fwd", "hcg_mid_layer_fwd": "k_mid_layer_fwd"}.get(entry)
             vals = [v["hbm_bytes"] for k, v in tj.items() if prefix and k.startswith(prefix)]
             traffic = sum(vals) / len(vals) if vals else None
+            if traffic is not None and entry.startswith("hcg_mid_") and D > 64:
+                traffic *= D // 64            # one call of the entry point = one kernel launch per 64-column half
             traffic_src = "profiles/traffic_latest.json: builder-run rocprofv3 PMC passes of this command, not measured in this run"
         except (OSError, ValueError, KeyError, AttributeError):
             traffic = None
