@@ -253,6 +253,8 @@ def main():
     from hcatgnet_amd import _lib, algbytes, synth
     from hcatgnet_amd.ddp import DataParallelGCN
     from hcatgnet_amd.train import FusedTrainStep
+    if os.environ.get("HCG_LIB"):      # a library variant for A/B measurements (tools/build_variants.sh)
+        _lib.LIB_PATH = os.path.abspath(os.environ["HCG_LIB"])
     lib = _lib.load()
     # development A/B switches (tools/ab_env.sh): measurement tooling only, the product has no environment switches
     if os.environ.get("HCG_NO_POOLBITS") == "1":

@@ -87,11 +87,14 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 // anyway; it is not the cause: plain v_fma_f32 sites sat at the same 12).  Guards: tools/isa_lint.py (tests/
 // test_isa_lint.py, CPU, every build: no non-MFMA instruction may touch an MFMA destination within 19 wait states in
 // fused.o / mid.o / head.o) and tests/test_gpu_train_step.py::test_forty_launches_are_bitwise_identical (behaviour).
+#ifndef HCG_FENCE_ASM      // (tools/build_variants.sh builds shorter fences for A/B measurements; the product build uses this one)
+#define HCG_FENCE_ASM "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+#endif
 __device__ __forceinline__ void mfma_results_fence(f32x16& a, f32x16& b) {
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
+  asm volatile(HCG_FENCE_ASM : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void mfma_results_fence(f32x16& a) {
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a));
+  asm volatile(HCG_FENCE_ASM : "+v"(a));
 }
 
 // acc += a * b with both operands split: the six cross terms >= 2^-24, smallest first

@@ -4,15 +4,19 @@ import sys, os, collections, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hcatgnet_amd as H
-from hcatgnet_amd import synth
+from hcatgnet_amd import synth, _lib
+if os.environ.get("HCG_LIB"):          # a library variant (tools/build_variants.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["HCG_LIB"])
+print("library", _lib.LIB_PATH, flush=True)
 from hcatgnet_amd.train import FusedTrainStep
 def digest(ts): 
     h = hashlib.md5()
     for t in ts: h.update(t.detach().cpu().numpy().tobytes())
     return h.hexdigest()
-for cfg, reps in (("C3", int(sys.argv[1]) if len(sys.argv) > 1 else 300), ("REAL", int(sys.argv[2]) if len(sys.argv) > 2 else 80)):
-    sb = synth.make_config(cfg)
-    m = H.make_network("GCN", H.default_options(), synth.CONFIGS[cfg]["feat"]).cuda()
+for cfg, reps in (("C3", int(sys.argv[1]) if len(sys.argv) > 1 else 300), ("REAL", int(sys.argv[2]) if len(sys.argv) > 2 else 80),
+                  ("RAGGED", int(sys.argv[3]) if len(sys.argv) > 3 else 80)):
+    sb = synth.make_config("C3", nodes_jitter=6, group_by_size=True) if cfg == "RAGGED" else synth.make_config(cfg)
+    m = H.make_network("GCN", H.default_options(), synth.CONFIGS["C3" if cfg == "RAGGED" else cfg]["feat"]).cuda()
     batch = sb.as_batch("cuda")
     step = FusedTrainStep(m, optimizer_step=False)
     c = collections.Counter()
