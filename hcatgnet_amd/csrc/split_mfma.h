@@ -82,6 +82,11 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 // destination (that is what the software wait states are for; dependent MFMAs through srcC are interlocked, which is why
 // the chains themselves never failed).  Safe distance at two waves per SIMD: 11 + 8 = 19 wait states.
 //
+// The model was then tested (round 2, tools/build_variants.sh + tools/stress_determinism.py): a fence of only 8 wait states
+// (`s_nop 7`: 19-20 with the compiler's own padding, the modelled minimum) and one of 20 both returned 0 bad launches of 600
+// (400 x C3, 100 x reference-sized, 100 x ragged batches), where 12 had failed 11-31 of 80.  They buy 0.8 % of the step
+// (0.1106 vs 0.1115 ms: the partner wave fills most of the idle slots), so the product keeps the long fence as margin.
+//
 // Fix kept here: 64 idle quad-cycles (4 x s_nop 15) between a chain's last MFMA and the first non-MFMA touch of its
 // accumulators (0 of 80 afterwards), and -fno-slp-vectorize for the MFMA files (v_pk_*_f32 beside MFMAs is slower on CDNA4
 // anyway; it is not the cause: plain v_fma_f32 sites sat at the same 12).  Guards: tools/isa_lint.py (tests/
