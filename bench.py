@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--combine", default="sse", choices=("sse", "mean"),
                     help="N > 1: 'sse' = gradient of sqrt(MSE) over the concatenated batch of all ranks (the reference's "
                          "semantics at batch N*B); 'mean' = mean of per-rank RMSE gradients (DDP convention)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "rccl", "oneshot"),
+                    help="N > 1: 'rccl' = all-reduce of the flat gradient between two launches; 'oneshot' = every rank writes its "
+                         "gradients into the peers' inboxes over the direct xGMI links inside the slab reduction + Adam launch; "
+                         "'auto' = one-shot if it sets up and passes its self test on this machine, else RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -458,22 +462,9 @@ def main():
     log("warm-up done")
     launch_counts = count_launching_calls()
 
-    launch_mode, graph_err = "eager", None
-    if not args.no_graph:
-        try:
-            if world > 1 and fused_ok:          # the exchange sits between backward and update: the graph ends before it
-                for tr in trainers + [fwdbwd]:
-                    tr.grad_sync = (lambda flat: None)
-                    tr.combine = args.combine
-            capture_all()                       # before RCCL comes up: no collective activity while a stream is capturing
-            launch_mode = "hipgraph"
-            log("step captured into hipGraphs")
-        except Exception as exc:  # report, never hide: the eager number stands
-            replay.clear()
-            graph_err = f"{type(exc).__name__}: {exc}"
-            log(f"graph capture failed, keeping eager launches: {graph_err}")
-
-    rccl_world = None
+    # ---- N > 1: process group, weights replicated, the gradient exchange chosen -- BEFORE the capture, so that a one-shot
+    #      exchange (inside the step's last launch) is captured with the step
+    rccl_world, exchange_mode, xchg = None, "none", None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -483,13 +474,38 @@ def main():
         rccl_world = dist.get_world_size()
         if rccl_world != world:
             raise SystemExit(f"bench.py: the process group reports world size {rccl_world}, expected {world}")
-        dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place: the graphs see them)
+        dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place)
+        exchange_mode = "rccl"
         if fused_ok:
             for tr in trainers + [fwdbwd]:
                 dp.attach(tr)
-        for j in range(3):
+            if args.exchange != "rccl":
+                # the one-shot xGMI exchange, if it sets up and passes its self test against the process group's own
+                # all-reduce on THIS machine (every rank gets the same verdict); else the RCCL collective stays
+                from hcatgnet_amd.xgmi import OneShotExchange
+                xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
+                if xchg.ok and xchg.self_test():
+                    for tr in trainers:
+                        xchg.attach(tr)
+                    exchange_mode = "oneshot"
+                elif args.exchange == "oneshot":
+                    raise SystemExit("bench.py: --exchange oneshot, but the one-shot exchange failed its set-up / self test")
+                log(f"one-shot exchange: {'in use' if exchange_mode == 'oneshot' else 'not usable here, RCCL all-reduce stays'}")
+        for j in range(max(3, NB)):
             eager_step(j % NB)
-        log(f"{'gloo (rehearsal)' if rehearsal else 'RCCL'} process group up: world {rccl_world}")
+        torch.cuda.synchronize()
+        log(f"{'gloo (rehearsal)' if rehearsal else 'RCCL'} process group up: world {rccl_world}, exchange {exchange_mode}")
+
+    launch_mode, graph_err = "eager", None
+    if not args.no_graph:
+        try:
+            capture_all()     # (RCCL form: the graph ends before the collective; one-shot form: the whole step is one graph)
+            launch_mode = "hipgraph"
+            log("step captured into hipGraphs")
+        except Exception as exc:  # report, never hide: the eager number stands
+            replay.clear()
+            graph_err = f"{type(exc).__name__}: {exc}"
+            log(f"graph capture failed, keeping eager launches: {graph_err}")
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
     mid = r0.sb.max_nodes > 32
@@ -548,6 +564,8 @@ def main():
         f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode})")
     for tr in trainers:
         tr.check_health()
+    if xchg is not None and exchange_mode == "oneshot":
+        xchg.check()
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(v for k, v in bd.items() if not args.forward_only or k.endswith("_fwd") or k == "csr_build")
@@ -613,7 +631,7 @@ def main():
                                               if fused_ok else 0))
         fwd_only_note = "plan/gcn_norm build + forward (conv stack, pool, readout) only" if args.forward_only else \
             (f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
-             f"{'RCCL all-reduce (' + args.combine + '), ' if world > 1 else ''}Adam update")
+             f"{('one-shot xGMI exchange inside the update launch (' if exchange_mode == 'oneshot' else 'RCCL all-reduce (') + args.combine + '), ' if world > 1 else ''}Adam update")
         rec = {
             "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s" if not args.forward_only
                       else "molecular graphs/sec FORWARD ONLY (configs[1]; not the headline metric)",
@@ -626,8 +644,9 @@ def main():
                                    f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
                                    f"{'' if (launch_mode != 'hipgraph' or args.plan_overlap == 'none' or not fused_ok) else ', plan build of the NEXT batch ' + ('inside the last launch of the step' if args.plan_overlap == 'fused' else 'on a forked graph branch')}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
-                       "parallelism": f"dp{world} (batch-of-graphs, RCCL all-reduce of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
-            "rccl_world": rccl_world,
+                       "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
+                                      f"of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
+            "rccl_world": rccl_world, "exchange": exchange_mode,
             "distinct_batches": NB, "bytes_touched_between_reuse": touched,
             "sustained_s": sus_s, "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3,
                                                 "value": world * B * sus_steps / sus_s if sus_s > 0 else None,

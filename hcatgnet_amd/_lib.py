@@ -17,6 +17,7 @@ HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
 HCG_HEAD_MSE, HCG_HEAD_RMSE, HCG_HEAD_SSE = 0, 1, 2      # `rmse` argument of hcg_head_fwd_bwd_ex
 HCG_HEAD_SYNC_WORDS, HCG_HEAD_ERR_TIMEOUT = 520, 1
+HCG_XCHG_MEAN, HCG_XCHG_SSE, HCG_XCHG_ERR_TIMEOUT, HCG_XCHG_MAX_WORLD = 0, 1, 1, 8
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
                16: "a graph exceeds the fused-kernel tile",
@@ -80,6 +81,15 @@ SIGNATURES = {
     "hcg_adam_step_dev": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P]),
     "hcg_reduce_slabs_adam_plan": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P, P, I64, I64, I64, P, P, P, P]),
     "hcg_fused_reduce_grads": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
+    "hcg_xchg_inbox_bytes": (SZ, [I64, INT]),
+    "hcg_xchg_alloc": (INT, [SZ, P]),
+    "hcg_xchg_free": (INT, [P]),
+    "hcg_xchg_zero": (INT, [P, SZ]),
+    "hcg_xchg_ipc_export": (INT, [P, P]),
+    "hcg_xchg_ipc_open": (INT, [P, P]),
+    "hcg_xchg_ipc_close": (INT, [P]),
+    "hcg_reduce_slabs_xchg_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P, P, INT, INT, INT, P, P,
+                                         P, P, I64, I64, I64, P, P, P, P]),
 }
 
 _lib = None

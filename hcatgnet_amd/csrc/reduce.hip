@@ -4,6 +4,7 @@
 // segments that are written (with optional row compaction KPAD -> F) to their gradient tensors.
 // Every output element is summed over the slabs in a fixed order: bitwise reproducible.
 #include "common.h"
+#include <string.h>
 #include "ptrs.h"
 
 namespace {
@@ -54,8 +55,63 @@ struct PlanArgs {
   int32_t* status;
 };
 
-template <bool ADAM, bool PLAN = false>
-__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, PlanArgs P = PlanArgs{}) {
+// XCHG: data-parallel one-shot exchange fused between the reduction and the update.  Every rank owns an
+// INBOX of 2 x world x (n + 2) eight-byte granules {fp32 value, step stamp} in fine-grained (uncached) device memory that
+// its peers map through IPC.  The thread that finishes a gradient element stores it as ONE 8-byte system-scope granule into
+// every peer's inbox over the direct xGMI link (a granule is written by one store: no flag, no ordering needed), then polls
+// the `world - 1` granules its peers wrote into ITS inbox until their stamp is this step's, adds all contributions in
+// RANK ORDER (bitwise the same sum on every rank: replicas cannot drift) and applies the update.  Inboxes are double-buffered
+// by step parity: a peer can only overwrite the slots of step s at step s + 2, which it reaches after it has received this
+// rank's step-(s + 1) granules, i.e. after this rank has finished reading step s.  Every poll is bounded (2 s of the
+// 100 MHz clock): on expiry the error word gets HCG_XCHG_ERR_TIMEOUT and the element becomes NaN instead of a hang.
+struct XchgArgs {
+  unsigned long long* inbox;                     // this rank's inbox (local, fine-grained)
+  unsigned long long* peer[HCG_XCHG_MAX_WORLD];  // every rank's inbox as mapped here (peer[rank] == inbox)
+  int rank, world;
+  int64_t n_ext;                                 // n + 2: gradients | SSE | count
+  int mode;                                      // HCG_XCHG_MEAN: (sum over ranks) / world; HCG_XCHG_SSE: the SSE form's scale
+  float* flat_ext;                               // [n + 2] local: gradients are written back here, [n], [n + 1] = this rank's SSE, count
+  float* loss;                                   // [2]: SSE mode: global sqrt(MSE), MSE
+  int32_t* err;
+};
+
+constexpr unsigned long long XCHG_SPIN_TICKS = 200000000ull;
+
+__device__ __forceinline__ void xchg_publish(const XchgArgs& X, int parity, int64_t elem, float v, unsigned step) {
+  const unsigned long long g = ((unsigned long long)step << 32) | (unsigned long long)__float_as_uint(v);
+  const size_t slot = ((size_t)parity * X.world + X.rank) * X.n_ext + elem;
+  for (int p = 0; p < X.world; ++p)
+    if (p != X.rank) __hip_atomic_store(X.peer[p] + slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// sum over the ranks in rank order; `mine` = this rank's own contribution
+__device__ __forceinline__ float xchg_gather(const XchgArgs& X, int parity, int64_t elem, float mine, unsigned step) {
+  float sum = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int q = 0; q < X.world; ++q) {
+    float v = mine;
+    if (q != X.rank) {
+      const unsigned long long* src = X.inbox + ((size_t)parity * X.world + q) * X.n_ext + elem;
+      unsigned long long g;
+      for (;;) {
+        g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(g >> 32) == step) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > XCHG_SPIN_TICKS) {
+          atomicOr(X.err, HCG_XCHG_ERR_TIMEOUT);
+          g = 0x7fc00000ull;                         // NaN
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      v = __uint_as_float((unsigned)g);
+    }
+    sum += v;
+  }
+  return sum;
+}
+
+template <bool ADAM, bool PLAN = false, bool XCHG = false>
+__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, PlanArgs P = PlanArgs{}, XchgArgs X = XchgArgs{}) {
   if (PLAN && (int)blockIdx.y == jobs.njobs) {        // block-uniform
     const int64_t total = P.N + P.E + 2, stride = (int64_t)gridDim.x * 256;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride)
@@ -67,11 +123,29 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
   const int o = threadIdx.x % RO, sl = threadIdx.x / RO;
   const int idx = blockIdx.x * RO + o;
   if (blockIdx.x * RO >= J.slab_floats) return;   // block-uniform
-  __shared__ float adam_c[3];                        // lr / bias-correction-1, sqrt(bias-correction-2)
+  __shared__ float adam_c[3];                        // lr / bias-correction-1, sqrt(bias-correction-2), [XCHG] gradient scale
+  const unsigned xstep = XCHG ? (unsigned)A.step_dev[0] : 0u;
+  const int parity = (int)(xstep & 1u);
   if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation
     const int t = A.step_dev[0];                     // number of THIS update (advanced earlier in the step)
     adam_c[0] = A.lr_dev[0] / (float)(1.0 - hcg_powi((double)A.b1, t));
     adam_c[1] = (float)sqrt(1.0 - hcg_powi((double)A.b2, t));
+  }
+  if (XCHG && threadIdx.x == 255) {                  // the two tail elements [SSE, count]: published once per rank, gathered by every block
+    const int64_t n = X.n_ext - 2;
+    const float sse = X.flat_ext[n], cnt = X.flat_ext[n + 1];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      xchg_publish(X, parity, n, sse, xstep);
+      xchg_publish(X, parity, n + 1, cnt, xstep);
+    }
+    float scale = 1.0f / (float)X.world;
+    if (X.mode == HCG_XCHG_SSE) {
+      const float sse_t = xchg_gather(X, parity, n, sse, xstep), cnt_t = xchg_gather(X, parity, n + 1, cnt, xstep);
+      const float mse = sse_t / cnt_t, lv = sqrtf(mse);
+      scale = 1.0f / (cnt_t * lv);
+      if (blockIdx.x == 0 && blockIdx.y == 0) { X.loss[0] = lv; X.loss[1] = mse; }
+    }
+    adam_c[2] = scale;
   }
   // where this output element goes (threads of slice 0 only), and -- fused update -- its parameter and moments,
   // requested BEFORE the slab loop: the update then waits on nothing but the sum
@@ -105,6 +179,10 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < RS; ++k) tot += part[k][o];
+    if (XCHG) {                                        // this rank's partial -> every peer; all ranks' partials -> the gradient
+      xchg_publish(X, parity, (int64_t)off, tot, xstep);
+      tot = xchg_gather(X, parity, (int64_t)off, tot, xstep) * adam_c[2];
+    }
     *gdst = tot;
     if (ADAM) {
       const float mi = A.b1 * m0 + (1.0f - A.b1) * tot;
@@ -119,7 +197,7 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
 }  // namespace
 
 static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamArgs* adam, int64_t n_flat, hipStream_t stream,
-                         const PlanArgs* plan = nullptr) {
+                         const PlanArgs* plan = nullptr, const XchgArgs* xchg = nullptr) {
   if (njobs < 0 || njobs > HCG_REDUCE_MAX_JOBS || (njobs > 0 && !jobs_host)) return HCG_ERR_INVALID_ARG;
   if (njobs == 0) return adam ? HCG_ERR_INVALID_ARG : HCG_OK;
   Jobs jobs;
@@ -144,9 +222,11 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
   unsigned gx = (max_floats + RO - 1) / RO;
   if (plan) { const unsigned px = (unsigned)hcg_cdiv(plan->N + plan->E + 2, 256); if (px > gx) gx = px; }
   const dim3 grid(gx, njobs + (plan ? 1 : 0));
-  if (plan && adam) hipLaunchKernelGGL((k_reduce_jobs<true, true>), grid, dim3(256), 0, stream, jobs, *adam, *plan);
-  else if (adam) hipLaunchKernelGGL((k_reduce_jobs<true, false>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{});
-  else hipLaunchKernelGGL((k_reduce_jobs<false, false>), grid, dim3(256), 0, stream, jobs, AdamArgs{}, PlanArgs{});
+  if (xchg && adam && plan) hipLaunchKernelGGL((k_reduce_jobs<true, true, true>), grid, dim3(256), 0, stream, jobs, *adam, *plan, *xchg);
+  else if (xchg && adam) hipLaunchKernelGGL((k_reduce_jobs<true, false, true>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{}, *xchg);
+  else if (plan && adam) hipLaunchKernelGGL((k_reduce_jobs<true, true, false>), grid, dim3(256), 0, stream, jobs, *adam, *plan, XchgArgs{});
+  else if (adam) hipLaunchKernelGGL((k_reduce_jobs<true, false, false>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{}, XchgArgs{});
+  else hipLaunchKernelGGL((k_reduce_jobs<false, false, false>), grid, dim3(256), 0, stream, jobs, AdamArgs{}, PlanArgs{}, XchgArgs{});
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
@@ -176,6 +256,70 @@ extern "C" int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int n
   AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
   PlanArgs pl{next_edge_index, next_batch, N, E, B, next_graph_ptr, next_edge_ptr, next_status};
   return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, &pl);
+}
+
+// ---- one-shot gradient exchange over xGMI (data parallel): buffers + the fused launch ------------------------------
+extern "C" size_t hcg_xchg_inbox_bytes(int64_t n, int world) {
+  if (n <= 0 || world < 1 || world > HCG_XCHG_MAX_WORLD) return 0;
+  return (size_t)2 * world * (n + 2) * sizeof(unsigned long long);
+}
+// fine-grained (uncached) device memory for an inbox: the ONE allocation this library makes (a peer's kernel writes into
+// it while this rank's kernel polls it, which ordinary coarse-grained device memory does not make visible); zero-filled
+extern "C" int hcg_xchg_alloc(size_t bytes, void** ptr) {
+  if (!ptr || bytes == 0) return HCG_ERR_INVALID_ARG;
+  hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) return hcg_hip_err(e);
+  e = hipMemset(*ptr, 0, bytes);
+  if (e != hipSuccess) return hcg_hip_err(e);
+  return hcg_hip_err(hipDeviceSynchronize());
+}
+extern "C" int hcg_xchg_free(void* ptr) { return ptr ? hcg_hip_err(hipFree(ptr)) : HCG_OK; }
+// zero an inbox (between optimisers: the stamps are step numbers); synchronises the device
+extern "C" int hcg_xchg_zero(void* ptr, size_t bytes) {
+  if (!ptr) return HCG_ERR_INVALID_ARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemset(ptr, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return hcg_hip_err(e);
+}
+extern "C" int hcg_xchg_ipc_export(void* ptr, void* handle64) {
+  if (!ptr || !handle64) return HCG_ERR_INVALID_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == HCG_XCHG_HANDLE_BYTES, "IPC handle size");
+  return hcg_hip_err(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle64), ptr));
+}
+extern "C" int hcg_xchg_ipc_open(const void* handle64, void** ptr) {
+  if (!ptr || !handle64) return HCG_ERR_INVALID_ARG;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  return hcg_hip_err(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+}
+extern "C" int hcg_xchg_ipc_close(void* ptr) { return ptr ? hcg_hip_err(hipIpcCloseMemHandle(ptr)) : HCG_OK; }
+
+extern "C" int hcg_reduce_slabs_xchg_adam(const hcg_reduce_job* jobs_host, int njobs, float* flat_ext, float* param_flat,
+                                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
+                                          float beta2, float eps, const int32_t* step_dev, void* inbox, void* const* peers,
+                                          int rank, int world, int mode, float* loss, int32_t* err,
+                                          const int64_t* next_edge_index, const int64_t* next_batch, int64_t N, int64_t E,
+                                          int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr, int32_t* next_status,
+                                          hcg_stream_t stream) {
+  if (n <= 0 || !flat_ext || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || !inbox || !peers || !loss || !err)
+    return HCG_ERR_INVALID_ARG;
+  if (world < 1 || world > HCG_XCHG_MAX_WORLD || rank < 0 || rank >= world || (mode != HCG_XCHG_MEAN && mode != HCG_XCHG_SSE))
+    return HCG_ERR_INVALID_ARG;
+  AdamArgs a{flat_ext, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
+  XchgArgs x{};
+  x.inbox = (unsigned long long*)inbox;
+  for (int p = 0; p < world; ++p) {
+    if (!peers[p]) return HCG_ERR_INVALID_ARG;
+    x.peer[p] = (unsigned long long*)peers[p];
+  }
+  x.rank = rank; x.world = world; x.n_ext = n + 2; x.mode = mode; x.flat_ext = flat_ext; x.loss = loss; x.err = err;
+  if (next_batch) {
+    if (N < 0 || E < 0 || B < 0 || !next_graph_ptr || !next_edge_ptr || !next_status || (E > 0 && !next_edge_index)) return HCG_ERR_INVALID_ARG;
+    PlanArgs pl{next_edge_index, next_batch, N, E, B, next_graph_ptr, next_edge_ptr, next_status};
+    return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, &pl, &x);
+  }
+  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, nullptr, &x);
 }
 
 extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }

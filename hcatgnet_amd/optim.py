@@ -129,7 +129,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._make_dev_state(fl, group)
         return fl["step_dev"]
 
-    def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor, next_plan=None) -> bool:
+    def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor, next_plan=None, exchange=None,
+                            flat_ext=None, mode: str = "mean", loss_buf=None) -> bool:
         """The backward's slab reduction and this optimiser's update as ONE launch (hcg_reduce_slabs_adam): `jobs_addr`
         = host address of the hcg_reduce_job array whose segments write `flat_grad` (the buffer the parameters'
         `.grad` are views of, in parameter order).  The step word returned by `fused_update_ready` must have been
@@ -161,6 +162,12 @@ class FusedAdam(torch.optim.Optimizer):
             np_ = next_plan
             if np_.mode != "blocked" or np_.has_csr or not np_.shared_status:
                 raise _lib.HcgError("next_plan must be a pointers-only blocked plan built with validate=False")
+        if exchange is not None:      # data parallel: the one-shot xGMI exchange sits between the reduction and the update
+            if flat_ext is None or flat_ext.data_ptr() != flat_grad.data_ptr() or flat_ext.numel() != fl["n"] + 2 or loss_buf is None:
+                raise _lib.HcgError("one-shot exchange: needs the extended flat buffer [gradients | SSE | count] and the loss buffer")
+            exchange.launch(jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan)
+            return True
+        if next_plan is not None:
             _lib.check(lib.hcg_reduce_slabs_adam_plan(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
                                                       fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
                                                       fl["step_dev"].data_ptr(), np_.edge_index.data_ptr(), np_.batch.data_ptr(),

@@ -27,6 +27,7 @@ import ctypes
 from typing import Optional
 
 import torch
+import torch.distributed
 
 from . import _lib
 from . import functional as HF
@@ -74,6 +75,9 @@ class FusedTrainStep:
         # launch (slab reduction + Adam) re-derives its graph_ptr / edge_ptr from the tensors' current contents, so the next
         # step -- on a batch object that carries that plan (`batch._hcg_plan = plan`) -- starts without a plan launch
         self.next_plan = None
+        # data parallel: a `xgmi.OneShotExchange` (set by its `attach`): the gradient exchange then happens INSIDE the slab
+        # reduction + Adam launch instead of as an RCCL collective between two launches
+        self.exchange = None
 
     def _sync_words(self, dev: torch.device) -> torch.Tensor:
         """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
@@ -181,8 +185,8 @@ class FusedTrainStep:
                 views[id(q)] = flat[off:off + q.numel()]
                 off += q.numel()
             g = lambda prm: p(views[id(prm)])
-            if (self.optimizer_step and self.grad_sync is None and self.combine == "mean" and not self._capturing_split
-                    and hasattr(opt, "fused_update_ready")):
+            if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
+                    and (self.combine == "mean" or self.exchange is not None) and hasattr(opt, "fused_update_ready")):
                 step_word = opt.fused_update_ready(flat)
         sse = self.combine == "sse" and not _forward_only
         mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
@@ -238,7 +242,8 @@ class FusedTrainStep:
             _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
             njobs += 1
         if step_word is not None:
-            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan):
+            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
+                                           flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
@@ -400,8 +405,8 @@ class FusedTrainStep:
             g = lambda prm: p(views[id(prm)])
             # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
             # advances the step number that launch reads
-            if (self.optimizer_step and self.grad_sync is None and self.combine == "mean" and not self._capturing_split
-                    and hasattr(opt, "fused_update_ready")):
+            if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
+                    and (self.combine == "mean" or self.exchange is not None) and hasattr(opt, "fused_update_ready")):
                 step_word = opt.fused_update_ready(flat)
         sse = self.combine == "sse" and not _forward_only
         mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
@@ -490,7 +495,8 @@ class FusedTrainStep:
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
         #      are one launch (the update reads each gradient element as it is produced)
         if step_word is not None:
-            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan):    # (same preconditions as fused_update_ready)
+            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
+                                           flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):    # (same preconditions as fused_update_ready)
                 raise _lib.HcgError("optimizer state changed between head launch and update")
         else:
             _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
@@ -570,7 +576,9 @@ class FusedTrainStep:
             self._capturing_split = split              # with an exchange, the graph ends after the slab reduction
             g_main = torch.cuda.CUDAGraph()
             fork = torch.cuda.Stream() if prefetch is not None else None
-            with torch.cuda.graph(g_main):
+            # (a live process group has helper threads that query events: their calls must not fail this capture)
+            mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            with torch.cuda.graph(g_main, capture_error_mode=mode):
                 if fork is not None:
                     main = torch.cuda.current_stream()
                     fork.wait_stream(main)

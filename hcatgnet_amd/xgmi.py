@@ -1,0 +1,189 @@
+"""One-shot gradient exchange over xGMI for the data-parallel step.
+
+RCCL's all-reduce of the 66 KB flat gradient is latency-bound (a ring is 2 x 7 hops on a point-to-point fabric) and sits,
+with its own launch and the separate update launch, on the critical path of a ~0.11 ms step.  On MI355X every GPU has a
+direct link to each of its 7 peers, so the exchange can be ONE hop: each rank writes its partial gradient straight into
+every peer's inbox and sums the 8 contributions it received -- fused INTO the slab reduction + Adam launch
+(`hcg_reduce_slabs_xchg_adam`, csrc/reduce.hip), so the data-parallel step keeps the launch count of the single-GPU step
+and is captured as one hipGraph.
+
+    xchg = OneShotExchange(n_params)            # after torch.distributed is up: inboxes allocated, mapped across processes
+    ok = xchg.self_test()                       # a few exchanges of known data against torch.distributed's all-reduce
+    step = dp.make_train_step(); xchg.attach(step)   # only if ok: else the RCCL path stays
+
+The reference has no distributed code (scripts_experiments/train_GNN.py:29); this is build-defined.  The kernel's polls
+are bounded: a peer that never writes gives NaN gradients and `check()` raises -- never a hang.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class OneShotExchange:
+    def __init__(self, n: int, process_group=None, device: Optional[torch.device] = None):
+        """Collective: every rank of the group constructs one.  `self.ok` is the ALL-RANK verdict of the set-up (allocation,
+        IPC export, mapping of every peer's inbox): whatever fails on whichever rank, every rank issues the same
+        collectives and ends with the same `ok` -- a rank must never be left waiting inside one."""
+        if not (dist.is_available() and dist.is_initialized()):
+            raise _lib.HcgError("OneShotExchange needs an initialised torch.distributed process group")
+        lib = _lib.load()
+        self.lib, self.group, self.n = lib, process_group, int(n)
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.inbox, self.bytes, self._opened = None, 0, []
+        self.peers = (ctypes.c_void_p * max(self.world, 1))()
+        self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
+        good, handle = self.world <= _lib.HCG_XCHG_MAX_WORLD, b""
+        if good:
+            try:
+                self.bytes = int(lib.hcg_xchg_inbox_bytes(self.n, self.world))
+                ptr = ctypes.c_void_p()
+                _lib.check(lib.hcg_xchg_alloc(self.bytes, ctypes.byref(ptr)), "hcg_xchg_alloc")
+                self.inbox = ptr.value
+                hbuf = ctypes.create_string_buffer(64)
+                _lib.check(lib.hcg_xchg_ipc_export(self.inbox, hbuf), "hcg_xchg_ipc_export")
+                handle = hbuf.raw
+            except Exception:                                       # noqa: BLE001
+                good = False
+        handles: List[Optional[bytes]] = [None] * self.world
+        dist.all_gather_object(handles, handle if good else b"", group=process_group)
+        if good and all(h is not None and len(h) == 64 for h in handles):
+            try:
+                for q in range(self.world):
+                    if q == self.rank:
+                        self.peers[q] = self.inbox
+                        continue
+                    pp = ctypes.c_void_p()
+                    _lib.check(lib.hcg_xchg_ipc_open(handles[q], ctypes.byref(pp)), "hcg_xchg_ipc_open")
+                    self.peers[q] = pp.value
+                    self._opened.append(pp.value)
+            except Exception:                                       # noqa: BLE001
+                good = False
+        else:
+            good = False
+        verdict = torch.tensor([1 if good else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=process_group)   # (also: every inbox is mapped everywhere from here on)
+        self.ok = bool(int(verdict.item()))
+
+    # ------------------------------------------------------------------ the fused launch (called by FusedAdam)
+    def launch(self, jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan=None):
+        np_ = next_plan
+        args = (None, None, 0, 0, 0, None, None, None) if np_ is None else (
+            np_.edge_index.data_ptr(), np_.batch.data_ptr(), np_.N, np_.E, np_.B, np_.graph_ptr.data_ptr(),
+            np_.edge_ptr.data_ptr(), np_.status.data_ptr())
+        _lib.check(self.lib.hcg_reduce_slabs_xchg_adam(
+            jobs_addr, njobs, flat_ext.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(), fl["n"],
+            fl["lr_dev"].data_ptr(), b1, b2, eps, fl["step_dev"].data_ptr(), self.inbox, self.peers, self.rank, self.world,
+            _lib.HCG_XCHG_SSE if mode == "sse" else _lib.HCG_XCHG_MEAN, loss_buf.data_ptr(), self.err.data_ptr(), *args,
+            _lib.stream_ptr()), "hcg_reduce_slabs_xchg_adam")
+
+    def attach(self, step):
+        """Route a `train.FusedTrainStep` (already made data parallel by `DataParallelGCN.attach`) through this exchange:
+        its `grad_sync` hook is dropped -- the exchange happens inside the step's last launch."""
+        if not self.ok:
+            raise _lib.HcgError("this exchange failed its set-up or self test: keep the RCCL path")
+        n = sum(q.numel() for q in step.model.parameters() if q.requires_grad)
+        if n != self.n:
+            raise ValueError(f"exchange built for {self.n} gradients, the model has {n}")
+        if not (step.optimizer_step and hasattr(step.model.optimizer, "step_with_reduction")):
+            raise ValueError("the one-shot exchange rides in the fused update: it needs optimizer_step=True and FusedAdam")
+        step.exchange = self
+        step.grad_sync = None
+        return step
+
+    def check(self):
+        """Synchronising read of the error word: raises if a poll timed out (that step's gradients are NaN)."""
+        if int(self.err[0].item()) & _lib.HCG_XCHG_ERR_TIMEOUT:
+            self.err.zero_()
+            raise _lib.HcgError("one-shot exchange: a peer's gradients never arrived (poll timed out)")
+
+    # ------------------------------------------------------------------ self test against torch.distributed
+    def self_test(self, rounds: int = 3) -> bool:
+        """A few exchanges of rank-dependent data through a throw-away parameter set, checked against the process group's
+        own all-reduce on EVERY rank (the verdict is all-reduced too: all ranks agree).  False = do not use this exchange."""
+        from .optim import FusedAdam
+        ok = self.ok
+        dev, n = self.device, self.n
+        try:
+            p = torch.nn.Parameter(torch.zeros(n, device=dev))
+            opt = FusedAdam([p], lr=0.0)
+            opt.enable_capturable()
+            flat_ext = torch.zeros(n + 2, device=dev)
+            p.grad = flat_ext[:n]
+            if opt.fused_update_ready(flat_ext[:n]) is None:
+                raise _lib.HcgError("self test: the fused update is not available")
+            fl = opt._flat[0]
+            loss = torch.zeros(2, device=dev)
+            # one reduction job over ONE slab = the data itself
+            jb = self.lib.hcg_reduce_job_bytes()
+            job = ctypes.create_string_buffer(jb)
+            slab = torch.empty(n, device=dev)
+
+            class _Seg(ctypes.Structure):
+                _fields_ = [("begin", ctypes.c_int32), ("count", ctypes.c_int32), ("row_in", ctypes.c_int32),
+                            ("row_out", ctypes.c_int32), ("dst", ctypes.c_void_p)]
+
+            class _Job(ctypes.Structure):
+                _fields_ = [("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int32), ("slab_floats", ctypes.c_int32),
+                            ("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("seg", _Seg * 4)]
+            assert ctypes.sizeof(_Job) == jb
+            j = _Job.from_buffer(job)
+            j.slabs, j.nslabs, j.slab_floats, j.nseg = slab.data_ptr(), 1, n, 1
+            j.seg[0] = _Seg(0, n, n, n, flat_ext.data_ptr())
+            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        except Exception:                                           # noqa: BLE001  (any failure = fall back to RCCL)
+            ok = False
+        # the rounds: every rank issues the SAME collectives whatever fails locally (a rank that raised must not leave
+        # the others waiting inside an all-reduce)
+        for r in range(rounds):
+            ref = torch.zeros(self.n + 2, device=self.device)
+            if ok:
+                try:
+                    data = torch.randn(n, generator=g).to(dev)
+                    slab.copy_(data)
+                    flat_ext[n] = float(self.rank + 1) * (r + 1)        # "SSE"
+                    flat_ext[n + 1] = 10.0 * (self.rank + 1)            # "count"
+                    fl["step_dev"][0] += 1                              # what the head kernel does in a real step
+                    ref = torch.cat([data, flat_ext[n:].clone()])
+                    self.launch(ctypes.addressof(job), 1, flat_ext, fl, 0.9, 0.999, 1e-9, "sse", loss)
+                    torch.cuda.synchronize()
+                except Exception:                                       # noqa: BLE001
+                    ok = False
+            dist.all_reduce(ref, group=self.group)
+            if ok:
+                sse, cnt = float(ref[n]), float(ref[n + 1])
+                want = ref[:n] / (cnt * (sse / cnt) ** 0.5)
+                got = flat_ext[:n]
+                err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+                if (not (err <= 1e-5) or int(self.err[0].item()) != 0
+                        or not (abs(float(loss[0]) - (sse / cnt) ** 0.5) <= 1e-5 * (sse / cnt) ** 0.5)):
+                    ok = False
+        verdict = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
+        self.err.zero_()
+        # the throw-away optimiser's step stamps are gone: the inbox must be clean for the real one
+        self.reset()
+        self.ok = bool(int(verdict.item()))
+        return self.ok
+
+    def reset(self):
+        """Zero this rank's inbox (between optimisers: stamps are step numbers).  Collective: all ranks call it."""
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        if self.inbox:
+            self.lib.hcg_xchg_zero(self.inbox, self.bytes)
+        dist.barrier(group=self.group)
+
+    def close(self):
+        for pp in self._opened:
+            self.lib.hcg_xchg_ipc_close(pp)
+        self._opened = []
+        if self.inbox:
+            self.lib.hcg_xchg_free(self.inbox)
+            self.inbox = None

@@ -377,6 +377,38 @@ int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int njobs, const
                                int64_t N, int64_t E, int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr,
                                int32_t* next_status, hcg_stream_t stream);
 
+/* ---- data parallel: one-shot gradient exchange over xGMI, fused between the slab reduction and the update ------------
+ * Every rank owns an inbox (hcg_xchg_inbox_bytes: 2 x world x (n + 2) eight-byte {value, step} granules) in fine-grained
+ * device memory (hcg_xchg_alloc: the one allocation this library makes), exports it (hcg_xchg_ipc_export -> 64-byte handle,
+ * exchanged by the host through torch.distributed) and maps its peers' (hcg_xchg_ipc_open).  hcg_reduce_slabs_xchg_adam =
+ * hcg_reduce_slabs_adam where every reduced element is first written into all peers' inboxes (one 8-byte system-scope store
+ * per peer, over the direct links), the peers' contributions are polled out of the own inbox and added in rank order, and
+ * the update runs on the total: `mode` HCG_XCHG_MEAN divides by `world`; HCG_XCHG_SSE applies the SSE form's scale
+ * (flat_ext[n], [n + 1] = this rank's SSE and count from hcg_head_fwd_bwd_ex; loss[0..1] = the global sqrt(MSE), MSE).
+ * Polls are bounded (2 s): HCG_XCHG_ERR_TIMEOUT is ORed into err[0] and the element becomes NaN.  `step_dev[0]` (advanced
+ * earlier in the step by the head kernel) stamps the granules: it must advance by one per exchange on every rank, and an
+ * inbox must be re-zeroed before it serves another optimiser.  peers: HOST array of `world` device pointers (peers[rank] =
+ * inbox).  next_batch != NULL: also derives the next batch's plan (hcg_reduce_slabs_adam_plan). */
+#define HCG_XCHG_MAX_WORLD 8
+#define HCG_XCHG_HANDLE_BYTES 64
+#define HCG_XCHG_MEAN 0
+#define HCG_XCHG_SSE 1
+#define HCG_XCHG_ERR_TIMEOUT 1
+size_t hcg_xchg_inbox_bytes(int64_t n, int world);
+int hcg_xchg_alloc(size_t bytes, void** ptr);
+int hcg_xchg_free(void* ptr);
+int hcg_xchg_zero(void* ptr, size_t bytes);
+int hcg_xchg_ipc_export(void* ptr, void* handle64);
+int hcg_xchg_ipc_open(const void* handle64, void** ptr);
+int hcg_xchg_ipc_close(void* ptr);
+int hcg_reduce_slabs_xchg_adam(const hcg_reduce_job* jobs_host, int njobs, float* flat_ext, float* param_flat,
+                               float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
+                               float eps, const int32_t* step_dev, void* inbox, void* const* peers_host, int rank, int world,
+                               int mode, float* loss, int32_t* err,
+                               const int64_t* next_edge_index, const int64_t* next_batch /*nullable: no plan*/, int64_t N,
+                               int64_t E, int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr, int32_t* next_status,
+                               hcg_stream_t stream);
+
 /* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),
  * node_ptr_all / edge_ptr_all [G+1] (int64), y_all [G], idx_all [G].  `ids` [B] selects graphs (device).

@@ -349,3 +349,86 @@ def test_next_batch_plan_inside_the_last_launch_of_the_step(H, oracle):
     check(tb, collate(gl[48:]))                             # ... tb's last launch re-derives a's plan
     check(ta, a2)
     assert int(pa.status[0].item()) == 0
+
+
+def _rank_main_xchg(rank, world, port, q):
+    """One rank of a two-rank job that exchanges gradients through `xgmi.OneShotExchange` (both ranks on cuda:0: the peers'
+    inboxes are mapped through IPC exactly as across GPUs; what a one-GPU box cannot show is the xGMI hop itself)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hcatgnet_amd as H
+        from hcatgnet_amd import synth
+        from hcatgnet_amd.batch import collate
+        from hcatgnet_amd.ddp import DataParallelGCN
+        from hcatgnet_amd.xgmi import OneShotExchange
+        sb = synth.make_config("C2", num_graphs=128)
+        gl = sb.as_graph_list()
+        mine = collate(gl[:70] if rank == 0 else gl[70:]).to("cuda")        # unequal halves
+        m = H.make_network("GCN", H.default_options(), 64).cuda()
+        twin = H.make_network("GCN", H.default_options(), 64).cuda()
+        dp, dp_twin = DataParallelGCN(m, combine="sse"), DataParallelGCN(twin, combine="sse")
+        w0 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+        xchg = OneShotExchange(sum(p.numel() for p in m.parameters()))
+        ok_setup = xchg.ok
+        ok_test = xchg.self_test() if ok_setup else False
+        res = {"rank": rank, "setup": ok_setup, "selftest": ok_test}
+        if ok_test:
+            step = xchg.attach(dp.make_train_step())
+            ref = dp_twin.make_train_step()                                   # the collective path: the comparison
+            l1, l2 = float(step(mine)), float(ref(mine))
+            res["loss"], res["loss_ref"] = l1, l2
+            res["grads"] = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+            step.capture(mine)                                               # two more warm-up steps + the capture ...
+            for _ in range(2):
+                ref(mine)
+            for _ in range(3):                                               # ... then three replays against three eager steps
+                l1, l2 = float(step.replay()), float(ref(mine))
+            res["loss3"], res["loss3_ref"] = l1, l2
+            res["w"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy().copy()
+            res["w_ref"] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu().numpy().copy()
+            xchg.check()
+        res["w0"] = w0
+        q.put(res)
+        xchg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_exchange_two_ranks_equals_the_collective_path(H, oracle):
+    """`xgmi.OneShotExchange`: set-up (fine-grained inbox, IPC export / open), self test, then the REAL step with the
+    exchange inside its last launch, eager and captured: gradients = the oracle's concatenated-batch gradient, losses and
+    weights follow the all-reduce path, both ranks bitwise equal."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.batch import collate
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_xchg, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0["setup"] and r1["setup"], "one-shot exchange did not set up (IPC of fine-grained memory)"
+    assert r0["selftest"] and r1["selftest"], "one-shot exchange failed its self test"
+    sb = synth.make_config("C2", num_graphs=128)
+    whole = collate(sb.as_graph_list())
+    w0 = {k: torch.from_numpy(v) for k, v in r0["w0"].items()}
+    l_ref, _, _, g_ref = _oracle_of(oracle, w0, whole)
+    for r in (r0, r1):
+        assert abs(r["loss"] - float(l_ref)) <= 1e-6 * abs(float(l_ref)) and abs(r["loss"] - r["loss_ref"]) <= 1e-6 * abs(r["loss_ref"])
+        assert abs(r["loss3"] - r["loss3_ref"]) <= 1e-4 * abs(r["loss3_ref"])
+        for k in g_ref:
+            tol = 1e-6 if g_ref[k].numel() <= 64 else 1e-5
+            assert rel_inf(torch.from_numpy(r["grads"][k]), g_ref[k]) <= tol, k
+        assert float(np.abs(r["w"] - r["w_ref"]).max()) <= 2e-3 * float(np.abs(r["w_ref"]).max())   # (Adam, eps 1e-9: loose)
+    assert np.array_equal(r0["w"], r1["w"])                                    # replicas bitwise in sync
+    for k in r0["grads"]:
+        assert np.array_equal(r0["grads"][k], r1["grads"][k]), k
