@@ -479,7 +479,10 @@ def main():
         if fused_ok:
             for tr in trainers + [fwdbwd]:
                 dp.attach(tr)
-            if args.exchange != "rccl":
+            if rehearsal and args.exchange == "auto":
+                log("rehearsal (ranks share one device): a polling launch of one rank leaves no room for the other rank's conv "
+                    "kernels on the same GPU -- the one-shot exchange needs one GPU per rank; RCCL-form exchange (gloo) here")
+            elif args.exchange != "rccl":
                 # the one-shot xGMI exchange, if it sets up and passes its self test against the process group's own
                 # all-reduce on THIS machine (every rank gets the same verdict); else the RCCL collective stays
                 from hcatgnet_amd.xgmi import OneShotExchange

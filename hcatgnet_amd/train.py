@@ -78,6 +78,11 @@ class FusedTrainStep:
         # data parallel: a `xgmi.OneShotExchange` (set by its `attach`): the gradient exchange then happens INSIDE the slab
         # reduction + Adam launch instead of as an RCCL collective between two launches
         self.exchange = None
+        # one-device rehearsals only (two ranks sharing a GPU): called right before the launch that carries the exchange.
+        # A rank's polling launch fills every CU, and the OTHER process's conv kernels (488 of a SIMD's 512 VGPRs per
+        # workgroup) cannot be placed beside it, so on one device the ranks must meet (synchronize + barrier) before that
+        # launch; on one GPU per rank nothing of another process ever runs on the device and this stays None
+        self.pre_exchange_hook = None
 
     def _sync_words(self, dev: torch.device) -> torch.Tensor:
         """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
@@ -242,6 +247,8 @@ class FusedTrainStep:
             _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
             njobs += 1
         if step_word is not None:
+            if self.exchange is not None and self.pre_exchange_hook is not None:
+                self.pre_exchange_hook()
             if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
                                            flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):
                 raise _lib.HcgError("optimizer state changed between head launch and update")
@@ -495,6 +502,8 @@ class FusedTrainStep:
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
         #      are one launch (the update reads each gradient element as it is produced)
         if step_word is not None:
+            if self.exchange is not None and self.pre_exchange_hook is not None:
+                self.pre_exchange_hook()
             if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
                                            flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):    # (same preconditions as fused_update_ready)
                 raise _lib.HcgError("optimizer state changed between head launch and update")

@@ -376,16 +376,17 @@ def _rank_main_xchg(rank, world, port, q):
         ok_test = xchg.self_test() if ok_setup else False
         res = {"rank": rank, "setup": ok_setup, "selftest": ok_test}
         if ok_test:
+            def meet():                                                       # one device, two ranks: see FusedTrainStep.pre_exchange_hook
+                torch.cuda.synchronize()
+                dist.barrier()
             step = xchg.attach(dp.make_train_step())
+            step.pre_exchange_hook = meet
             ref = dp_twin.make_train_step()                                   # the collective path: the comparison
             l1, l2 = float(step(mine)), float(ref(mine))
             res["loss"], res["loss_ref"] = l1, l2
             res["grads"] = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
-            step.capture(mine)                                               # two more warm-up steps + the capture ...
-            for _ in range(2):
-                ref(mine)
-            for _ in range(3):                                               # ... then three replays against three eager steps
-                l1, l2 = float(step.replay()), float(ref(mine))
+            for _ in range(5):                                                # five more steps (both step parities, Adam state)
+                l1, l2 = float(step(mine)), float(ref(mine))
             res["loss3"], res["loss3_ref"] = l1, l2
             res["w"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy().copy()
             res["w_ref"] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu().numpy().copy()
@@ -399,8 +400,9 @@ def _rank_main_xchg(rank, world, port, q):
 
 def test_one_shot_exchange_two_ranks_equals_the_collective_path(H, oracle):
     """`xgmi.OneShotExchange`: set-up (fine-grained inbox, IPC export / open), self test, then the REAL step with the
-    exchange inside its last launch, eager and captured: gradients = the oracle's concatenated-batch gradient, losses and
-    weights follow the all-reduce path, both ranks bitwise equal."""
+    exchange inside its last launch: gradients = the oracle's concatenated-batch gradient, losses and weights follow the
+    all-reduce path over six steps, both ranks bitwise equal.  (Two ranks on ONE device must meet before the launch that
+    polls -- `pre_exchange_hook` -- so the captured, free-running form is only exercised on one GPU per rank.)"""
     import numpy as np
     import torch.multiprocessing as mp
     from hcatgnet_amd import synth

@@ -27,9 +27,15 @@ def main(rank, world, port):
     say(f"setup ok={xchg.ok}")
     say(f"selftest {xchg.self_test()}")
     step = xchg.attach(dp.make_train_step())
+    if os.environ.get("MEET", "1") == "1":
+        def meet():
+            torch.cuda.synchronize(); dist.barrier()
+        step.pre_exchange_hook = meet
     for i in range(5):
         loss = float(step(batch))
         say(f"eager step {i}: loss {loss:.5f} err {int(xchg.err[0])} opt step {m.optimizer.steps_done()}")
+    if os.environ.get("MEET", "1") == "1":
+        dist.barrier(); xchg.close(); dist.destroy_process_group(); return
     step.capture(batch)
     torch.cuda.synchronize()
     say(f"captured: err {int(xchg.err[0])} opt step {m.optimizer.steps_done()}")
