@@ -282,12 +282,20 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
                                                          float slope, int apply_act, float* __restrict__ out, int ldo, int coff,
                                                          float* __restrict__ emb, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const MidLds L = carve(smem, npad, emax, DD, KPAD, false);
+  const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
+  const MidLds L = carve(smem, npad, emax, DD * nkc, KPAD, false);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
-  const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
 
-  if (!MULTIK) stage_weight_split<false, MT, DD, KPAD>(L.wl, W, DD, F);    // one chunk: the weight image is loop invariant
+  // the weight image(s) are loop invariant: staged ONCE per workgroup, every K-chunk's image resident (MULTIK: two images,
+  // 55 KB -- these kernels run one workgroup per CU anyway; re-staging a chunk's image per graph cost 8 global loads, 24
+  // splits and 24 ds_write_b16 per thread and graph)
+  constexpr int IMG = 3 * DD * (KPAD + WPAD);
+  if (!MULTIK) {
+    stage_weight_split<false, MT, DD, KPAD>(L.wl, W, DD, F);
+  } else {
+    for (int kc = 0; kc < nkc; ++kc) stage_weight_split<false, MT, DD, KPAD>(L.wl + kc * IMG, W, DD, F, kc * KPAD);
+  }
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
   __syncthreads();
 
@@ -330,10 +338,9 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         if (kc > 0) {
           __syncthreads();                                           // every wave is done with the previous chunk
           stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
+          __syncthreads();
         }
-        stage_weight_split<false, MT, DD, KPAD>(L.wl, W, DD, F, kc * KPAD);
-        __syncthreads();
-        if (mb < gi.nblk) tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
+        if (mb < gi.nblk) tile_gemm_split<KPAD>(blk, L.wl + kc * IMG, acc0, acc1, lane);
       }
       __syncthreads();                                               // the last x chunk is dead: H' may overwrite it
       if (mb < gi.nblk) {
@@ -591,19 +598,33 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
           }
 #pragma unroll
           for (int nb = 0; nb < NBF; ++nb) mfma_results_fence(dxa[nb]);
+          // second column half of a 128-wide layer (acc_dx): the first half's dx is read back -- all 16 values of a
+          // 32-column block requested TOGETHER, unconditionally (clamped), behind one kernel-uniform branch; inside the
+          // per-lane guards below every one of them was a serialised memory round trip
+          const int nlast = gi.n > 0 ? gi.n - 1 : 0;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = mb * 32 + krow(i, h);
-            if (row < gi.n) {
+          for (int nb = 0; nb < NBF; ++nb) {
+            const int f = fc * KPAD + nb * 32 + r;
+            const int fcl = f < F ? f : F - 1;
+            if (premask) {
 #pragma unroll
-              for (int nb = 0; nb < NBF; ++nb) {
-                const int f = fc * KPAD + nb * 32 + r;
-                if (f < F) {
-                  float* dst = dx + (size_t)(gi.nbase + row) * F + f;
-                  const float v = premask ? dxa[nb][i] * hcg_leaky_grad(L.t0[row * HS + nb * 32 + r], slope) : dxa[nb][i];
-                  *dst = acc_dx ? *dst + v : v;
-                }
+              for (int i = 0; i < 16; ++i)
+                dxa[nb][i] *= hcg_leaky_grad(L.t0[(mb * 32 + krow(i, h)) * HS + nb * 32 + r], slope);
+            }
+            if (acc_dx) {                                  // eight at a time: the kernel is at its register limit
+#pragma unroll
+              for (int i0 = 0; i0 < 16; i0 += 8) {
+                float old[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) old[i] = dx[(size_t)(gi.nbase + min(mb * 32 + krow(i0 + i, h), nlast)) * F + fcl];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dxa[nb][i0 + i] += old[i];
               }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = mb * 32 + krow(i, h);
+              if (row < gi.n && f < F) dx[(size_t)(gi.nbase + row) * F + f] = dxa[nb][i];
             }
           }
         }
@@ -695,7 +716,8 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
     return hcg_w64_fwd_launch(x, W, b, edge_index, E, graph_ptr, edge_ptr, B, F, slope, apply_act, out, emb, status, stream);
   const int npad = pad32(max_nodes), emax = pad8(max_edges);
   const int kpad = F <= 32 ? 32 : 64;
-  const size_t lds = mid_lds_bytes(npad, emax, DD, kpad, false);
+  const int nimg = F > 64 ? (int)((F + 63) / 64) : 1;                 // K-chunk weight images kept resident (MULTIK)
+  const size_t lds = mid_lds_bytes(npad, emax, DD * nimg, kpad, false);
   const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
 #define LAUNCH_MID_FWD(KP, PL, MK)                                                                                         \
   do {                                                                                                                     \
