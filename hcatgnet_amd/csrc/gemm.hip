@@ -24,9 +24,9 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ base, int64
     for (int it = 0; it < 4; ++it) {
       const int i = (tid >> 4) + it * 16;
       const int64_t gi = i0 + i, gk = k0 + k;
-      float v = 0.f;
-      if (gi < imax && gk < kmax) v = base[gi * si + gk];
-      tile[k][i] = v;
+      // unconditional, clamped load + select: a load behind a per-lane guard is a serialised memory round trip
+      const float v = base[(gi < imax ? gi : imax - 1) * si + (gk < kmax ? gk : kmax - 1)];
+      tile[k][i] = (gi < imax && gk < kmax) ? v : 0.f;
     }
   } else {  // i contiguous (or generic): 64 consecutive threads walk the i-range
     const int i = tid & 63;
@@ -34,9 +34,8 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ base, int64
     for (int it = 0; it < 4; ++it) {
       const int k = (tid >> 6) + it * 4;
       const int64_t gi = i0 + i, gk = k0 + k;
-      float v = 0.f;
-      if (gi < imax && gk < kmax) v = base[gi * si + gk * sk];
-      tile[k][i] = v;
+      const float v = base[(gi < imax ? gi : imax - 1) * si + (gk < kmax ? gk : kmax - 1) * sk];
+      tile[k][i] = (gi < imax && gk < kmax) ? v : 0.f;
     }
   }
 }
