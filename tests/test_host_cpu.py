@@ -138,3 +138,32 @@ def test_fused_train_step_support_check_is_host_only():
     assert "shape" in FusedTrainStep.unsupported_reason(odd, mk(max_nodes=30, max_edges=64, edges_grouped=True))
     deep = H.make_network("GCN", H.default_options(readout_layers=3), 25)
     assert "readout" in FusedTrainStep.unsupported_reason(deep)
+
+
+def test_base_network_dispatch_mirrors_the_reference():
+    """`BaseNetwork._make_loss / _make_optimizer / _make_scheduler` (reference model/networks.py:28-56): every branch the
+    reference's option parser can select builds the same kind of object, unknown names raise the reference's errors."""
+    import pytest
+    import hcatgnet_amd as H
+    from hcatgnet_amd.optim import FusedAdam
+    kinds = {"StepLR": torch.optim.lr_scheduler.StepLR, "ExponentialLR": torch.optim.lr_scheduler.ExponentialLR,
+             "ReduceLROnPlateau": torch.optim.lr_scheduler.ReduceLROnPlateau}
+    for name, cls in kinds.items():
+        m = H.make_network("GCN", H.default_options(scheduler=name), 25)
+        assert isinstance(m.scheduler, cls) and isinstance(m.optimizer, FusedAdam)
+        assert m.optimizer.param_groups[0]["eps"] == 1e-9 and m.optimizer.param_groups[0]["lr"] == 0.01      # networks.py:38
+    m = H.make_network("GCN", H.default_options(scheduler="MultiStepLR", step_size=[3, 6]), 25)
+    assert isinstance(m.scheduler, torch.optim.lr_scheduler.MultiStepLR)
+    assert isinstance(H.make_network("GCN", H.default_options(optimizer="SGD"), 25).optimizer, torch.optim.SGD)
+    assert isinstance(H.make_network("GCN", H.default_options(optimizer="rmsprop"), 25).optimizer, torch.optim.RMSprop)
+    assert isinstance(H.make_network("GCN", H.default_options(problem_type="classification", n_classes=3), 25).loss,
+                      torch.nn.CrossEntropyLoss)
+    with pytest.raises(NotImplementedError):
+        H.make_network("GCN", H.default_options(optimizer="LBFGS"), 25)
+    with pytest.raises(NotImplementedError):
+        H.make_network("GCN", H.default_options(scheduler="Cosine"), 25)
+    with pytest.raises(ValueError):
+        H.make_network("GCN", H.default_options(problem_type="ranking"), 25)
+    with pytest.raises(ValueError):
+        H.make_network("GAT", H.default_options(), 25)                        # call_methods.py:7-12
+    assert m.name == "GCN"
