@@ -487,7 +487,25 @@ def main():
                 # all-reduce on THIS machine (every rank gets the same verdict); else the RCCL collective stays
                 from hcatgnet_amd.xgmi import OneShotExchange
                 xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
-                if xchg.ok and xchg.self_test():
+                ok = xchg.ok and xchg.self_test()
+                if ok:
+                    # ... and a free-running soak on a throw-away model: 64 real steps back to back, no host synchronisation
+                    # in between (what the timed loop does), every rank's verdict combined
+                    soak_model = H.make_network("GCN", opt, F).to(dev)
+                    soak_dp = DataParallelGCN(soak_model, combine=args.combine)
+                    soak = xchg.attach(soak_dp.make_train_step())
+                    last = None
+                    for j in range(64):
+                        last = soak(res[j % NB].fresh())
+                    torch.cuda.synchronize()
+                    good = int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item())
+                    verdict = torch.tensor([1 if good else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                    ok = bool(int(verdict.item()))
+                    xchg.err.zero_()
+                    xchg.reset()                    # the soak's step stamps must not meet the real optimiser's
+                    del soak, soak_dp, soak_model
+                if ok:
                     for tr in trainers:
                         xchg.attach(tr)
                     exchange_mode = "oneshot"
