@@ -243,7 +243,7 @@ __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restri
       for (int j = 0; j < NIT; ++j) {
         const int idx = tid + j * MT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
         if (j * MT < rows * PER_ROW)           // block-uniform guard, clamped address: no per-lane branch around the load
-          v[j] = *reinterpret_cast<const float4*>(g + (size_t)(nbase + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + c0 + 4 * c4);
+          v[j] = *reinterpret_cast<const float4*>(g + (size_t)((n > 0 ? nbase : 0) + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + c0 + 4 * c4);   // (an empty graph at the end of the batch has nbase == N)
       }
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int j = 0; j < NR; ++j) {
       const int row = rg + j * (MT / 16);
       if (j * (MT / 16) < rows) {                          // block-uniform
-        const size_t at = (size_t)(gi.nbase + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * ldo + coff + 4 * c4;
+        const size_t at = (size_t)((gi.n > 0 ? gi.nbase : 0) + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * ldo + coff + 4 * c4;
         if (need_a) av[j] = *reinterpret_cast<const float4*>(a_out + at);   // (kernel-uniform)
         if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(dout + at);
       }
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
               for (int i0 = 0; i0 < 16; i0 += 8) {
                 float old[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) old[i] = dx[(size_t)(gi.nbase + min(mb * 32 + krow(i0 + i, h), nlast)) * F + fcl];
+                for (int i = 0; i < 8; ++i) old[i] = dx[(size_t)((gi.n > 0 ? gi.nbase : 0) + min(mb * 32 + krow(i0 + i, h), nlast)) * F + fcl];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dxa[nb][i0 + i] += old[i];
               }

@@ -57,7 +57,8 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-struct WGraph { int nbase, n, ebase, ne, nblk; };
+struct WGraph { int nbase, n, ebase, ne, nblk, nld; };   // nld: row base for (clamped) LOADS: an empty graph at the very end
+                                                         // of the batch has nbase == N, one row past the matrices
 
 __device__ __forceinline__ WGraph w_graph(int g, int B, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
                                           int lane, int32_t* status) {
@@ -73,6 +74,7 @@ __device__ __forceinline__ WGraph w_graph(int g, int B, const int32_t* __restric
     gi.ne = 0;
   }
   gi.nblk = (gi.n + 31) / 32;
+  gi.nld = gi.n > 0 ? gi.nbase : 0;
   return gi;
 }
 
@@ -86,6 +88,7 @@ __device__ __forceinline__ WGraph w_uniform(const WGraph& a) {
   u.ebase = __builtin_amdgcn_readfirstlane(a.ebase);
   u.ne = __builtin_amdgcn_readfirstlane(a.ne);
   u.nblk = __builtin_amdgcn_readfirstlane(a.nblk);
+  u.nld = __builtin_amdgcn_readfirstlane(a.nld);
   return u;
 }
 
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
 
   const bool wide = F == KPAD && ((uintptr_t)x % 16 == 0);   // whole float4 rows: the first rows of a graph are requested a graph ahead
   WRowsAhead<KPAD> ahead;
-  if (wide && g < B) ahead.load(x, F, gi.nbase, gi.n, 0, lane);
+  if (wide && g < B) ahead.load(x, F, gi.nld, gi.n, 0, lane);
 
   for (; g < B; g += stride) {
     const WGraph gc = w_uniform(gi);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
       ahead.write(L.t0, gc.n, rows, 0, lane);
       for (int base = WRowsAhead<KPAD>::ROWS; base < rows; base += WRowsAhead<KPAD>::ROWS) {
         WRowsAhead<KPAD> more;
-        more.load(x, F, gc.nbase, gc.n, base, lane);
+        more.load(x, F, gc.nld, gc.n, base, lane);
         more.write(L.t0, gc.n, rows, base, lane);
       }
     } else {
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_fwd(const float* __restri
       }
     }
     wave_sync();
-    if (wide && have_next) ahead.load(x, F, gi.nbase, gi.n, 0, lane);   // lands while this graph is aggregated and stored
+    if (wide && have_next) ahead.load(x, F, gi.nld, gi.n, 0, lane);   // lands while this graph is aggregated and stored
 
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
 #pragma unroll                                           // activation derivative needed) the upstream gradient itself
     for (int j = 0; j < 16; ++j) av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-      const float* src = (need_a ? a_out : dout) + (size_t)gc.nbase * DD + 4 * q;
+      const float* src = (need_a ? a_out : dout) + (size_t)gc.nld * DD + 4 * q;
 #pragma unroll
       for (int j = 0; j < 8; ++j)                        // rows 0..31: unconditional, clamped (min, not a branch)
         av[j] = *reinterpret_cast<const float4*>(src + (size_t)min(r4 + 4 * j, nlast) * DD);
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!POOLG) {
           d = av[j];                                     // (no activation derivative: av IS the upstream gradient)
-          if (need_a) d = *reinterpret_cast<const float4*>(dout + (size_t)(gc.nbase + min(row, nlast)) * DD + 4 * q);
+          if (need_a) d = *reinterpret_cast<const float4*>(dout + (size_t)(gc.nld + min(row, nlast)) * DD + 4 * q);
         }
         if (row < gc.n) {
           const float4 a = av[j];
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void k_w64_layer_bwd(
     wave_sync();
 
     // x operand of the dW contraction, k-step 0: requested here, a whole segmented-sum phase ahead of its use
-    const float* xg = x + (size_t)gc.nbase * F;
+    const float* xg = x + (size_t)gc.nld * F;
     float bv0[8], bv1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
