@@ -312,6 +312,81 @@ def mid_gcn_layer(x, weight, bias, plan: BatchPlan, apply_act=True, slope=LEAKY_
     return _MidLayerFn.apply(x, weight, bias, plan, apply_act, slope, pool)
 
 
+class _TallLayerFn(torch.autograd.Function):
+    """Wide layers (D = 128) over large graphs: dense row-streaming transform + per-graph segmented sum (csrc/tall.hip).
+    Same contract as `_MidLayerFn`; the forward's H = x W^T makes a round trip through a workspace."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, plan: BatchPlan, apply_act: bool, slope: float, pool: bool):
+        lib = _lib.load()
+        _lib.require_gpu(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, F = x.shape
+        D = weight.shape[0]
+        if weight.shape[1] != F or N != plan.N:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(weight.shape)}, plan N {plan.N}")
+        dev = x.device
+        out = torch.empty(N, D, dtype=torch.float32, device=dev)
+        emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
+        wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.hcg_tall_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
+                                    _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, plan.max_nodes,
+                                    plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
+                                    _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_tall_layer_fwd")
+        ctx.plan, ctx.apply_act, ctx.slope, ctx.pool = plan, apply_act, slope, pool
+        if pool:
+            ctx.save_for_backward(x, weight, out, emb)
+            return emb
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        import ctypes
+        lib = _lib.load()
+        plan = ctx.plan
+        if ctx.pool:
+            x, weight, out, emb = ctx.saved_tensors
+            dout, demb = None, _f32c(grad)
+        else:
+            x, weight, out = ctx.saved_tensors
+            emb, dout, demb = None, _f32c(grad), None
+        N, F = x.shape
+        D = weight.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(D, dtype=torch.float32, device=dev)
+        wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        stream = _lib.stream_ptr()
+        rc = lib.hcg_tall_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), _lib.ptr(x), _lib.ptr(weight),
+                                    _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N,
+                                    plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
+                                    _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)
+        _lib.check(rc, "hcg_tall_layer_bwd")
+        jb = lib.hcg_reduce_job_bytes()
+        jobs = ctypes.create_string_buffer(jb * 2)
+        _lib.check(lib.hcg_tall_reduce_jobs(_lib.ptr(ws), wsb, N, plan.B, F, D, _lib.ptr(dW), _lib.ptr(db),
+                                            ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
+        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), 2, stream), "hcg_reduce_slabs")
+        return dx, dW, db, None, None, None, None
+
+
+def tall_supported(plan: BatchPlan, F: int, D: int) -> bool:
+    """True when the wide-layer kernels (csrc/tall.hip: D = 128) apply to this plan / layer shape."""
+    if (plan.mode != "blocked" or plan.ew_csr is not None or plan.max_nodes is None or plan.max_edges is None
+            or plan.B == 0 or plan.N == 0):
+        return False
+    return bool(_lib.load().hcg_tall_supported(F, D, plan.max_nodes, plan.max_edges))
+
+
+def tall_gcn_layer(x, weight, bias, plan: BatchPlan, apply_act=True, slope=LEAKY_SLOPE, pool=False):
+    return _TallLayerFn.apply(x, weight, bias, plan, apply_act, slope, pool)
+
+
 class _Readout2Fn(torch.autograd.Function):
     """out = (LeakyReLU(emb W0^T + b0)) W1^T + b1 in one launch (csrc/readout.hip)."""
 

@@ -39,6 +39,7 @@ class GCNConv(nn.Module):
         # explain-mode hooks with PyG MessagePassing's attribute names (set by hcatgnet_amd.explain.set_masks):
         # when `explain` is on, every message is multiplied by `_edge_mask` (after a sigmoid if `_apply_sigmoid`)
         self.explain, self._edge_mask, self._apply_sigmoid = False, None, True
+        self.family = "auto"      # "mid": keep a 128-wide layer on the one-graph-per-workgroup kernels (tests / A-B runs)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -59,6 +60,8 @@ class GCNConv(nn.Module):
         gpt = 0 if (use_edge_weight or not fused) else HF.fused_graphs_per_tile(plan, self.in_channels, self.out_channels)
         if gpt > 0:
             return HF.fused_gcn_layer(x, self.lin.weight, self.bias, plan, gpt, apply_act, pool=pool)
+        if fused and not use_edge_weight and self.family != "mid" and HF.tall_supported(plan, self.in_channels, self.out_channels):
+            return HF.tall_gcn_layer(x, self.lin.weight, self.bias, plan, apply_act, pool=pool)  # wide layer, large graphs
         if fused and not use_edge_weight and HF.mid_supported(plan, self.in_channels, self.out_channels):
             return HF.mid_gcn_layer(x, self.lin.weight, self.bias, plan, apply_act, pool=pool)   # one graph per workgroup
         h = HF.gcn_layer(x, self.lin.weight, self.bias, plan, use_edge_weight, apply_act)

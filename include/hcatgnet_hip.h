@@ -241,6 +241,28 @@ int hcg_mid_layer_bwd(const float* dout /*nullable*/, const float* demb, const f
                       float slope, int apply_act, float* dx /*nullable*/, int32_t* status,
                       void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
+/* ---- wide layers over large graphs (D = 128; BASELINE configs[4]: 200-atom graphs x 128-d): the layer as a dense
+ * row-streaming transform over all nodes (weight image resident in LDS, A fragments straight from global memory, no
+ * barrier in the steady state) + a per-graph segmented sum that keeps only the CSR in LDS and gathers rows through L2
+ * (csrc/tall.hip).  Same contract and graph limits as hcg_mid_layer_* (raw grouped edge_index + graph_ptr / edge_ptr of a
+ * BLOCKED plan, gcn_norm rebuilt on chip per graph, pooled epilogue / pooled-gradient prologue, apply_act bits of
+ * hcg_fused_layer_bwd); F a multiple of 4, <= 128.  The forward needs the workspace too (H = x W^T makes a round trip).
+ * hcg_tall_layer_bwd leaves dW / db slabs in the workspace: hcg_tall_reduce_jobs fills TWO jobs (dW, db) for
+ * hcg_reduce_slabs.  Replaces the same PyG GCNConv call sites (model/gcn.py:58-63) and their autograd. */
+int hcg_tall_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph);
+size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int64_t D);
+int hcg_tall_layer_fwd(const float* x, const float* W, const float* b,
+                       const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                       int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
+                       float slope, int apply_act, float* out, float* emb /*nullable*/, int32_t* status,
+                       void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+int hcg_tall_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
+                       const float* out, const float* x, const float* W,
+                       const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
+                       int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
+                       float slope, int apply_act, float* dx /*nullable*/, int32_t* status,
+                       void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+
 /* ---- fused readout head (a10 + its backward) for the reference's default shape:
  *      z = LeakyReLU(emb W0^T + b0) [B,2D]->[B,D];  out = z W1^T + b1 [B,D]->[B,C];  D = 64, C <= 8.
  * forward: one launch (z is kept for the backward).  backward: one launch + fixed-order slab reduce;
@@ -332,6 +354,9 @@ int hcg_readout2_reduce_job(const void* workspace, size_t workspace_bytes, int64
 /* one job per 64-column half (half = 0 .. D/64 - 1): rows [64 half, 64 half + 64) of dW [D, F] / db [D] */
 int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int64_t D,
                        int64_t max_nodes, int64_t max_edges, int half, float* dW, float* db, hcg_reduce_job* job_host);
+/* job_host[0] = dW [D, F], job_host[1] = db [D] of hcg_tall_layer_bwd */
+int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
+                         float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 /* `more` (same slab geometry and destinations, slabs directly behind `job`'s) becomes part of `job`: one fixed-order sum */

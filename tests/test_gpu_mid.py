@@ -167,6 +167,8 @@ def test_mid_wide_layers_vs_oracle_and_general_path(H, oracle, nodes, jitter, fe
                              max_nodes=sb.max_nodes, max_edges=sb.max_edges)
     batch._hcg_plan = plan
     assert HF.mid_supported(plan, feat, D) and HF.mid_supported(plan, D, D)
+    for c in [m.conv1] + list(m.conv_layers):
+        c.family = "mid"                      # (128-wide layers default to csrc/tall.hip: tests/test_gpu_tall.py)
     m.use_fused = True
     out_f, emb_f, g_f = _step_grads(m, batch, batch.y)
     assert plan.check_status() == 0
