@@ -77,9 +77,11 @@ SIGNATURES = {
     "hcg_readout2_bwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P, SZ, P]),
     "hcg_head_supported": (INT, [I64, I64]),
     "hcg_head_workspace_bytes": (SZ, [I64]),
+    "hcg_head_workspace_bytes_d": (SZ, [I64, I64]),
     "hcg_head_fwd_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P]),
     "hcg_head_fwd_bwd_ex": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P, P]),
     "hcg_head_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
+    "hcg_head_reduce_job_d": (INT, [P, SZ, I64, I64, I64, P, P, P, P, P]),
     "hcg_sse_finalize": (INT, [P, I64, P, P]),
     "hcg_adam_step_dev_sse": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P, P]),
     "hcg_reduce_slabs_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P]),

@@ -27,29 +27,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // last MFMA when several waves share the SIMD's matrix pipe (f32 32x32x2: 16 passes = 64 cycles)
 __device__ __forceinline__ void mfma_results_fence(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a)); }
 
-constexpr int RD = 64;            // hidden width
-constexpr int RK = 2 * RD;        // pooled embedding width
 constexpr int RT = 32;            // graphs per tile
-constexpr int ES = RK + 4;        // LDS stride of the emb tile
-constexpr int ZS = RD + 4;        // LDS stride of the z / dz tile
-constexpr int WS0 = RK + 1;       // LDS stride of the W0 image [64][128]
-constexpr int HW = 4;             // waves per workgroup
 constexpr int RCMAX = 8;
-// slab layout per WORKGROUP (same as readout.hip): dW0 [RD][RK] | db0 [RD] | dW1 [C][RD] | db1 [C]  (C padded to RCMAX)
-constexpr int SLAB = RD * RK + RD + RCMAX * RD + RCMAX;
 constexpr int MAXGRID = 256;
 static_assert(2 + 2 * MAXGRID <= HCG_HEAD_SYNC_WORDS, "sync words");
 
+// Shapes of the head for hidden width RD (= embedding_dim: 64, the reference's default, options/base_options.py:199-204;
+// 128 = BASELINE configs[4]).  Wave roles: forward = RD/32 output column blocks x 2 K halves -> HW = RD/16 waves (4 / 8);
+// backward = one 32-column block of the 2RD-wide embedding per wave (2RD/32 = HW blocks).
+template <int RD_>
+struct HC {
+  static constexpr int RD = RD_;          // hidden width
+  static constexpr int RK = 2 * RD;       // pooled embedding width
+  static constexpr int NB = RD / 32;      // output column blocks of the forward GEMM
+  static constexpr int HW = 2 * NB;       // waves per workgroup
+  static constexpr int NT = HW * 64;
+  static constexpr int ES = RK + 4;       // LDS stride of the emb tile
+  static constexpr int ZS = RD + 4;       // LDS stride of the z / dz tile
+  static constexpr int WS0 = RK + 1;      // LDS stride of the W0 image [RD][RK]
+  static constexpr bool W0_LDS = RD <= 64;   // RD = 128: the image would be 131 KB -- the W0 fragments come from global memory / L2
+  static constexpr int OJ = RD / 8;       // out projection: threads per graph row (8 hidden units each)
+  static constexpr int QN = RD / 4;       // backward step 1: float4 column groups of a dz row
+  // slab layout per WORKGROUP (same as readout.hip): dW0 [RD][RK] | db0 [RD] | dW1 [C][RD] | db1 [C]  (C padded to RCMAX)
+  static constexpr int SMALL = RD + RCMAX * RD + RCMAX;       // db0 | dW1 | db1
+  static constexpr int SLAB = RD * RK + SMALL;
+  static constexpr int ESZ = RT * ES > HW * (SMALL + 8) ? RT * ES : HW * (SMALL + 8);    // emb tile, later the combine scratch
+};
+
 __device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
+template <int RD>
 struct HeadLds {
-  float w0[RD * WS0];            // W0 [d][k]
-  float e[RT * ES];              // emb tile
-  float z[RT * ZS];              // z tile, later dz
-  float part[2][RT * 33];        // K-half partial sums of the forward GEMM (per column block)
+  using C_ = HC<RD>;
+  float w0[C_::W0_LDS ? RD * C_::WS0 : 4];   // W0 [d][k]
+  float e[C_::ESZ];              // emb tile
+  float z[RT * C_::ZS];          // z tile, later dz
+  float part[C_::NB][RT * 33];   // K-half partial sums of the forward GEMM (per column block)
   float diff[RT][RCMAX];         // out - y, later dout
   float w1[RCMAX * RD];
-  float red[HW * 64];
+  float red[C_::HW * 64];
   float bcast[4];
 };
 
@@ -117,33 +133,39 @@ __device__ __forceinline__ float collect_partials(int* sync, int nblk, int gen, 
 }
 
 // stage rows [g0, g0 + n) of a [B, W] matrix into dst[row * ld + c], rows >= n zero (all 256 threads, float4)
-template <int W>
+template <int W, int NT>
 __device__ __forceinline__ void stage_rows(float* dst, int ld, const float* __restrict__ src, int g0, int n, int B) {
-  constexpr int PER_ROW = W / 4, ITER = RT * PER_ROW / (HW * 64);
+  constexpr int PER_ROW = W / 4, ITER = RT * PER_ROW / NT;
+  static_assert(RT * PER_ROW % NT == 0, "rows per thread");
   float4 v[ITER];
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const int idx = threadIdx.x + it * HW * 64, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+    const int idx = threadIdx.x + it * NT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
     int g = g0 + row;
     if (g > B - 1) g = B - 1;
     v[it] = *reinterpret_cast<const float4*>(src + (size_t)g * W + 4 * c4);
   }
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const int idx = threadIdx.x + it * HW * 64, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+    const int idx = threadIdx.x + it * NT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
     if (row >= n) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(dst + row * ld + 4 * c4) = v[it];
   }
 }
 
-__global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ emb, const float* __restrict__ y,
-                                                     const float* __restrict__ W0, const float* __restrict__ b0,
-                                                     const float* __restrict__ W1, const float* __restrict__ b1, int B, int C,
-                                                     float slope, int rmse, float* __restrict__ z, float* __restrict__ out,
-                                                     float* __restrict__ loss, float* __restrict__ demb,
-                                                     float* __restrict__ slabs, int* __restrict__ sync,
-                                                     int* __restrict__ step_counter, float* __restrict__ sse_tail) {
-  __shared__ HeadLds L;
+template <int RD>
+__global__ __launch_bounds__(HC<RD>::NT, 1) void k_head(const float* __restrict__ emb, const float* __restrict__ y,
+                                                       const float* __restrict__ W0, const float* __restrict__ b0,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1, int B, int C,
+                                                       float slope, int rmse, float* __restrict__ z, float* __restrict__ out,
+                                                       float* __restrict__ loss, float* __restrict__ demb,
+                                                       float* __restrict__ slabs, int* __restrict__ sync,
+                                                       int* __restrict__ step_counter, float* __restrict__ sse_tail) {
+  using K = HC<RD>;
+  constexpr int RK = K::RK, NB = K::NB, HW = K::HW, NT = K::NT, ES = K::ES, ZS = K::ZS, WS0 = K::WS0, OJ = K::OJ, QN = K::QN;
+  constexpr int SMALL = K::SMALL, SLAB = K::SLAB;
+  constexpr bool W0_LDS = K::W0_LDS;
+  __shared__ HeadLds<RD> L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int tiles = (B + RT - 1) / RT;
@@ -154,31 +176,36 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   // weights -> LDS once.  Every global load of the prologue is issued before the first LDS write (a load-store
   // loop would serialise 32 HBM round trips per thread: that alone cost ~15 us of this launch-latency-bound kernel)
   {
-    constexpr int W4 = RD * RK / 4 / (HW * 64);          // 8 float4 of W0 per thread
+    constexpr int W4 = W0_LDS ? RD * RK / 4 / NT : 1;          // 8 float4 of W0 per thread
+    constexpr int W1N = RCMAX * RD / NT;
     float4 wv[W4];
+    if (W0_LDS) {
 #pragma unroll
-    for (int it = 0; it < W4; ++it) wv[it] = *reinterpret_cast<const float4*>(W0 + 4 * (threadIdx.x + it * HW * 64));
-    float w1v[RCMAX * RD / (HW * 64)];
+      for (int it = 0; it < W4; ++it) wv[it] = *reinterpret_cast<const float4*>(W0 + 4 * (threadIdx.x + it * NT));
+    }
+    float w1v[W1N];
 #pragma unroll
-    for (int it = 0; it < RCMAX * RD / (HW * 64); ++it) {
-      const int idx = threadIdx.x + it * HW * 64;
+    for (int it = 0; it < W1N; ++it) {
+      const int idx = threadIdx.x + it * NT;
       w1v[it] = W1[idx < C * RD ? idx : 0];
     }
+    if (W0_LDS) {
 #pragma unroll
-    for (int it = 0; it < W4; ++it) {
-      const int f4 = threadIdx.x + it * HW * 64, row = f4 / (RK / 4), c4 = f4 - row * (RK / 4);
-      float* dst = L.w0 + row * WS0 + 4 * c4;
-      dst[0] = wv[it].x; dst[1] = wv[it].y; dst[2] = wv[it].z; dst[3] = wv[it].w;
+      for (int it = 0; it < W4; ++it) {
+        const int f4 = threadIdx.x + it * NT, row = f4 / (RK / 4), c4 = f4 - row * (RK / 4);
+        float* dst = L.w0 + row * WS0 + 4 * c4;
+        dst[0] = wv[it].x; dst[1] = wv[it].y; dst[2] = wv[it].z; dst[3] = wv[it].w;
+      }
     }
 #pragma unroll
-    for (int it = 0; it < RCMAX * RD / (HW * 64); ++it) {
-      const int idx = threadIdx.x + it * HW * 64;
+    for (int it = 0; it < W1N; ++it) {
+      const int idx = threadIdx.x + it * NT;
       L.w1[idx] = idx < C * RD ? w1v[it] : 0.f;
     }
   }
-  const int nb = wave & 1, kh = wave >> 1;              // forward: output column block / K half of this wave
+  const int nb = wave % NB, kh = wave / NB;             // forward: output column block / K half of this wave
   const float bz = b0[nb * 32 + r];
-  const int orow = threadIdx.x >> 3, oj = threadIdx.x & 7;   // out projection: 8 threads per graph row, 8 hidden units each
+  const int orow = threadIdx.x / OJ, oj = threadIdx.x % OJ;   // out projection: OJ threads per graph row, 8 hidden units each
   float b1v[RCMAX];
 #pragma unroll
   for (int c = 0; c < RCMAX; ++c) b1v[c] = b1[c < C ? c : 0];
@@ -194,22 +221,42 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     for (int c = 0; c < RCMAX; ++c)
       yv[c] = y[(size_t)(g0 + orow < B ? g0 + orow : B - 1) * C + (c < C ? c : C - 1)];
     __syncthreads();                                    // previous tile's readers are done (also orders the weight staging)
-    stage_rows<RK>(L.e, ES, emb, g0, n, B);
+    stage_rows<RK, NT>(L.e, ES, emb, g0, n, B);
     __syncthreads();
     HSTAMP(1);
     staged = t;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (W0_LDS) {
 #pragma unroll
-    for (int t8 = 0; t8 < RK / 16; ++t8) {              // this wave's K half: k = 64 kh + 8 t8 + 4h + u
-      const int k0 = 64 * kh + 8 * t8 + 4 * h;
-      const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + k0);
-      const float* wrow = L.w0 + (nb * 32 + r) * WS0 + k0;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wrow[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wrow[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wrow[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
+      for (int t8 = 0; t8 < RK / 16; ++t8) {              // this wave's K half: k = RD kh + 8 t8 + 4h + u
+        const int k0 = RD * kh + 8 * t8 + 4 * h;
+        const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + k0);
+        const float* wrow = L.w0 + (nb * 32 + r) * WS0 + k0;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wrow[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wrow[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wrow[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
+      }
+    } else {
+      // W0 fragments straight from global memory / L2 (every workgroup reads the same 131 KB): eight float4 in flight
+      constexpr int WB = 8;
+      const float* wg = W0 + (size_t)(nb * 32 + r) * RK + RD * kh + 4 * h;
+#pragma unroll
+      for (int t0 = 0; t0 < RK / 16; t0 += WB) {
+        float4 wv[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const float4*>(wg + 8 * (t0 + u));
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + RD * kh + 8 * (t0 + u) + 4 * h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
+        }
+      }
     }
     mfma_results_fence(acc);
     HSTAMP(2);
@@ -229,7 +276,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     }
     __syncthreads();
     {   // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y.  Thread (row, j): hidden units 8j..8j+7 of every class,
-        // the 8 partial sums of a row meet by xor-shuffles (fixed order); the target is loaded ahead of the arithmetic
+        // the OJ partial sums of a row meet by xor-shuffles (fixed order); the target is loaded ahead of the arithmetic
       const float4 za = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj);
       const float4 zb = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj + 4);
 #pragma unroll
@@ -238,9 +285,8 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
           const float4 wa = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj);
           const float4 wb = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj + 4);
           float s = ((za.x * wa.x + za.y * wa.y) + (za.z * wa.z + za.w * wa.w)) + ((zb.x * wb.x + zb.y * wb.y) + (zb.z * wb.z + zb.w * wb.w));
-          s += __shfl_xor(s, 1, 64);
-          s += __shfl_xor(s, 2, 64);
-          s += __shfl_xor(s, 4, 64);
+#pragma unroll
+          for (int off = 1; off < OJ; off <<= 1) s += __shfl_xor(s, off, 64);
           if (oj == 0) {
             float d = 0.f;
             if (orow < n) {
@@ -262,7 +308,9 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   for (int off = 32; off > 0; off >>= 1) sse += __shfl_xor(sse, off, 64);
   if (lane == 0) L.red[wave] = sse;
   __syncthreads();
-  const float block_sse = ((L.red[0] + L.red[1]) + L.red[2]) + L.red[3];
+  float block_sse = L.red[0];
+#pragma unroll
+  for (int w = 1; w < HW; ++w) block_sse += L.red[w];
   HSTAMP(3);
 
   // ---------------------------------------------------------------- grid-wide: every workgroup needs the batch's squared error
@@ -295,11 +343,11 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
   };
 
   // ---------------------------------------------------------------- phase 2: backward (unscaled), loss, scale
-  const int q = lane & 15, r4 = lane >> 4;
-  const int cb = wave;                                 // backward: this wave's 32-column block of the 128-wide embedding
-  f32x16 dw0[2];
+  const int q = threadIdx.x % QN, rgrp = threadIdx.x / QN;     // step 1: float4 column group / row (16 rows per pass)
+  const int cb = wave;                                 // backward: this wave's 32-column block of the 2RD-wide embedding
+  f32x16 dw0[NB];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) dw0[mb][i] = 0.f;
   float4 db0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,9 +360,9 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
     if (t != staged) {                                 // more tiles than workgroups: bring the tile back (block-uniform)
       __syncthreads();
-      stage_rows<RK>(L.e, ES, emb, g0, n, B);
-      stage_rows<RD>(L.z, ZS, z, g0, n, B);
-      {
+      stage_rows<RK, NT>(L.e, ES, emb, g0, n, B);
+      stage_rows<RD, NT>(L.z, ZS, z, g0, n, B);
+      if (threadIdx.x < RT * RCMAX) {
         const int row = threadIdx.x >> 3, c = threadIdx.x & 7;
         float d = 0.f;
         if (c < C && row < n) d = out[(size_t)(g0 + row) * C + c] - y[(size_t)(g0 + row) * C + c];
@@ -327,7 +375,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     float4 dzv[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = it * 16 + (threadIdx.x >> 4);
+      const int row = it * 16 + rgrp;
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < n) {
         const float4 zz = *reinterpret_cast<const float4*>(L.z + row * ZS + 4 * q);
@@ -350,7 +398,7 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     __syncthreads();                                   // every read of z is done
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = it * 16 + (threadIdx.x >> 4);
+      const int row = it * 16 + rgrp;
       *reinterpret_cast<float4*>(L.z + row * ZS + 4 * q) = dzv[it];
     }
     __syncthreads();
@@ -360,21 +408,42 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
     for (int s = 0; s < RT / 2; ++s) {
       const int row = 2 * s + h;
       const float bv = L.e[row * ES + cb * 32 + r];
-      dw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + r], bv, dw0[0], 0, 0, 0);
-      dw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + 32 + r], bv, dw0[1], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+        dw0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + mb * 32 + r], bv, dw0[mb], 0, 0, 0);
     }
     // 3. demb[:, cb] = dz W0[:, cb]
     f32x16 de;
 #pragma unroll
     for (int i = 0; i < 16; ++i) de[i] = 0.f;
+    if (W0_LDS) {
 #pragma unroll
-    for (int t8 = 0; t8 < RD / 8; ++t8) {
-      const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * t8 + 4 * h);
-      const int d0 = 8 * t8 + 4 * h;
-      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, L.w0[(d0 + 0) * WS0 + cb * 32 + r], de, 0, 0, 0);
-      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, L.w0[(d0 + 1) * WS0 + cb * 32 + r], de, 0, 0, 0);
-      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, L.w0[(d0 + 2) * WS0 + cb * 32 + r], de, 0, 0, 0);
-      de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      for (int t8 = 0; t8 < RD / 8; ++t8) {
+        const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * t8 + 4 * h);
+        const int d0 = 8 * t8 + 4 * h;
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, L.w0[(d0 + 0) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, L.w0[(d0 + 1) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, L.w0[(d0 + 2) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      }
+    } else {
+      constexpr int WB = 4;                            // 16 dword loads of W0 in flight (coalesced across r)
+#pragma unroll
+      for (int t0 = 0; t0 < RD / 8; t0 += WB) {
+        float wv[WB][4];
+#pragma unroll
+        for (int u = 0; u < WB; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wv[u][j] = W0[(size_t)(8 * (t0 + u) + 4 * h + j) * RK + cb * 32 + r];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * (t0 + u) + 4 * h);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u][0], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u][1], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u][2], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u][3], de, 0, 0, 0);
+        }
+      }
     }
     mfma_results_fence(de);
     HSTAMP(6);
@@ -389,51 +458,57 @@ __global__ __launch_bounds__(HW * 64, 1) void k_head(const float* __restrict__ e
 
   // ---------------------------------------------------------------- one slab per workgroup
   float* slab = slabs + (size_t)blockIdx.x * SLAB;
-  mfma_results_fence(dw0[0]);
-  mfma_results_fence(dw0[1]);
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < NB; ++mb) mfma_results_fence(dw0[mb]);
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) slab[(mb * 32 + krow(i, h)) * RK + cb * 32 + r] = gscale * dw0[mb][i];
-  // db0 / dW1 / db1: thread (rowgroup = threadIdx >> 4, q) holds partial sums for columns 4q..4q+3; combine the four
-  // row groups of a wave by shuffles, the four waves through LDS -- all in a fixed order
+  // db0 / dW1 / db1: thread (row group, q) holds partial sums for columns 4q..4q+3; combine the row groups of a wave
+  // (64 / QN of them) by shuffles, the waves through LDS -- all in a fixed order
   auto fold = [](float4 v) {
-    v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+#pragma unroll
+    for (int off = QN; off < 64; off <<= 1) {
+      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+    }
     return v;
   };
   __syncthreads();
-  constexpr int SMALL = RD + RCMAX * RD + RCMAX;       // db0 | dW1 | db1
   float* scratch = L.e;                                // [HW][SMALL + 8]: the emb tile is dead
   {
     float* mine = scratch + wave * (SMALL + 8);
     db0 = fold(db0);
-    if (r4 == 0) *reinterpret_cast<float4*>(mine + 4 * q) = db0;
+    if (lane < QN) *reinterpret_cast<float4*>(mine + 4 * q) = db0;
 #pragma unroll
     for (int c = 0; c < RCMAX; ++c) {
       if (c < C) {                                     // block-uniform: classes the model does not have cost no shuffles
         const float4 v = fold(dw1[c]);
-        if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
-        float sc = db1[c];                             // lanes with q == 0 hold the partial sums (4 of them)
-        sc += __shfl_xor(sc, 16, 64);
-        sc += __shfl_xor(sc, 32, 64);
+        if (lane < QN) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
+        float sc = db1[c];                             // lanes with q == 0 hold the partial sums
+#pragma unroll
+        for (int off = QN; off < 64; off <<= 1) sc += __shfl_xor(sc, off, 64);
         if (lane == 0) mine[RD + RCMAX * RD + c] = sc;
       } else {
-        if (r4 == 0) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < QN) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane == 0) mine[RD + RCMAX * RD + c] = 0.f;
       }
     }
   }
   __syncthreads();
   HSTAMP(7);
-  for (int idx = threadIdx.x; idx < SMALL; idx += HW * 64)
-    slab[RD * RK + idx] = gscale * (((scratch[idx] + scratch[(SMALL + 8) + idx]) + scratch[2 * (SMALL + 8) + idx]) + scratch[3 * (SMALL + 8) + idx]);
+  for (int idx = threadIdx.x; idx < SMALL; idx += NT) {
+    float sm = scratch[idx];
+#pragma unroll
+    for (int w = 1; w < HW; ++w) sm += scratch[w * (SMALL + 8) + idx];
+    slab[RD * RK + idx] = gscale * sm;
+  }
 }
 
 // Workgroups that are certainly co-resident: the grid-wide exchange needs every workgroup of the launch on a CU at the
-// same time.  One per CU at most (70 KB of LDS each), and only if the occupancy query admits one at all; the guide's
+// same time.  One per CU at most (70-80 KB of LDS each), and only if the occupancy query admits one at all; the guide's
 // SGPR cap min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)) is >= 7 for any kernel, far above the 1 used here.
-int head_resident_cap() {
+template <int RD>
+int head_resident_cap_t() {
   static int cap = -1;      // queried once per process (also keeps the query out of a stream capture)
   if (cap >= 0) return cap;
   int dev = 0, cus = MAXGRID, per_cu = 0;
@@ -441,26 +516,32 @@ int head_resident_cap() {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_head, HW * 64, 0) != hipSuccess) per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_head<RD>, HC<RD>::NT, 0) != hipSuccess) per_cu = 0;
   if (cus > MAXGRID) cus = MAXGRID;
   cap = per_cu >= 1 ? cus : 0;
   return cap;
 }
+int head_resident_cap(int64_t D) { return D == 128 ? head_resident_cap_t<128>() : head_resident_cap_t<64>(); }
 
-int head_grid(int64_t B) {
-  int cus = head_resident_cap();
+int head_grid(int64_t B, int64_t D) {
+  int cus = head_resident_cap(D);
   if (cus < 1) cus = 1;     // (hcg_head_fwd_bwd refuses to launch when the cap is 0)
   int grid = (int)((B + RT - 1) / RT);
   if (grid > cus) grid = cus;
   return grid < 1 ? 1 : grid;
 }
+size_t head_slab(int64_t D) { return D == 128 ? (size_t)HC<128>::SLAB : (size_t)HC<64>::SLAB; }
 
 }  // namespace
 
-extern "C" int hcg_head_supported(int64_t D, int64_t C) { return (D == RD && C >= 1 && C <= RCMAX) ? 1 : 0; }
+extern "C" int hcg_head_supported(int64_t D, int64_t C) { return ((D == 64 || D == 128) && C >= 1 && C <= RCMAX) ? 1 : 0; }
 
 // workspace: [grid][SLAB] gradient slabs
-extern "C" size_t hcg_head_workspace_bytes(int64_t B) { return hcg_align_up((size_t)head_grid(B) * SLAB * sizeof(float), 256) + 256; }
+extern "C" size_t hcg_head_workspace_bytes_d(int64_t B, int64_t D) {
+  if (D != 64 && D != 128) return 0;
+  return hcg_align_up((size_t)head_grid(B, D) * head_slab(D) * sizeof(float), 256) + 256;
+}
+extern "C" size_t hcg_head_workspace_bytes(int64_t B) { return hcg_head_workspace_bytes_d(B, 64); }
 
 extern "C" int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
                                 const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse, float* z,
@@ -477,25 +558,31 @@ extern "C" int hcg_head_fwd_bwd_ex(const float* emb, const float* y, const float
                                    int32_t* sync, int32_t* step_counter, float* sse_tail, hcg_stream_t stream) {
   if (!hcg_head_supported(D, C)) return HCG_ERR_UNSUPPORTED;
   if (rmse < 0 || rmse > HCG_HEAD_SSE || (rmse == HCG_HEAD_SSE && !sse_tail)) return HCG_ERR_INVALID_ARG;
-  if (head_resident_cap() < 1) return HCG_ERR_UNSUPPORTED;   // not even one workgroup per CU: the exchange cannot run
+  if (head_resident_cap(D) < 1) return HCG_ERR_UNSUPPORTED;   // not even one workgroup per CU: the exchange cannot run
   if (B <= 0 || !emb || !y || !W0 || !b0 || !W1 || !b1 || !z || !out || !loss || !demb || !workspace || !sync)
     return HCG_ERR_INVALID_ARG;
-  if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
-  const int grid = head_grid(B);
+  if (workspace_bytes < hcg_head_workspace_bytes_d(B, D)) return HCG_ERR_WORKSPACE;
+  const int grid = head_grid(B, D);
   float* slabs = (float*)workspace;
-  hipLaunchKernelGGL(k_head, dim3(grid), dim3(HW * 64), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C, slope,
-                     rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter, sse_tail);
+  if (D == 128)
+    hipLaunchKernelGGL(k_head<128>, dim3(grid), dim3(HC<128>::NT), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C,
+                       slope, rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter, sse_tail);
+  else
+    hipLaunchKernelGGL(k_head<64>, dim3(grid), dim3(HC<64>::NT), 0, (hipStream_t)stream, emb, y, W0, b0, W1, b1, (int)B, (int)C,
+                       slope, rmse, z, out, loss, demb, slabs, (int*)sync, (int*)step_counter, sse_tail);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
 
-extern "C" int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, float* dW0,
-                                   float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
-  if (B <= 0 || C < 1 || C > RCMAX || !dW0 || !db0 || !dW1 || !db1 || !job || !workspace) return HCG_ERR_INVALID_ARG;
-  if (workspace_bytes < hcg_head_workspace_bytes(B)) return HCG_ERR_WORKSPACE;
+extern "C" int hcg_head_reduce_job_d(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C, float* dW0,
+                                     float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
+  if (B <= 0 || (D != 64 && D != 128) || C < 1 || C > RCMAX || !dW0 || !db0 || !dW1 || !db1 || !job || !workspace)
+    return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_head_workspace_bytes_d(B, D)) return HCG_ERR_WORKSPACE;
+  const int32_t RD = (int32_t)D, RK = 2 * RD;
   job->slabs = (const float*)workspace;
-  job->nslabs = head_grid(B);
-  job->slab_floats = SLAB;
+  job->nslabs = head_grid(B, D);
+  job->slab_floats = (int32_t)head_slab(D);
   job->nseg = 4;
   job->reserved = 0;
   job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
@@ -503,4 +590,8 @@ extern "C" int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes
   job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};
   job->seg[3] = hcg_reduce_seg{RD * RK + RD + RCMAX * RD, (int32_t)C, 1, 1, db1};
   return HCG_OK;
+}
+extern "C" int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, float* dW0,
+                                   float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
+  return hcg_head_reduce_job_d(workspace, workspace_bytes, B, 64, C, dW0, db0, dW1, db1, job);
 }

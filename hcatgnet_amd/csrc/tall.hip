@@ -26,31 +26,37 @@
 namespace {
 
 // =====================================================================================================
-// dense part 1: out[N x NO] = A[N x K] * B   (B's pre-split image resident in LDS; one 32-row block per wave iteration)
+// dense part 1: out[N x NO] = A[N x K] * B   (B's pre-split image resident in LDS)
 // =====================================================================================================
-constexpr int TW = 8;                 // waves per workgroup: two per SIMD, 256 VGPRs each
+constexpr int TW = 16;                // waves per workgroup: the whole CU, four per SIMD, 128 VGPRs each
 constexpr int TT = TW * 64;
 
 // TRANS = false: B[k][n] = W[n][k]  (H = X W^T;  W is [NO x K] row-major = the layer's weight)
 // TRANS = true : B[k][n] = W[k][n]  (dX = dH W;  W is [K x NO] row-major = the same weight)
 // KP / NOB * 32: K and NO padded to the image extent; lda / ldo: the real row lengths of A / out (multiples of 4).
+// A wave owns one 32-row block x NBW 32-column blocks (NOB = 4: two waves share a row block, each re-reading its A rows
+// -- the second read hits L1 / L2); its A fragments come straight from global memory, a chunk of CK k-steps ahead.
+// (First version: 8 waves x 4 column blocks at 244 VGPRs: 68.6 us for C5's layer, three times its MFMA time -- two waves
+// per SIMD do not cover the row loads and the stores.)
 template <int KP, int NOB, bool TRANS, bool PREMASK>
-__global__ __launch_bounds__(TT, 1) void k_tall_mm(const float* __restrict__ A, int lda, const float* __restrict__ W, int wrows,
+__global__ __launch_bounds__(TT, 4) void k_tall_mm(const float* __restrict__ A, int lda, const float* __restrict__ W, int wrows,
                                                    int wcols, float* __restrict__ out, int ldo, const float* __restrict__ xmask,
                                                    float slope, int N) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* wl = reinterpret_cast<short*>(smem);
   constexpr int ROWS = NOB * 32, ld = KP + WPAD, plane = ROWS * ld;
+  constexpr int CS = NOB >= 2 ? 2 : 1, NBW = NOB / CS;          // waves per row block / column blocks per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   stage_weight_split<TRANS, TT, ROWS, KP>(wl, W, wrows, wcols);
   __syncthreads();
 
   constexpr int KS = KP / 16;                    // k-steps of a row block
-  constexpr int CK = KS >= 4 ? 4 : KS;           // k-steps per chunk: 32 A values per lane in flight
+  constexpr int CK = KS >= 2 ? 2 : KS;           // k-steps per chunk: 16 A values per lane in flight (4: 20-84 spilled registers)
   constexpr int NCH = KS / CK;
   const int nrb = (N + 31) / 32;
-  const int stride = gridDim.x * TW;
+  const int stride = gridDim.x * (TW / CS);
+  const int nb0 = (wave % CS) * NBW;
 
   // chunk c of row block rb: this lane's 8 consecutive k of every k-step (two float4; clamped, never guarded: columns
   // past lda meet zero image columns, rows past N are not stored)
@@ -63,20 +69,24 @@ __global__ __launch_bounds__(TT, 1) void k_tall_mm(const float* __restrict__ A, 
       int k0 = (c * CK + s) * 16 + 8 * h, k1 = k0 + 4;
       if (k0 > lda - 4) k0 = lda - 4;
       if (k1 > lda - 4) k1 = lda - 4;
+#ifdef HCG_PROBE_NOLOAD
+      const float4 v0 = make_float4((float)k0, 1.f, 2.f, 3.f), v1 = make_float4((float)k1, (float)row, 1.f, 0.f);
+#else
       const float4 v0 = *reinterpret_cast<const float4*>(base + k0);
       const float4 v1 = *reinterpret_cast<const float4*>(base + k1);
+#endif
       a[s][0] = v0.x; a[s][1] = v0.y; a[s][2] = v0.z; a[s][3] = v0.w;
       a[s][4] = v1.x; a[s][5] = v1.y; a[s][6] = v1.z; a[s][7] = v1.w;
     }
   };
 
-  int rb = blockIdx.x * TW + wave;
+  int rb = blockIdx.x * (TW / CS) + wave / CS;
   float cur[CK][8], nxt[CK][8];
   if (rb < nrb) load_chunk(cur, rb, 0);
   for (; rb < nrb; rb += stride) {
-    f32x16 acc[NOB];
+    f32x16 acc[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NOB; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 #pragma unroll
@@ -88,10 +98,14 @@ __global__ __launch_bounds__(TT, 1) void k_tall_mm(const float* __restrict__ A, 
       for (int s = 0; s < CK; ++s) {
         const Split3 As = split3(cur[s]);
 #pragma unroll
-        for (int nb = 0; nb < NOB; ++nb) {
-          const short* w0 = wl + (nb * 32 + r) * ld + (c * CK + s) * 16 + 8 * h;
+        for (int nb = 0; nb < NBW; ++nb) {
+          const short* w0 = wl + ((nb0 + nb) * 32 + r) * ld + (c * CK + s) * 16 + 8 * h;
+#ifdef HCG_PROBE_NOMFMA
+          acc[nb][0] += cur[s][nb] + (float)As.p1[0] + (float)(*reinterpret_cast<const bf16x8*>(w0))[0];
+#else
           mfma_split(acc[nb], As, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
                      *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
+#endif
         }
       }
 #pragma unroll
@@ -100,27 +114,34 @@ __global__ __launch_bounds__(TT, 1) void k_tall_mm(const float* __restrict__ A, 
         for (int j = 0; j < 8; ++j) cur[s][j] = nxt[s][j];
     }
 #pragma unroll
-    for (int nb = 0; nb < NOB; ++nb) mfma_results_fence(acc[nb]);
+    for (int nb = 0; nb < NBW; ++nb) mfma_results_fence(acc[nb]);
     const int row0 = rb * 32;
 #pragma unroll
-    for (int nb = 0; nb < NOB; ++nb) {
-      const int col = nb * 32 + r;
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int col = (nb0 + nb) * 32 + r;
       const int colc = col < ldo ? col : ldo - 1;
-      if (PREMASK) {      // dx handed down already multiplied by leaky'(x) of the layer below (16 loads together, clamped)
-        float xm[16];
+      if (PREMASK) {      // dx handed down already multiplied by leaky'(x) of the layer below (4 loads together, clamped: the kernel is at its register limit)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = row0 + krow(i, h);
-          if (row > N - 1) row = N - 1;
-          xm[i] = xmask[(size_t)row * ldo + colc];
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+          float xm[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int row = row0 + krow(i0 + i, h);
+            if (row > N - 1) row = N - 1;
+            xm[i] = xmask[(size_t)row * ldo + colc];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[nb][i0 + i] *= hcg_leaky_grad(xm[i], slope);
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][i] *= hcg_leaky_grad(xm[i], slope);
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = row0 + krow(i, h);
+#ifdef HCG_PROBE_NOSTORE
+        if (row < N && col < ldo && acc[nb][i] == 1.2345e30f) out[(size_t)row * ldo + col] = acc[nb][i];
+#else
         if (row < N && col < ldo) out[(size_t)row * ldo + col] = acc[nb][i];
+#endif
       }
     }
   }
@@ -129,26 +150,35 @@ __global__ __launch_bounds__(TT, 1) void k_tall_mm(const float* __restrict__ A, 
 // =====================================================================================================
 // dense part 2: dW[D x F] = dH^T X over all nodes, split over workgroups by node rows -> one slab per workgroup
 // =====================================================================================================
-// A workgroup walks 64-row tiles of dH [N x D] and X [N x F] (both staged row-contiguous into LDS, the next tile's loads in
-// flight under this tile's MFMAs); the D/32 x FP/32 output blocks are spread over the 8 waves (16 blocks: two per wave
-// sharing the dH fragment; fewer blocks than waves: the waves of a block take alternate k-steps and meet in LDS at the
-// end, fixed order).  Both operands are read down LDS columns (K = nodes).
+// A workgroup of 8 waves walks 64-row tiles of dH [N x D] and X [N x F].  K = nodes: both MFMA operands run DOWN the
+// columns of the row-major tensors, so every (column, 8 nodes) fragment is loaded once (8 dword loads, a wave's lanes on
+// consecutive columns: 256-byte segments; the next tile's loads in flight under this tile's MFMAs), split ONCE into its
+// three bf16 pieces and stored as three 16-byte LDS writes into a [column][node] image -- the waves then fetch finished
+// operands with ds_read_b128 and spend no VALU on them.  (First version: f32 tiles in LDS, 24 ds_read_b32 + three
+// 44-instruction splits per k-step and wave: 66.9 us for C5's layer, VALU-bound.)  The D/32 x FP/32 output blocks are
+// spread over the waves (16 blocks: two per wave sharing the dH fragment; fewer blocks than waves: the waves of a block
+// take alternate k-steps and meet in LDS at the end, fixed order).
+constexpr int DWW = 8, DWT = DWW * 64;
+// position of node octet `o` inside column c's image row: XOR-swizzled by the column's 16-block, so that the 16 lanes of a
+// ds_write_b128 phase (columns 4 apart: 144-dword stride = 16 banks) spread over all 64 banks; the readers (16 consecutive
+// columns of one 16-block: 36-dword stride) are conflict-free either way
+__device__ __forceinline__ constexpr int dw_oct(int c, int o) { return o ^ ((c >> 4) & 3); }
+
 template <int DB, int NBF>
-__global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
-                                                   float* __restrict__ slabs, int N) {
-  constexpr int D = DB * 32, FP = NBF * 32, TR = 64;
-  constexpr int ZS = D + 4, XS = FP + 4;
-  constexpr int NTILE = DB * NBF, TPW = NTILE >= TW ? NTILE / TW : 1, KPARTS = NTILE >= TW ? 1 : TW / NTILE;
-  static_assert(NTILE * KPARTS == TW * TPW, "block -> wave map");
+__global__ __launch_bounds__(DWT, 2) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
+                                                    float* __restrict__ slabs, int N) {
+  constexpr int D = DB * 32, FP = NBF * 32, TR = 64, LDT = TR + 8;
+  constexpr int NTILE = DB * NBF, TPW = NTILE >= DWW ? NTILE / DWW : 1, KPARTS = NTILE >= DWW ? 1 : DWW / NTILE;
+  static_assert(NTILE * KPARTS == DWW * TPW, "block -> wave map");
   static_assert(TPW == 1 || NBF % TPW == 0, "a wave's blocks share the dH fragment");
+  static_assert(D == 128 && DWT == 512, "staging map: 256 threads per tensor, a (column quad, node octet) each");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* zt = reinterpret_cast<float*>(smem);          // [TR][ZS]
-  float* xt = zt + TR * ZS;                            // [TR][XS]
+  short* zp = reinterpret_cast<short*>(smem);          // 3 planes [D][LDT]
+  short* xp = zp + 3 * D * LDT;                        // 3 planes [FP][LDT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int blk0 = (wave % (NTILE / TPW)) * TPW, part = wave / (NTILE / TPW);
   const int mbd = blk0 / NBF, nbf0 = blk0 % NBF;
-  constexpr int ZPT = TR * D / 4 / TT, XPT = (TR * FP / 4 + TT - 1) / TT;     // float4 per thread and tile
   const int ntiles = (N + TR - 1) / TR;
 
   f32x16 dw[TPW];
@@ -157,37 +187,44 @@ __global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) dw[j][i] = 0.f;
 
-  float4 zv[ZPT], xv[XPT];
+  // staging: threads 0..255 take dH, 256..511 take X; thread (cq, oct): columns 4 cq .. 4 cq + 3 of nodes 8 oct .. 8 oct + 7:
+  // eight float4 loads (a wave covers two whole 512-byte rows per instruction), four splits, twelve 16-byte LDS writes
+  const bool is_x = tid >= 256;
+  const int cq = tid & 31, oct = (tid >> 5) & 7;
+  const bool x_live = 4 * cq < FP;                     // (FP < 128: some X stagers idle)
+  float4 sv[8];
   auto load_tile = [&](int t) {
-    const int row0 = t * TR;
+    const int row0 = t * TR + oct * 8;
+    const float* src = is_x ? X : Z;
+    const int ldm = is_x ? F : D;
+    int c = 4 * cq;
+    if (c > ldm - 4) c = ldm - 4;
 #pragma unroll
-    for (int j = 0; j < ZPT; ++j) {
-      const int idx = tid + j * TT, row = idx / (D / 4), c4 = idx - row * (D / 4);
-      int gr = row0 + row;
-      if (gr > N - 1) gr = N - 1;
-      zv[j] = *reinterpret_cast<const float4*>(Z + (size_t)gr * D + 4 * c4);
-    }
-#pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int idx = tid + j * TT, row = (idx / (FP / 4)) % TR, c4 = idx % (FP / 4);
-      int gr = row0 + row, c = 4 * c4;
-      if (gr > N - 1) gr = N - 1;
-      if (c > F - 4) c = F - 4;
-      xv[j] = *reinterpret_cast<const float4*>(X + (size_t)gr * F + c);
+    for (int u = 0; u < 8; ++u) {
+      int node = row0 + u;
+      if (node > N - 1) node = N - 1;
+      sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
     }
   };
   auto store_tile = [&](int t) {                       // rows past N and columns past F become zeros (they are summed)
-    const int row0 = t * TR;
+    const int row0 = t * TR + oct * 8;
+    if (is_x && !x_live) return;
+    short* planes = is_x ? xp : zp;
+    const int rows = is_x ? FP : D, lim = is_x ? F : D;
 #pragma unroll
-    for (int j = 0; j < ZPT; ++j) {
-      const int idx = tid + j * TT, row = idx / (D / 4), c4 = idx - row * (D / 4);
-      *reinterpret_cast<float4*>(zt + row * ZS + 4 * c4) = row0 + row < N ? zv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * cq + i;
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int idx = tid + j * TT, row = idx / (FP / 4), c4 = idx - row * (FP / 4);
-      if (row < TR)
-        *reinterpret_cast<float4*>(xt + row * XS + 4 * c4) = (row0 + row < N && 4 * c4 < F) ? xv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u) {
+        const float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
+        v[u] = (row0 + u < N && c < lim) ? e : 0.f;
+      }
+      const Split3 sp = split3(v);
+      short* dst = planes + c * LDT + dw_oct(c, oct) * 8;
+      *reinterpret_cast<bf16x8*>(dst) = sp.p1;
+      *reinterpret_cast<bf16x8*>(dst + rows * LDT) = sp.p2;
+      *reinterpret_cast<bf16x8*>(dst + 2 * rows * LDT) = sp.p3;
     }
   };
 
@@ -200,18 +237,19 @@ __global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, 
     if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
 #pragma unroll
     for (int ks = 0; ks < TR / 16; ++ks) {
-      if (KPARTS > 1 && (ks % KPARTS) != part) continue;      // (compile-time unrolled; wave-uniform)
-      float av[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) av[j] = zt[(16 * ks + 8 * h + j) * ZS + mbd * 32 + r];
-      const Split3 As = split3(av);
+      if (KPARTS > 1 && (ks % KPARTS) != part) continue;      // (wave-uniform)
+      const int ca = mbd * 32 + r;
+      const short* za = zp + ca * LDT + dw_oct(ca, 2 * ks + h) * 8;
+      Split3 As;
+      As.p1 = *reinterpret_cast<const bf16x8*>(za);
+      As.p2 = *reinterpret_cast<const bf16x8*>(za + D * LDT);
+      As.p3 = *reinterpret_cast<const bf16x8*>(za + 2 * D * LDT);
 #pragma unroll
       for (int b = 0; b < TPW; ++b) {
-        float bv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = xt[(16 * ks + 8 * h + j) * XS + (nbf0 + b) * 32 + r];
-        const Split3 Bs = split3(bv);
-        mfma_split(dw[b], As, Bs.p1, Bs.p2, Bs.p3);
+        const int cb = (nbf0 + b) * 32 + r;
+        const short* xb = xp + cb * LDT + dw_oct(cb, 2 * ks + h) * 8;
+        mfma_split(dw[b], As, *reinterpret_cast<const bf16x8*>(xb), *reinterpret_cast<const bf16x8*>(xb + FP * LDT),
+                   *reinterpret_cast<const bf16x8*>(xb + 2 * FP * LDT));
       }
     }
   }
@@ -226,9 +264,9 @@ __global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) slab[(mbd * 32 + krow(i, h)) * FP + (nbf0 + b) * 32 + r] = dw[b][i];
   } else {
-    __syncthreads();                                   // the tiles are dead: [NTILE][32 * 32] combine scratch over them
-    float* comb = zt;
-    static_assert(NTILE * 1024 <= TR * ZS + TR * XS || KPARTS == 1, "combine scratch");
+    __syncthreads();                                   // the images are dead: [NTILE][32 * 32] combine scratch over them
+    float* comb = reinterpret_cast<float*>(smem);
+    static_assert(KPARTS == 1 || NTILE * 1024 * 4 <= 3 * (D + FP) * LDT * 2, "combine scratch");
     for (int round = 0; round < KPARTS; ++round) {
       if (part == round) {
 #pragma unroll
@@ -239,7 +277,7 @@ __global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, 
       }
       __syncthreads();
     }
-    for (int idx = tid; idx < NTILE * 1024; idx += TT) {
+    for (int idx = tid; idx < NTILE * 1024; idx += DWT) {
       const int b = idx >> 10, rr = (idx >> 5) & 31, cc = idx & 31;
       slab[((b / NBF) * 32 + rr) * FP + (b % NBF) * 32 + cc] = comb[idx];
     }
@@ -247,34 +285,39 @@ __global__ __launch_bounds__(TT, 4) void k_tall_dw(const float* __restrict__ Z, 
 }
 
 // =====================================================================================================
-// graph part: one graph per workgroup of 4 waves; only the CSR lives in LDS, rows are gathered from global memory / L2
+// graph part: one graph per workgroup iteration, 16 waves (the whole CU); the graph's rows sit in ONE LDS tile
 // =====================================================================================================
-constexpr int SN = 256, SW = SN / 64;
+// A 200-node x 128-d graph is 102 KB: it fits LDS once (not twice, and not beside a weight image -- which is why the dense
+// part runs apart).  Per graph: rows -> registers (requested one graph AHEAD, under the previous graph's sums), CSR build,
+// rows scaled by dinv into the tile, wavefront segmented sum out of LDS (32 lanes x float4 per row, 32 rows per pass),
+// epilogue, row-contiguous 512-byte stores.  Gathering the neighbour rows from L2 instead (one workgroup of 4 waves per
+// graph, 4 workgroups per CU) was measured first: 59-93 us per launch on C5, every pass a dependent L2 round trip.
+constexpr int SN = 1024, SW = SN / 64;
 constexpr int SEG_MAX_NODES = 224;    // (same limits as mid.hip: every batch one family takes, the other takes too)
-constexpr int SEG_MAX_EDGES = 1024;
-constexpr int SEPT = SEG_MAX_EDGES / SN;
-constexpr int SEG_MAX_D = 128;
+constexpr int SEG_MAX_EDGES = 1024;   // one edge per thread
+constexpr int SEG_D = 128, SEG_TS = SEG_D + 4;
+constexpr int SEG_RPT = SEG_MAX_NODES * (SEG_D / 4) / SN;      // float4 per thread to hold one graph's rows (7)
+static_assert(SEG_MAX_EDGES == SN && SEG_MAX_NODES * (SEG_D / 4) % SN == 0, "thread maps");
 
 struct SegLds {
-  int rowptr[SEG_MAX_NODES + 1 + 3];
+  int rowptr[SEG_MAX_NODES + 4];
   int cursor[SEG_MAX_NODES];
   int degin[SEG_MAX_NODES];
   float dinv[SEG_MAX_NODES];
   unsigned short col[SEG_MAX_EDGES];
-  float red[SW * 2 * SEG_MAX_D];
-  float bc[SEG_MAX_D];
+  float red[SW * 2 * SEG_D];
 };
 
 struct SegGraph { int nbase, n, ebase, ne, nld; };
 
 __device__ __forceinline__ SegGraph seg_graph(int g, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
-                                              int32_t* status) {
+                                              int npad, int32_t* status) {
   SegGraph gi;
   gi.nbase = graph_ptr[g];
   gi.n = graph_ptr[g + 1] - gi.nbase;
   gi.ebase = edge_ptr[g];
   gi.ne = edge_ptr[g + 1] - gi.ebase;
-  if (gi.n < 0 || gi.n > SEG_MAX_NODES || gi.ne < 0 || gi.ne > SEG_MAX_EDGES) {     // host metadata was wrong: refuse the graph
+  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > SEG_MAX_EDGES) {     // host metadata was wrong: refuse the graph
     if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
     gi.n = 0;
     gi.ne = 0;
@@ -283,46 +326,53 @@ __device__ __forceinline__ SegGraph seg_graph(int g, const int32_t* __restrict__
   return gi;
 }
 
-struct SegEdges {
-  long long s[SEPT], d[SEPT];
+struct SegEdge {       // this thread's edge of the graph (loads only: unconditional, clamped)
+  long long s, d;
   __device__ __forceinline__ void load(const SegGraph& gi, const int64_t* __restrict__ ei, int64_t E) {
+    const int e = threadIdx.x;
+    int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
+    if (k > E - 1) k = E - 1;
+    s = ei[k];
+    d = ei[E + k];
+  }
+};
+
+// this thread's share of a graph's rows: rows rg, rg + 32, ... (rg = tid / 32), columns 4 c4 .. 4 c4 + 3 (c4 = tid % 32)
+struct SegRows {
+  float4 v[SEG_RPT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi) {
+    const int rg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+    const float* base = src + (size_t)gi.nld * SEG_D + 4 * c4;
 #pragma unroll
-    for (int j = 0; j < SEPT; ++j) {
-      const int e = threadIdx.x + j * SN;
-      int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
-      if (k > E - 1) k = E - 1;
-      s[j] = ei[k];
-      d[j] = ei[E + k];
+    for (int j = 0; j < SEG_RPT; ++j) {
+      if (j * 32 < gi.n) {                      // block-uniform guard, clamped address: no per-lane branch around the load
+        const int row = rg + 32 * j;
+        v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * SEG_D);
+      }
     }
   }
 };
 
-// The algorithm of mid.hip's build_csr for 256 threads: in-degree -> dinv = (1 + deg_in)^-1/2, counting sort into rows
-// (BY_SRC: rows = sources = the transpose), explicit (i, i) edges collapse into the unit self loop, every row sorted by id.
+// The algorithm of mid.hip's build_csr for 1024 threads (one edge each): in-degree -> dinv = (1 + deg_in)^-1/2, counting
+// sort into rows (BY_SRC: rows = sources = the transpose), explicit (i, i) edges collapse into the unit self loop, every
+// row sorted by id.  Ends with a barrier.
 template <bool BY_SRC>
-__device__ __forceinline__ void seg_build_csr(SegLds& L, const SegGraph& gi, const SegEdges& er, int32_t* status) {
+__device__ __forceinline__ void seg_build_csr(SegLds& L, const SegGraph& gi, const SegEdge& er, int32_t* status) {
   const int tid = threadIdx.x;
   const int n = gi.n;
-  for (int i = tid; i < n; i += SN) { L.cursor[i] = 0; if (BY_SRC) L.degin[i] = 0; }
+  if (tid < n) { L.cursor[tid] = 0; if (BY_SRC) L.degin[tid] = 0; }
   __syncthreads();
-  unsigned short es[SEPT], ed[SEPT];
+  unsigned short es = 0xffff, ed = 0xffff;
   bool bad = false;
-#pragma unroll
-  for (int j = 0; j < SEPT; ++j) {
-    const int e = tid + j * SN;
-    es[j] = 0xffff;
-    ed[j] = 0xffff;
-    if (e < gi.ne) {
-      const long long s = er.s[j], d = er.d[j];
-      const unsigned sl = (unsigned)((int)s - gi.nbase), dl = (unsigned)((int)d - gi.nbase);
-      const bool ok = sl < (unsigned)n && dl < (unsigned)n && (s >> 31) == 0 && (d >> 31) == 0;
-      bad |= !ok;
-      if (ok && sl != dl) {
-        es[j] = (unsigned short)sl;
-        ed[j] = (unsigned short)dl;
-        atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
-        if (BY_SRC) atomicAdd(&L.degin[dl], 1);
-      }
+  if (tid < gi.ne) {
+    const unsigned sl = (unsigned)((int)er.s - gi.nbase), dl = (unsigned)((int)er.d - gi.nbase);
+    const bool ok = sl < (unsigned)n && dl < (unsigned)n && (er.s >> 31) == 0 && (er.d >> 31) == 0;
+    bad = !ok;
+    if (ok && sl != dl) {
+      es = (unsigned short)sl;
+      ed = (unsigned short)dl;
+      atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
+      if (BY_SRC) atomicAdd(&L.degin[dl], 1);
     }
   }
   if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);
@@ -350,20 +400,20 @@ __device__ __forceinline__ void seg_build_csr(SegLds& L, const SegGraph& gi, con
       run += v[j];
     }
     if (tid == 63) L.rowptr[n] = incl;
-  }
-  for (int i = tid; i < n; i += SN) L.dinv[i] = 1.0f / sqrtf(1.0f + (float)(BY_SRC ? L.degin[i] : L.cursor[i]));
-  __syncthreads();
-  for (int i = tid; i < n; i += SN) L.cursor[i] = L.rowptr[i];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < SEPT; ++j) {
-    if (es[j] != 0xffff) {
-      const int p = atomicAdd(&L.cursor[BY_SRC ? es[j] : ed[j]], 1);
-      L.col[p] = BY_SRC ? ed[j] : es[j];
-    }
+  } else if (tid >= SN - SEG_MAX_NODES) {      // (other waves, meanwhile) dinv of every row
+    const int i = tid - (SN - SEG_MAX_NODES);
+    if (i < n) L.dinv[i] = 1.0f / sqrtf(1.0f + (float)(BY_SRC ? L.degin[i] : L.cursor[i]));
   }
   __syncthreads();
-  for (int i = tid; i < n; i += SN) {
+  if (tid < n) L.cursor[tid] = L.rowptr[tid];
+  __syncthreads();
+  if (es != 0xffff) {
+    const int p = atomicAdd(&L.cursor[BY_SRC ? es : ed], 1);
+    L.col[p] = BY_SRC ? ed : es;
+  }
+  __syncthreads();
+  if (tid < n) {
+    const int i = tid;
     const int kb = L.rowptr[i], ke = L.rowptr[i + 1], len = ke - kb;
     if (len > 1 && len <= 4) {
       unsigned a0 = L.col[kb], a1 = L.col[kb + 1], a2 = len > 2 ? L.col[kb + 2] : 0xffffu, a3 = len > 3 ? L.col[kb + 3] : 0xffffu;
@@ -393,75 +443,74 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 __device__ __forceinline__ float4 f4_scale(float s, float4 v) { return make_float4(s * v.x, s * v.y, s * v.z, s * v.w); }
 __device__ __forceinline__ void f4_add(float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
 
-// One row's slot of the walk: the row, its CSR range and its first four neighbours (absent ones point at the row itself)
-struct SegRow {
-  int row, kb, ke, c[4];
-  bool valid;
-  __device__ __forceinline__ void set(const SegLds& L, int row_, int n) {
-    valid = row_ < n;
-    row = valid ? row_ : (n > 0 ? n - 1 : 0);
-    kb = valid ? L.rowptr[row] : 0;
-    ke = valid ? L.rowptr[row + 1] : 0;
+// acc = t[row] + sum_{k in [kb, ke)} t[col[k]] for this lane's (row, 4 c4 ..) slot: the first four neighbours' rows are
+// requested together (independent LDS reads instead of a chain of dependent ones), longer rows loop on
+__device__ __forceinline__ float4 seg_row_sum(const float* t, const unsigned short* col, int row, int kb, int ke, int c4) {
+  float4 acc = *reinterpret_cast<const float4*>(t + row * SEG_TS + 4 * c4);
+  int c[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? L.col[kb + j] : row;
+  for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? col[kb + j] : row;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(t + c[j] * SEG_TS + 4 * c4);
+    if (kb + j < ke) f4_add(acc, v);
   }
-};
+  for (int k = kb + 4; __any(k < ke); ++k) {
+    if (k < ke) f4_add(acc, *reinterpret_cast<const float4*>(t + col[k] * SEG_TS + 4 * c4));
+  }
+  return acc;
+}
 
-// ---- forward: out_i = LeakyReLU(dinv_i (dinv_i H_i + sum_k dinv_k H_k) + b), [max | mean] pooling
-template <int D, bool POOL>
+// ---- forward: H' = dinv . H;  out_i = LeakyReLU(dinv_i (H'_i + sum_k H'_k) + b), [max | mean] pooling
+template <bool POOL>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ H, const float* __restrict__ bias,
-                                                const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
-                                                const int32_t* __restrict__ edge_ptr, int B, float slope, int apply_act,
-                                                float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
+                                                   const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
+                                                   const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int apply_act,
+                                                   float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
+  constexpr int D = SEG_D;
   __shared__ SegLds L;
-  constexpr int LPR = D / 4, RPW = 64 / LPR, RPP = RPW * SW, INF = 2;      // INF rows of a lane in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);          // [npad][SEG_TS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane % LPR, rsub = lane / LPR;
-  const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+  const int c4 = tid & 31, rg = tid >> 5;
+  const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * c4);
 
   SegGraph gnext;
-  SegEdges er;
+  SegEdge er;
+  SegRows rows;
   if ((int)blockIdx.x < B) {
-    gnext = seg_graph(blockIdx.x, graph_ptr, edge_ptr, status);
+    gnext = seg_graph(blockIdx.x, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
+    rows.load(H, gnext);
   }
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const SegGraph gi = gnext;
     seg_build_csr<false>(L, gi, er, status);
-    if (g + (int)gridDim.x < B) {                     // the NEXT graph's scalars and edges: in flight under this graph's rows
-      gnext = seg_graph(g + gridDim.x, graph_ptr, edge_ptr, status);
+#pragma unroll
+    for (int j = 0; j < SEG_RPT; ++j) {
+      const int row = rg + 32 * j;
+      if (j * 32 < gi.n && row < gi.n) *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], rows.v[j]);
+    }
+    __syncthreads();
+    if (g + (int)gridDim.x < B) {                     // the NEXT graph's scalars, edge and rows: in flight under this graph's sums
+      gnext = seg_graph(g + gridDim.x, graph_ptr, edge_ptr, npad, status);
       er.load(gnext, ei, E);
+      rows.load(H, gnext);
     }
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = f4_zero();
-    const float* Hg = H + (size_t)gi.nld * D + 4 * q;
-    for (int pb = 0; pb < gi.n; pb += RPP * INF) {     // (block-uniform trip count: the tail loop below votes per wave)
-      const int row0 = pb + wave * RPW + rsub;
-      SegRow rw[INF];
-      float4 hs[INF], hv[INF][4];
 #pragma unroll
-      for (int u = 0; u < INF; ++u) {
-        rw[u].set(L, row0 + u * RPP, gi.n);
-        hs[u] = *reinterpret_cast<const float4*>(Hg + (size_t)rw[u].row * D);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hv[u][j] = *reinterpret_cast<const float4*>(Hg + (size_t)rw[u].c[j] * D);
-      }
-#pragma unroll
-      for (int u = 0; u < INF; ++u) {
-        const SegRow& w = rw[u];
-        const float di = L.dinv[w.row];
-        float4 acc = f4_scale(di, hs[u]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (w.kb + j < w.ke) f4_add(acc, f4_scale(L.dinv[w.c[j]], hv[u][j]));
-        for (int k = w.kb + 4; __any(k < w.ke); ++k) {
-          const int c = k < w.ke ? L.col[k] : w.row;
-          const float4 v = *reinterpret_cast<const float4*>(Hg + (size_t)c * D);
-          if (k < w.ke) f4_add(acc, f4_scale(L.dinv[c], v));
-        }
+    for (int j = 0; j < SEG_RPT; ++j) {
+      if (j * 32 < gi.n) {                             // (block-uniform: the tail loop of seg_row_sum votes per wave)
+        const int row = rg + 32 * j;
+        const bool valid = row < gi.n;
+        const int rr = valid ? row : gi.n - 1;
+        const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
+        const float4 acc = seg_row_sum(tile, L.col, rr, kb, ke, c4);
+        const float di = L.dinv[rr];
         float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
         if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
-        if (w.valid) {
-          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + w.row) * D + 4 * q) = y;
+        if (valid) {
+          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * D + 4 * c4) = y;
           if (POOL) {
             pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
             f4_add(psum, y);
@@ -469,23 +518,20 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ H, 
         }
       }
     }
-    if (POOL) {
-#pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) {
-        pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, off, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, off, 64)),
-                           fmaxf(pmax.z, __shfl_xor(pmax.z, off, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, off, 64)));
-        psum.x += __shfl_xor(psum.x, off, 64); psum.y += __shfl_xor(psum.y, off, 64);
-        psum.z += __shfl_xor(psum.z, off, 64); psum.w += __shfl_xor(psum.w, off, 64);
-      }
-      if (rsub == 0) {
-        *reinterpret_cast<float4*>(L.red + wave * 2 * D + 4 * q) = pmax;
-        *reinterpret_cast<float4*>(L.red + wave * 2 * D + D + 4 * q) = psum;
+    if (POOL) {      // the two row slots of a wave (xor 32) -> workgroup (LDS, fixed order over the waves)
+      pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 32, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 32, 64)),
+                         fmaxf(pmax.z, __shfl_xor(pmax.z, 32, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 32, 64)));
+      psum.x += __shfl_xor(psum.x, 32, 64); psum.y += __shfl_xor(psum.y, 32, 64);
+      psum.z += __shfl_xor(psum.z, 32, 64); psum.w += __shfl_xor(psum.w, 32, 64);
+      if (lane < 32) {
+        *reinterpret_cast<float4*>(L.red + wave * 2 * D + 4 * c4) = pmax;
+        *reinterpret_cast<float4*>(L.red + wave * 2 * D + D + 4 * c4) = psum;
       }
       __syncthreads();
       if (tid < D) {
         float m = -INFINITY, s = 0.f;
 #pragma unroll
-        for (int w = 0; w < SW; ++w) {                  // fixed order over the waves
+        for (int w = 0; w < SW; ++w) {
           m = fmaxf(m, L.red[w * 2 * D + tid]);
           s += L.red[w * 2 * D + D + tid];
         }
@@ -494,148 +540,110 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ H, 
         emb[(size_t)g * 2 * D + D + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
       }
     }
-    __syncthreads();   // the CSR and the combine scratch are free for the next graph
+    __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
   }
 }
 
-// ---- backward: G = dA (.) leaky'(A);  db += colsum G;  dH_j = dinv_j (dinv_j G_j + sum_{k in row j of the transpose} dinv_k G_k)
+// ---- backward: G = dA (.) leaky'(A);  db += colsum G;  dY' = dinv . G;  dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_k)
 // POOLG: dA is the pooled gradient expanded on chip (mean share + the max's share split evenly over ties, as
-// global_max_pool's backward does through torch.max).  TWO: both dout and a_out are read per row (activation derivative
-// applied here); otherwise exactly one tensor is gathered.
-template <int D, bool POOLG, bool TWO>
+// global_max_pool's backward does through torch.max).  TWO: both dout and a_out are read (activation derivative applied
+// here); otherwise exactly one tensor is read.
+template <bool POOLG, bool TWO>
 __global__ __launch_bounds__(SN, 4) void k_seg_bwd(const float* __restrict__ dout, const float* __restrict__ demb,
-                                                const float* __restrict__ emb, const float* __restrict__ a_out,
-                                                const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
-                                                const int32_t* __restrict__ edge_ptr, int B, float slope, int act_here,
-                                                float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status) {
+                                                   const float* __restrict__ emb, const float* __restrict__ a_out,
+                                                   const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
+                                                   const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int act_here,
+                                                   float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status) {
+  constexpr int D = SEG_D;
+  constexpr bool NEED_A = POOLG || TWO;
   __shared__ SegLds L;
-  constexpr int LPR = D / 4, RPW = 64 / LPR, RPP = RPW * SW, INF = TWO ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane % LPR, rsub = lane / LPR;
+  const int c4 = tid & 31, rg = tid >> 5;
   float4 dbacc = f4_zero();
 
   SegGraph gnext;
-  SegEdges er;
-  if ((int)blockIdx.x < B) {
-    gnext = seg_graph(blockIdx.x, graph_ptr, edge_ptr, status);
+  SegEdge er;
+  SegRows drows, arows;
+  float4 gmx = f4_zero(), dmx = f4_zero(), dmean = f4_zero();
+  auto request = [&](int g) {                          // everything of graph g this thread will need: loads only
+    gnext = seg_graph(g, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
-  }
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
-    const SegGraph gi = gnext;
-    // the pooled pieces of this graph: requested before the CSR build
-    float4 gmx = f4_zero(), dmx = f4_zero(), dmean = f4_zero(), share = f4_zero();
+    if (!POOLG) drows.load(dout, gnext);
+    if (NEED_A) arows.load(a_out, gnext);
     if (POOLG) {
-      const size_t eb = (size_t)g * 2 * D + 4 * q;
+      const size_t eb = (size_t)g * 2 * D + 4 * c4;
       gmx = *reinterpret_cast<const float4*>(emb + eb);
       dmx = *reinterpret_cast<const float4*>(demb + eb);
       dmean = *reinterpret_cast<const float4*>(demb + eb + D);
     }
+  };
+  if ((int)blockIdx.x < B) request(blockIdx.x);
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const SegGraph gi = gnext;
     seg_build_csr<true>(L, gi, er, status);
-    if (g + (int)gridDim.x < B) {
-      gnext = seg_graph(g + gridDim.x, graph_ptr, edge_ptr, status);
-      er.load(gnext, ei, E);
-    }
-    const float* Ag = a_out ? a_out + (size_t)gi.nld * D + 4 * q : nullptr;
-    const float* Dg = dout ? dout + (size_t)gi.nld * D + 4 * q : nullptr;
+    float4 share = f4_zero(), dmn = f4_zero();
+    const float4 gm = gmx;
     if (POOLG) {
       const float cntf = (float)(gi.n > 0 ? gi.n : 1);
-      dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
-      // ties of the column maxima: one pass over the graph's rows (they stay in L2 for the gather below)
-      float4 ties = f4_zero();
-      constexpr int TB = 4;
-      for (int pb = 0; pb < gi.n; pb += RPP * TB) {
-        const int row0 = pb + wave * RPW + rsub;
-        float4 a[TB];
+      dmn = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
+      float4 ties = f4_zero();                           // ties of the column maxima among this thread's rows
 #pragma unroll
-        for (int u = 0; u < TB; ++u) {
-          int row = row0 + u * RPP;
-          if (row > gi.n - 1) row = gi.n > 0 ? gi.n - 1 : 0;
-          a[u] = *reinterpret_cast<const float4*>(Ag + (size_t)row * D);
-        }
-#pragma unroll
-        for (int u = 0; u < TB; ++u) {
-          if (row0 + u * RPP < gi.n) {
-            ties.x += (a[u].x == gmx.x); ties.y += (a[u].y == gmx.y); ties.z += (a[u].z == gmx.z); ties.w += (a[u].w == gmx.w);
-          }
+      for (int j = 0; j < SEG_RPT; ++j) {
+        if (j * 32 < gi.n && rg + 32 * j < gi.n) {
+          const float4 a = arows.v[j];
+          ties.x += (a.x == gm.x); ties.y += (a.y == gm.y); ties.z += (a.z == gm.z); ties.w += (a.w == gm.w);
         }
       }
-#pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) {
-        ties.x += __shfl_xor(ties.x, off, 64); ties.y += __shfl_xor(ties.y, off, 64);
-        ties.z += __shfl_xor(ties.z, off, 64); ties.w += __shfl_xor(ties.w, off, 64);
-      }
-      if (rsub == 0) *reinterpret_cast<float4*>(L.red + wave * D + 4 * q) = ties;
+      ties.x += __shfl_xor(ties.x, 32, 64); ties.y += __shfl_xor(ties.y, 32, 64);
+      ties.z += __shfl_xor(ties.z, 32, 64); ties.w += __shfl_xor(ties.w, 32, 64);
+      if (lane < 32) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = ties;
       __syncthreads();
       float4 tot = f4_zero();
 #pragma unroll
-      for (int w = 0; w < SW; ++w) f4_add(tot, *reinterpret_cast<const float4*>(L.red + w * D + 4 * q));   // (counts: exact)
+      for (int w = 0; w < SW; ++w) f4_add(tot, *reinterpret_cast<const float4*>(L.red + w * D + 4 * c4));   // (counts: exact)
       share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
     }
-    // G of one row from what was loaded for it
-    auto grad_of = [&](const float4 d, const float4 a) {
-      float4 gq;
-      if (POOLG) {
-        gq = make_float4(dmean.x + (a.x == gmx.x ? share.x : 0.f), dmean.y + (a.y == gmx.y ? share.y : 0.f),
-                         dmean.z + (a.z == gmx.z ? share.z : 0.f), dmean.w + (a.w == gmx.w ? share.w : 0.f));
-      } else {
-        gq = d;
-      }
-      if (POOLG || TWO) {
-        if (act_here) {
+#pragma unroll
+    for (int j = 0; j < SEG_RPT; ++j) {
+      const int row = rg + 32 * j;
+      if (j * 32 < gi.n && row < gi.n) {
+        float4 a = f4_zero(), gq;
+        if (NEED_A) a = arows.v[j];
+        if (POOLG) {
+          gq = make_float4(dmn.x + (a.x == gm.x ? share.x : 0.f), dmn.y + (a.y == gm.y ? share.y : 0.f),
+                           dmn.z + (a.z == gm.z ? share.z : 0.f), dmn.w + (a.w == gm.w ? share.w : 0.f));
+        } else {
+          gq = drows.v[j];
+        }
+        if (NEED_A && act_here) {
           gq.x *= hcg_leaky_grad(a.x, slope); gq.y *= hcg_leaky_grad(a.y, slope);
           gq.z *= hcg_leaky_grad(a.z, slope); gq.w *= hcg_leaky_grad(a.w, slope);
         }
-      }
-      return gq;
-    };
-    for (int pb = 0; pb < gi.n; pb += RPP * INF) {
-      const int row0 = pb + wave * RPW + rsub;
-      SegRow rw[INF];
-      float4 ds[INF], as[INF], dv[INF][4], av[INF][4];
-#pragma unroll
-      for (int u = 0; u < INF; ++u) {
-        rw[u].set(L, row0 + u * RPP, gi.n);
-        if (!POOLG) ds[u] = *reinterpret_cast<const float4*>(Dg + (size_t)rw[u].row * D);
-        if (POOLG || TWO) as[u] = *reinterpret_cast<const float4*>(Ag + (size_t)rw[u].row * D);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!POOLG) dv[u][j] = *reinterpret_cast<const float4*>(Dg + (size_t)rw[u].c[j] * D);
-          if (POOLG || TWO) av[u][j] = *reinterpret_cast<const float4*>(Ag + (size_t)rw[u].c[j] * D);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < INF; ++u) {
-        const SegRow& w = rw[u];
-        const float di = L.dinv[w.row];
-        const float4 gs = grad_of(POOLG ? f4_zero() : ds[u], (POOLG || TWO) ? as[u] : f4_zero());
-        if (w.valid) f4_add(dbacc, gs);
-        float4 acc = f4_scale(di, gs);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (w.kb + j < w.ke) {
-            const float4 gj = grad_of(POOLG ? f4_zero() : dv[u][j], (POOLG || TWO) ? av[u][j] : f4_zero());
-            f4_add(acc, f4_scale(L.dinv[w.c[j]], gj));
-          }
-        }
-        for (int k = w.kb + 4; __any(k < w.ke); ++k) {
-          const int c = k < w.ke ? L.col[k] : w.row;
-          float4 d2 = f4_zero(), a2 = f4_zero();
-          if (!POOLG) d2 = *reinterpret_cast<const float4*>(Dg + (size_t)c * D);
-          if (POOLG || TWO) a2 = *reinterpret_cast<const float4*>(Ag + (size_t)c * D);
-          if (k < w.ke) f4_add(acc, f4_scale(L.dinv[c], grad_of(d2, a2)));
-        }
-        if (w.valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + w.row) * D + 4 * q) = f4_scale(di, acc);
+        f4_add(dbacc, gq);
+        *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], gq);
       }
     }
-    __syncthreads();   // the CSR (and the tie scratch) are free for the next graph
-  }
-  // ---- this workgroup's bias-gradient slab [D]: lanes of a column -> wave (xor shuffles) -> workgroup (LDS), fixed order
+    __syncthreads();
+    if (g + (int)gridDim.x < B) request(g + gridDim.x);   // the NEXT graph: in flight under this graph's sums
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-    dbacc.x += __shfl_xor(dbacc.x, off, 64); dbacc.y += __shfl_xor(dbacc.y, off, 64);
-    dbacc.z += __shfl_xor(dbacc.z, off, 64); dbacc.w += __shfl_xor(dbacc.w, off, 64);
+    for (int j = 0; j < SEG_RPT; ++j) {
+      if (j * 32 < gi.n) {
+        const int row = rg + 32 * j;
+        const bool valid = row < gi.n;
+        const int rr = valid ? row : gi.n - 1;
+        const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
+        const float4 acc = seg_row_sum(tile, L.col, rr, kb, ke, c4);
+        if (valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + row) * D + 4 * c4) = f4_scale(L.dinv[rr], acc);
+      }
+    }
+    __syncthreads();   // the tile, the CSR and the tie scratch are free for the next graph
   }
-  if (rsub == 0) *reinterpret_cast<float4*>(L.red + wave * D + 4 * q) = dbacc;
+  // ---- this workgroup's bias-gradient slab [D]: a wave's two row slots (xor 32) -> workgroup (LDS), fixed order
+  dbacc.x += __shfl_xor(dbacc.x, 32, 64); dbacc.y += __shfl_xor(dbacc.y, 32, 64);
+  dbacc.z += __shfl_xor(dbacc.z, 32, 64); dbacc.w += __shfl_xor(dbacc.w, 32, 64);
+  if (lane < 32) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = dbacc;
   __syncthreads();
   if (tid < D) {
     float s = 0.f;
@@ -655,22 +663,24 @@ int cu_count() {
     cus = v;
   return cus;
 }
-int seg_grid(int64_t B) {            // 8 workgroups of 4 waves per CU at most (32 waves: what <= 64 VGPRs admit)
-  int64_t g = (int64_t)cu_count() * 8;
+int seg_grid(int64_t B) {            // one workgroup of 16 waves per CU
+  int64_t g = (int64_t)cu_count();
   if (g > B) g = B;
   return g < 1 ? 1 : (int)g;
 }
 int mm_grid(int64_t N) {
-  int64_t g = hcg_cdiv(hcg_cdiv(N, 32), TW);
+  int64_t g = hcg_cdiv(hcg_cdiv(N, 32), TW / 2);
   if (g > cu_count()) g = cu_count();
   return g < 1 ? 1 : (int)g;
 }
 constexpr int DW_TILE = 64;
-int dw_grid(int64_t N) {             // two workgroups per CU; every workgroup leaves a slab, so no more than there are tiles
+int dw_grid(int64_t N) {             // one workgroup per CU (110 KB of operand images); every workgroup leaves a slab
   int64_t g = hcg_cdiv(N, DW_TILE);
-  if (g > 2 * (int64_t)cu_count()) g = 2 * (int64_t)cu_count();
+  if (g > (int64_t)cu_count()) g = (int64_t)cu_count();
   return g < 1 ? 1 : (int)g;
 }
+int seg_npad(int64_t max_nodes) { return (int)((max_nodes + 3) / 4 * 4); }
+size_t seg_tile_bytes(int npad) { return (size_t)npad * SEG_TS * sizeof(float); }
 int tall_fpad(int64_t F) { return F <= 32 ? 32 : (F <= 64 ? 64 : 128); }
 
 template <auto KFN>
@@ -736,11 +746,17 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
 #undef LAUNCH_MM_FWD
   HCG_CHECK_LAUNCH();
   const dim3 sgrid(seg_grid(B)), sblk(SN);
+  const int npad = seg_npad(max_nodes);
+  const size_t slds = seg_tile_bytes(npad);
+  {
+    hipError_t e = emb ? allow_lds<k_seg_fwd<true>>(seg_tile_bytes(SEG_MAX_NODES)) : allow_lds<k_seg_fwd<false>>(seg_tile_bytes(SEG_MAX_NODES));
+    if (e != hipSuccess) return hcg_hip_err(e);
+  }
   if (emb)
-    hipLaunchKernelGGL((k_seg_fwd<128, true>), sgrid, sblk, 0, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B,
+    hipLaunchKernelGGL((k_seg_fwd<true>), sgrid, sblk, slds, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,
                        slope, apply_act, out, emb, status);
   else
-    hipLaunchKernelGGL((k_seg_fwd<128, false>), sgrid, sblk, 0, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B,
+    hipLaunchKernelGGL((k_seg_fwd<false>), sgrid, sblk, slds, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,
                        slope, apply_act, out, emb, status);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
@@ -768,23 +784,30 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
   const TallWs ws = tall_carve(workspace, N, B, F, D);
   const int act_here = apply_act & 1;
   const dim3 sgrid(seg_grid(B)), sblk(SN);
+  const int npad = seg_npad(max_nodes);
+  const size_t slds = seg_tile_bytes(npad), slds_max = seg_tile_bytes(SEG_MAX_NODES);
+  {
+    hipError_t e = poolg ? allow_lds<k_seg_bwd<true, false>>(slds_max)
+                         : (act_here ? allow_lds<k_seg_bwd<false, true>>(slds_max) : allow_lds<k_seg_bwd<false, false>>(slds_max));
+    if (e != hipSuccess) return hcg_hip_err(e);
+  }
   if (poolg)
-    hipLaunchKernelGGL((k_seg_bwd<128, true, false>), sgrid, sblk, 0, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
-                       edge_ptr, (int)B, slope, act_here, ws.inter, ws.db_slabs, status);
+    hipLaunchKernelGGL((k_seg_bwd<true, false>), sgrid, sblk, slds, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
+                       edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);
   else if (act_here)
-    hipLaunchKernelGGL((k_seg_bwd<128, false, true>), sgrid, sblk, 0, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
-                       edge_ptr, (int)B, slope, act_here, ws.inter, ws.db_slabs, status);
+    hipLaunchKernelGGL((k_seg_bwd<false, true>), sgrid, sblk, slds, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
+                       edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);
   else
-    hipLaunchKernelGGL((k_seg_bwd<128, false, false>), sgrid, sblk, 0, stream, dout, demb, emb, (const float*)nullptr, edge_index,
-                       E, graph_ptr, edge_ptr, (int)B, slope, 0, ws.inter, ws.db_slabs, status);
+    hipLaunchKernelGGL((k_seg_bwd<false, false>), sgrid, sblk, slds, stream, dout, demb, emb, (const float*)nullptr, edge_index,
+                       E, graph_ptr, edge_ptr, (int)B, npad, slope, 0, ws.inter, ws.db_slabs, status);
   HCG_CHECK_LAUNCH();
   const int fp = tall_fpad(F);
   // dW slabs = dH^T x
   {
-    const dim3 grid(dw_grid(N)), blk(TT);
+    const dim3 grid(dw_grid(N)), blk(DWT);
 #define LAUNCH_DW(NBF)                                                                                               \
   do {                                                                                                               \
-    const size_t lds = (size_t)DW_TILE * ((128 + 4) + (NBF * 32 + 4)) * sizeof(float);                               \
+    const size_t lds = (size_t)3 * (128 + NBF * 32) * (DW_TILE + 8) * sizeof(short);                                 \
     hipError_t e = allow_lds<k_tall_dw<4, NBF>>(lds);                                                                \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                      \
     hipLaunchKernelGGL((k_tall_dw<4, NBF>), grid, blk, lds, stream, ws.inter, x, (int)F, ws.dw_slabs, (int)N);       \

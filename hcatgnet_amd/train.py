@@ -271,7 +271,7 @@ class FusedTrainStep:
             capN = max(N, int(cap["N"] * 1.25) if cap and cap["sig"] == sig else 0)
             capB = max(B, cap["B"] if cap and cap["sig"] == sig else 0)
             f32 = dict(dtype=torch.float32, device=dev)
-            hb = lib.hcg_head_workspace_bytes(capB)
+            hb = lib.hcg_head_workspace_bytes_d(capB, D if lib.hcg_head_supported(D, C) else 64)
             cap = {"sig": sig, "N": capN, "B": capB,
                    "acts": [torch.empty(capN, D, **f32) for _ in range(n_conv)],
                    "dacts": [torch.empty(capN, D, **f32) for _ in range(n_conv - 1)],
@@ -284,9 +284,17 @@ class FusedTrainStep:
         if b is None:
             b = {"acts": [t[:N] for t in cap["acts"]], "dacts": [t[:N] for t in cap["dacts"]], "emb": cap["emb"][:B],
                  "demb": cap["demb"][:B], "z": cap["z"][:B], "out": cap["out"][:B], "loss": cap["loss"],
-                 "ws_head": cap["ws_head"], "ws_head_bytes": lib.hcg_head_workspace_bytes(B), "ws": cap["ws"]}
+                 "ws_head": cap["ws_head"], "ws_head_bytes": lib.hcg_head_workspace_bytes_d(B, D if lib.hcg_head_supported(D, C) else 64), "ws": cap["ws"]}
             self._bufs = {"cap": cap, key: b}          # views of the current shape (one live shape at a time)
         return b
+
+    def _tall_ws(self, bufs, l, N, B, F, D, dev):
+        """Workspace of layer l's wide-layer kernels (H / dH round trip + gradient slabs): forward and backward share it."""
+        wsb = _lib.load().hcg_tall_workspace_bytes(N, B, F, D)
+        ws = bufs["ws"].get(("tall", l))
+        if ws is None or ws.numel() < wsb:
+            ws = bufs["ws"][("tall", l)] = torch.empty(int(wsb * 1.25), dtype=torch.uint8, device=dev)
+        return ws, wsb
 
     def _head_buffers(self, bufs, B, D, C, dev):
         """Scratch of the any-shape head (five launches): allocated once per capacity."""
@@ -352,6 +360,9 @@ class FusedTrainStep:
         for c, gpt in zip(convs, gpts):
             if gpt <= 0 and not HF.mid_supported(plan, c.in_channels, c.out_channels):
                 raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused kernels")
+        # 128-wide layers over large graphs: dense row-streaming transform + per-graph segmented sum (csrc/tall.hip)
+        tall = [gpt <= 0 and getattr(c, "family", "auto") != "mid" and HF.tall_supported(plan, c.in_channels, c.out_channels)
+                for c, gpt in zip(convs, gpts)]
         mxn, mxe = plan.max_nodes, plan.max_edges
         bufs = self._buffers((N, B, F, plan.E), N, B, F, D, C, n_conv, dev)
         n_small = self._size_groups(batch, plan, convs, D, C, n_conv)
@@ -393,6 +404,12 @@ class FusedTrainStep:
                                                  p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]), pe,
                                                  p(plan.status), stream)
                     _lib.check(rc, "hcg_fused_layer_fwd")
+                elif tall[l]:
+                    ws, wsb = self._tall_ws(bufs, l, N, B, h.shape[1], D, dev)
+                    rc = lib.hcg_tall_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                                p(plan.edge_ptr), N, B, h.shape[1], D, mxn, mxe, slope, 1, p(acts[l]), pe,
+                                                p(plan.status), p(ws), wsb, stream)
+                    _lib.check(rc, "hcg_tall_layer_fwd")
                 else:
                     rc = lib.hcg_mid_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                                p(plan.edge_ptr), N, B, h.shape[1], D, mxn, mxe, slope, 1, p(acts[l]), pe,
@@ -432,8 +449,8 @@ class FusedTrainStep:
             if _forward_only:
                 self.last_out = bufs["out"]
                 return bufs["loss"][0]
-            _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
-                                               g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
+            _lib.check(lib.hcg_head_reduce_job_d(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, D, C, g(l0.weight), g(l0.bias),
+                                                 g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job_d")
             njobs = 1
         else:
             # any-shape head (embedding_dim 128): Linear + LeakyReLU, Linear, loss with its gradient, two Linear backwards
@@ -461,9 +478,10 @@ class FusedTrainStep:
             Fl = inp.shape[1]
             dx = bufs["dacts"][l - 1] if l > 0 else None
             small = gpts[l] > 0
-            wsb = lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l]) if small else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)
+            wsb = (lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l]) if small else
+                   (0 if tall[l] else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)))
             ws = bufs["ws"].get(l)
-            if ws is None or ws.numel() < wsb:
+            if (ws is None or ws.numel() < wsb) and wsb > 0:
                 ws = torch.empty(int(wsb * 1.25), dtype=torch.uint8, device=dev)
                 bufs["ws"][l] = ws
             last = l == n_conv - 1
@@ -485,6 +503,19 @@ class FusedTrainStep:
                 _lib.check(rc, "hcg_fused_layer_bwd")
                 _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
                                                     g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
+            elif tall[l]:
+                # (never premasks: the layer below reads its own output row-contiguous instead -- the premask would be 4-byte
+                #  strided loads in the dense kernel's epilogue for the same bytes)
+                act = 0 if premasked else 1
+                premasked = False
+                tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, dev)
+                rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
+                                            plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, act,
+                                            p(dx), p(plan.status), p(tws), twsb, stream)
+                _lib.check(rc, "hcg_tall_layer_bwd")
+                _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, g(convs[l].lin.weight), g(convs[l].bias),
+                                                    jaddr + njobs * jb), "hcg_tall_reduce_jobs")
+                njobs += 1                          # (two jobs: dW, db)
             else:
                 act = 0 if premasked else 1
                 premasked = self.PREMASK and l > 0

@@ -290,12 +290,14 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
  *                        after that the words must be re-zeroed before they are used again
  *   step_counter       : nullable; one int32 device word incremented by 1 per launch -- the number of the training
  *                        step, read later in the same step by hcg_reduce_slabs_adam
- * y is [B,C] like out.  D = 64, C <= 8 (hcg_head_supported). */
+ * y is [B,C] like out.  D = 64 or 128 (8 waves per workgroup, W0 fragments from L2 instead of LDS), C <= 8
+ * (hcg_head_supported). */
 #define HCG_HEAD_SYNC_WORDS 520
 #define HCG_HEAD_ERR_TIMEOUT 1 /* bit of sync[1] */
 #define HCG_HEAD_SSE 2         /* value of `rmse` for hcg_head_fwd_bwd_ex: see there */
 int hcg_head_supported(int64_t D, int64_t C);
-size_t hcg_head_workspace_bytes(int64_t B);
+size_t hcg_head_workspace_bytes(int64_t B);                 /* D = 64 */
+size_t hcg_head_workspace_bytes_d(int64_t B, int64_t D);    /* D = 64 or 128 */
 int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
                      const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
                      float* z, float* out, float* loss, float* demb,
@@ -359,6 +361,8 @@ int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t 
                          float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
+int hcg_head_reduce_job_d(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C,
+                          float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 /* `more` (same slab geometry and destinations, slabs directly behind `job`'s) becomes part of `job`: one fixed-order sum */
 int hcg_reduce_job_append(hcg_reduce_job* job_host, const hcg_reduce_job* more_host);
 int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);

@@ -15,30 +15,33 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.mark.parametrize("B,C,rmse", [(1, 1, 1), (31, 1, 1), (32, 3, 1), (4096, 1, 1), (4096, 8, 0), (9000, 2, 1)])
-def test_head_forward_loss_backward_one_launch(H, B, C, rmse):
+@pytest.mark.parametrize("B,C,rmse,D", [(1, 1, 1, 64), (31, 1, 1, 64), (32, 3, 1, 64), (4096, 1, 1, 64), (4096, 8, 0, 64), (9000, 2, 1, 64),
+                                        (1, 1, 1, 128), (33, 3, 1, 128), (1024, 1, 1, 128), (1024, 8, 0, 128), (9000, 2, 1, 128)])
+def test_head_forward_loss_backward_one_launch(H, B, C, rmse, D):
     """out / loss / demb / weight gradients of hcg_head_fwd_bwd vs torch fp64 autograd of
-    sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes workgroups loop over several tiles."""
+    sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes workgroups loop over several tiles; D = 128 is the
+    8-wave form with W0 read from L2 (BASELINE configs[4])."""
     from hcatgnet_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(7 * B + C)
-    emb = torch.randn(B, 128, generator=g); W0 = torch.randn(64, 128, generator=g) * 0.1; b0 = torch.randn(64, generator=g) * 0.1
-    W1 = torch.randn(C, 64, generator=g) * 0.1; b1 = torch.randn(C, generator=g) * 0.1; y = torch.randn(B, C, generator=g) * 3
+    emb = torch.randn(B, 2 * D, generator=g); W0 = torch.randn(D, 2 * D, generator=g) * 0.1; b0 = torch.randn(D, generator=g) * 0.1
+    W1 = torch.randn(C, D, generator=g) * 0.1; b1 = torch.randn(C, generator=g) * 0.1; y = torch.randn(B, C, generator=g) * 3
     d = [t.cuda().contiguous() for t in (emb, y, W0, b0, W1, b1)]
-    z = torch.empty(B, 64, device="cuda"); out = torch.empty(B, C, device="cuda"); loss = torch.empty(2, device="cuda")
-    demb = torch.empty(B, 128, device="cuda")
-    wsb = lib.hcg_head_workspace_bytes(B)
+    z = torch.empty(B, D, device="cuda"); out = torch.empty(B, C, device="cuda"); loss = torch.empty(2, device="cuda")
+    demb = torch.empty(B, 2 * D, device="cuda")
+    wsb = lib.hcg_head_workspace_bytes_d(B, D)
+    assert D != 64 or wsb == lib.hcg_head_workspace_bytes(B)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
     sync = torch.zeros(_lib.HCG_HEAD_SYNC_WORDS, dtype=torch.int32, device="cuda")    # this caller's own exchange words
     grads = [torch.empty_like(t) for t in d[2:]]
     p = _lib.ptr
     for rep in range(2):        # twice: the exchange words must be reusable launch after launch
-        rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, 64, C, 0.01, rmse, p(z), p(out),
+        rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, D, C, 0.01, rmse, p(z), p(out),
                                   p(loss), p(demb), p(ws), wsb, p(sync), None, _lib.stream_ptr())
         _lib.check(rc, "hcg_head_fwd_bwd")
         job = ctypes.create_string_buffer(lib.hcg_reduce_job_bytes())
-        _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
-                                           ctypes.addressof(job)), "hcg_head_reduce_job")
+        _lib.check(lib.hcg_head_reduce_job_d(p(ws), wsb, B, D, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
+                                             ctypes.addressof(job)), "hcg_head_reduce_job_d")
         _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(job), 1, _lib.stream_ptr()), "hcg_reduce_slabs")
         torch.cuda.synchronize()
         assert int(sync[0]) >= rep + 1        # generation advanced once per launch

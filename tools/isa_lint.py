@@ -32,7 +32,7 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 REQUIRED = 19
-MFMA_FILES = ("fused.o", "mid.o", "wave.o", "head.o")
+MFMA_FILES = ("fused.o", "mid.o", "wave.o", "tall.o", "head.o")
 
 _REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 _NOP = re.compile(r"^s_nop\s+(\d+)")
