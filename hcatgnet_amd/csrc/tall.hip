@@ -292,6 +292,12 @@ __global__ __launch_bounds__(DWT, 2) void k_tall_dw(const float* __restrict__ Z,
 // rows scaled by dinv into the tile, wavefront segmented sum out of LDS (32 lanes x float4 per row, 32 rows per pass),
 // epilogue, row-contiguous 512-byte stores.  Gathering the neighbour rows from L2 instead (one workgroup of 4 waves per
 // graph, 4 workgroups per CU) was measured first: 59-93 us per launch on C5, every pass a dependent L2 round trip.
+#ifdef HCG_SEG_STAMP      // tools/probe_seg.hip: s_memtime stamps of the per-graph phases
+__device__ unsigned long long g_seg_stamp[8 * 8 * 8];      // [block < 8][graph iteration < 8][phase < 8]
+#define SSTAMP(it, ph) do { if (threadIdx.x == 0 && blockIdx.x < 8 && (it) < 8) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); g_seg_stamp[(blockIdx.x * 8 + (it)) * 8 + (ph)] = _t; } } while (0)
+#else
+#define SSTAMP(it, ph) do { } while (0)
+#endif
 constexpr int SN = 1024, SW = SN / 64;
 constexpr int SEG_MAX_NODES = 224;    // (same limits as mid.hip: every batch one family takes, the other takes too)
 constexpr int SEG_MAX_EDGES = 1024;   // one edge per thread
@@ -299,14 +305,16 @@ constexpr int SEG_D = 128, SEG_TS = SEG_D + 4;
 constexpr int SEG_RPT = SEG_MAX_NODES * (SEG_D / 4) / SN;      // float4 per thread to hold one graph's rows (7)
 static_assert(SEG_MAX_EDGES == SN && SEG_MAX_NODES * (SEG_D / 4) % SN == 0, "thread maps");
 
-struct SegLds {
+template <bool WITH_RED>
+struct SegLdsT {
   int rowptr[SEG_MAX_NODES + 4];
   int cursor[SEG_MAX_NODES];
   int degin[SEG_MAX_NODES];
   float dinv[SEG_MAX_NODES];
   unsigned short col[SEG_MAX_EDGES];
-  float red[SW * 2 * SEG_D];
+  float red[WITH_RED ? SW * 2 * SEG_D : 4];       // combine scratch (the fused forward keeps it in its weight-chunk buffers)
 };
+using SegLds = SegLdsT<true>;
 
 struct SegGraph { int nbase, n, ebase, ne, nld; };
 
@@ -353,11 +361,27 @@ struct SegRows {
   }
 };
 
+// the same share of a graph's rows of a [N, F] tensor, F <= 128 a multiple of 4 (columns past F: clamped loads, zeroed by the user)
+struct SegRowsF {
+  float4 v[SEG_RPT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int F, const SegGraph& gi) {
+    const int rg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+    const float* base = src + (size_t)gi.nld * F + (4 * c4 < F ? 4 * c4 : F - 4);
+#pragma unroll
+    for (int j = 0; j < SEG_RPT; ++j) {
+      if (j * 32 < gi.n) {
+        const int row = rg + 32 * j;
+        v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * F);
+      }
+    }
+  }
+};
+
 // The algorithm of mid.hip's build_csr for 1024 threads (one edge each): in-degree -> dinv = (1 + deg_in)^-1/2, counting
 // sort into rows (BY_SRC: rows = sources = the transpose), explicit (i, i) edges collapse into the unit self loop, every
 // row sorted by id.  Ends with a barrier.
-template <bool BY_SRC>
-__device__ __forceinline__ void seg_build_csr(SegLds& L, const SegGraph& gi, const SegEdge& er, int32_t* status) {
+template <bool BY_SRC, class LDS>
+__device__ __forceinline__ void seg_build_csr(LDS& L, const SegGraph& gi, const SegEdge& er, int32_t* status) {
   const int tid = threadIdx.x;
   const int n = gi.n;
   if (tid < n) { L.cursor[tid] = 0; if (BY_SRC) L.degin[tid] = 0; }
@@ -462,41 +486,161 @@ __device__ __forceinline__ float4 seg_row_sum(const float* t, const unsigned sho
 }
 
 // ---- forward: H' = dinv . H;  out_i = LeakyReLU(dinv_i (H'_i + sum_k H'_k) + b), [max | mean] pooling
-template <bool POOL>
-__global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ H, const float* __restrict__ bias,
+// Pre-split image of a layer's weight in global memory for the fused forward: three bf16 planes of [128][KP] (zero past F),
+// W = p1 + p2 + p3.  One tiny launch per layer forward; every workgroup then streams 16-column chunks of it through LDS.
+__global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ W, int D, int F, int KP, short* __restrict__ img) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 128 * KP) return;
+  const int n = idx / KP, k = idx - n * KP;
+  const float x = (n < D && k < F) ? W[n * F + k] : 0.f;
+  const unsigned u1 = pk_bf16(x, 0.f) & 0xffffu;
+  const float r1 = x - __uint_as_float(u1 << 16);
+  const unsigned u2 = pk_bf16(r1, 0.f) & 0xffffu;
+  const float r2 = r1 - __uint_as_float(u2 << 16);
+  const unsigned u3 = pk_bf16(r2, 0.f) & 0xffffu;
+  // chunk-major: [k / 16][plane][row n][k % 16] -- a workgroup's per-k-step copy is then ONE contiguous 12 KB block (row-major
+  // planes made it 384 pieces of 32 bytes, a 128-byte L2 line each: 256 CUs pulling 4x the bytes through the same L2 channels
+  // in step was ~1500 of the k-step's 4200 cycles)
+  short* dst = img + (size_t)(k >> 4) * (3 * 128 * 16) + n * 16 + (k & 15);
+  dst[0] = (short)u1;
+  dst[128 * 16] = (short)u2;
+  dst[2 * 128 * 16] = (short)u3;
+}
+
+constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (three planes, unpadded rows, XOR-swizzled halves)
+
+// GEMM = false: H = x W^T comes from k_tall_mm (`src` = H).  GEMM = true (`src` = x [N, F], `gW` = k_split_weight's image):
+// the graph's H tile is produced here, on the matrix cores, straight into LDS -- H never exists in global memory (420 MB
+// less traffic per C5 layer pair).  The 98 KB weight image cannot sit in LDS beside the 106-118 KB tile, so it streams: one
+// 16-column chunk (12 KB, double buffered) per k-step, requested from L2 two k-steps ahead; wave (row block, column half)
+// keeps 2 accumulator blocks; the A fragments come from the graph's x rows staged through the same LDS tile.
+// Measured on C5 (tools/probe_seg.hip, per 200-node graph): CSR 2.3 us, MFMA phase 14 us (its MFMAs alone: 5.9 us -- the
+// barrier per k-step keeps all 16 waves in the same phase, so splitting, LDS traffic and MFMAs add up instead of
+// overlapping), sums + stores 9 us: 110 us per layer against 119 us for k_tall_mm + the unfused form, with half the HBM
+// traffic.  One workgroup per CU (the tile) is what bounds it; a second one does not fit 160 KB.
+template <bool POOL, bool GEMM>
+__global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
+                                                   const float* __restrict__ bias,
                                                    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
                                                    const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int apply_act,
                                                    float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
   constexpr int D = SEG_D;
-  __shared__ SegLds L;
+  __shared__ SegLdsT<!GEMM> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);          // [npad][SEG_TS]
+  short* wl = reinterpret_cast<short*>(tile + (size_t)npad * SEG_TS);     // GEMM: two weight chunks (2 x 12 KB), later the combine scratch
+  float* red = GEMM ? reinterpret_cast<float*>(wl) : L.red;
+  const float* H = src;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c4 = tid & 31, rg = tid >> 5;
+  const int r = lane & 31, h = lane >> 5;
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * c4);
 
   SegGraph gnext;
   SegEdge er;
   SegRows rows;
+  SegRowsF xrows;
   if ((int)blockIdx.x < B) {
     gnext = seg_graph(blockIdx.x, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
-    rows.load(H, gnext);
+    if (!GEMM) rows.load(H, gnext);
+    else xrows.load(src, F, gnext);
   }
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+  // (Per graph on C5, s_memtime stamps of tools/probe_seg.hip: CSR build 1.3 us, tile write 0.85 us, sums + stores 10 us -- the
+  //  last phase is the memory system draining 102 KB of loads and 102 KB of stores per CU at ~20 KB/us, i.e. ~5 TB/s over the
+  //  chip.  Requesting the next graph's rows one phase earlier, from a second register slot, moved that wait into the CSR
+  //  build -- the load issue blocks behind the previous graph's stores -- and was 7 % slower overall.)
+  [[maybe_unused]] int sit = 0;
+  for (int g = blockIdx.x; g < B; g += gridDim.x, ++sit) {
     const SegGraph gi = gnext;
+    SSTAMP(sit, 0);
     seg_build_csr<false>(L, gi, er, status);
+    SSTAMP(sit, 1);
+    if (!GEMM) {
 #pragma unroll
-    for (int j = 0; j < SEG_RPT; ++j) {
-      const int row = rg + 32 * j;
-      if (j * 32 < gi.n && row < gi.n) *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], rows.v[j]);
+      for (int j = 0; j < SEG_RPT; ++j) {
+        const int row = rg + 32 * j;
+        if (j * 32 < gi.n && row < gi.n) *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], rows.v[j]);
+      }
+    } else {
+      // ---- H' = dinv . (x W^T) -> tile.  The graph's x rows (requested a graph ahead, row-contiguous) go through the SAME
+      // LDS tile first: the A fragments are then conflict-free ds_read_b128 instead of 16-byte global loads of 32 different
+      // rows per instruction (measured: those loads were ~10 k of the phase's 33 k cycles on C5, and both waves of a row
+      // block issued them).  wave = (row block, column half); 14 of 16 waves busy on a 200-node graph.
+      const int rbw = wave >> 1, ch = wave & 1;
+      const bool active = rbw * 32 < gi.n;                          // wave-uniform
+      const int KS = KP / 16;
+#pragma unroll
+      for (int j = 0; j < SEG_RPT; ++j) {
+        const int row = rg + 32 * j;
+        if (j * 32 < gi.n && row < gi.n)
+          *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = 4 * c4 < F ? xrows.v[j] : f4_zero();
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+      // the chunk copy: threads 0 .. 767 move 16 bytes each: plane wp, image row wn, half whalf of the 16 columns
+      const int wp = tid >> 8, wn = (tid & 255) >> 1, whalf = tid & 1;
+      const bool wcopy = tid < 768;
+      const short* wsrc = gW + (wcopy ? tid : 0) * 8;                // (chunk-major image: thread t moves bytes [16 t, 16 t + 16) of a chunk)
+      short* wdst = wl + (wp * 128 + wn) * 16 + ((whalf ^ ((wn >> 3) & 1)) * 8);
+      // weight chunks are requested TWO k-steps ahead (one k-step of MFMAs is ~0.6 us, an L2 round trip under load ~1 us)
+      u32x4 wreg = {0u, 0u, 0u, 0u}, wreg2 = {0u, 0u, 0u, 0u};
+      if (wcopy) wreg = *reinterpret_cast<const u32x4*>(wsrc);
+      if (KS > 1 && wcopy) wreg2 = *reinterpret_cast<const u32x4*>(wsrc + WCH);
+      if (wcopy) *reinterpret_cast<u32x4*>(wdst) = wreg;           // chunk 0 -> buffer 0 (free since the previous graph's last barrier)
+      wreg = wreg2;
+      __syncthreads();                                             // x tile + chunk 0 visible
+      const float* arow = tile + (rbw * 32 + r) * SEG_TS + 8 * h;   // (rows past the graph: stale LDS, they only feed unused output rows)
+      auto split_a = [&](int ks) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        return split3(av);
+      };
+      // the A fragment of k-step ks + 1 is read and split in the shadow of k-step ks's MFMAs: it does not depend on the
+      // barrier (the x tile is complete), and right behind a barrier all 16 waves would otherwise run their ~50 VALU
+      // instructions of splitting at the same time, with the matrix pipes idle
+      Split3 As = split_a(0);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS && wcopy) wreg2 = *reinterpret_cast<const u32x4*>(wsrc + (size_t)(ks + 2) * WCH);
+        if (active) {
+          const short* wb = wl + (ks & 1) * WCH + (ch * 64 + r) * 16 + ((h ^ ((r >> 3) & 1)) * 8);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const short* w0 = wb + nb * 32 * 16;
+            mfma_split(acc[nb], As, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + 128 * 16),
+                       *reinterpret_cast<const bf16x8*>(w0 + 2 * 128 * 16));
+          }
+          if (ks + 1 < KS) As = split_a(ks + 1);
+        }
+        if (ks + 1 < KS && wcopy) *reinterpret_cast<u32x4*>(wdst + ((ks + 1) & 1) * WCH) = wreg;   // (that buffer's readers passed the last barrier)
+        __syncthreads();
+        wreg = wreg2;
+      }
+      // (the loop's last barrier: every A fragment has been read -- the accumulators may now overwrite the tile)
+      mfma_results_fence(acc[0], acc[1]);
+      if (active) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rbw * 32 + krow(i, h);
+            if (row < gi.n) tile[row * SEG_TS + (ch * 2 + nb) * 32 + r] = acc[nb][i] * L.dinv[row];
+          }
+      }
     }
+    SSTAMP(sit, 2);
     __syncthreads();
+    SSTAMP(sit, 3);
     if (g + (int)gridDim.x < B) {                     // the NEXT graph's scalars, edge and rows: in flight under this graph's sums
       gnext = seg_graph(g + gridDim.x, graph_ptr, edge_ptr, npad, status);
       er.load(gnext, ei, E);
-      rows.load(H, gnext);
-    }
+      if (!GEMM) rows.load(H, gnext);
+      else xrows.load(src, F, gnext);                 // (requested before the MFMA loop instead: the same ~5 us of exposed load
+    }                                                 //  time per graph moves into that phase -- measured equal, more spills)
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = f4_zero();
 #pragma unroll
     for (int j = 0; j < SEG_RPT; ++j) {
@@ -524,23 +668,25 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ H, 
       psum.x += __shfl_xor(psum.x, 32, 64); psum.y += __shfl_xor(psum.y, 32, 64);
       psum.z += __shfl_xor(psum.z, 32, 64); psum.w += __shfl_xor(psum.w, 32, 64);
       if (lane < 32) {
-        *reinterpret_cast<float4*>(L.red + wave * 2 * D + 4 * c4) = pmax;
-        *reinterpret_cast<float4*>(L.red + wave * 2 * D + D + 4 * c4) = psum;
+        *reinterpret_cast<float4*>(red + wave * 2 * D + 4 * c4) = pmax;
+        *reinterpret_cast<float4*>(red + wave * 2 * D + D + 4 * c4) = psum;
       }
       __syncthreads();
       if (tid < D) {
         float m = -INFINITY, s = 0.f;
 #pragma unroll
         for (int w = 0; w < SW; ++w) {
-          m = fmaxf(m, L.red[w * 2 * D + tid]);
-          s += L.red[w * 2 * D + D + tid];
+          m = fmaxf(m, red[w * 2 * D + tid]);
+          s += red[w * 2 * D + D + tid];
         }
         if (gi.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * D + tid] = m;
         emb[(size_t)g * 2 * D + D + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
       }
     }
+    SSTAMP(sit, 4);
     __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
+    SSTAMP(sit, 5);
   }
 }
 
@@ -733,6 +879,29 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const TallWs ws = tall_carve(workspace, N, B, F, D);
   const int fp = tall_fpad(F);
+  const dim3 sgrid(seg_grid(B)), sblk(SN);
+  const int npad = seg_npad(max_nodes);
+  const size_t slds = seg_tile_bytes(npad), slds_max = seg_tile_bytes(SEG_MAX_NODES);
+  const size_t wbuf = (size_t)2 * WCH * sizeof(short);
+  // fused form: x -> (MFMA) -> H tile in LDS -> sums.  Needs the tile, two weight chunks and the CSR in 160 KB of LDS
+  const bool fuse = sizeof(SegLdsT<false>) + slds + wbuf <= 160 * 1024 - 512;
+  if (fuse) {
+    const int KP = (int)((F + 15) / 16 * 16);
+    short* img = reinterpret_cast<short*>(ws.inter);                 // 3 x 128 x KP bf16 (the H buffer is not needed)
+    hipLaunchKernelGGL(k_split_weight, dim3((128 * KP + 255) / 256), dim3(256), 0, stream, W, (int)D, (int)F, KP, img);
+    HCG_CHECK_LAUNCH();
+    const size_t lds = slds + wbuf, lds_max = 160 * 1024 - 512 - sizeof(SegLdsT<false>);
+    hipError_t e = emb ? allow_lds<k_seg_fwd<true, true>>(lds_max) : allow_lds<k_seg_fwd<false, true>>(lds_max);
+    if (e != hipSuccess) return hcg_hip_err(e);
+    if (emb)
+      hipLaunchKernelGGL((k_seg_fwd<true, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
+                         graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
+    else
+      hipLaunchKernelGGL((k_seg_fwd<false, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
+                         graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
+    HCG_CHECK_LAUNCH();
+    return HCG_OK;
+  }
   const dim3 grid(mm_grid(N)), blk(TT);
 #define LAUNCH_MM_FWD(KP)                                                                                                  \
   do {                                                                                                                     \
@@ -745,19 +914,16 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
   if (fp == 32) LAUNCH_MM_FWD(32); else if (fp == 64) LAUNCH_MM_FWD(64); else LAUNCH_MM_FWD(128);
 #undef LAUNCH_MM_FWD
   HCG_CHECK_LAUNCH();
-  const dim3 sgrid(seg_grid(B)), sblk(SN);
-  const int npad = seg_npad(max_nodes);
-  const size_t slds = seg_tile_bytes(npad);
   {
-    hipError_t e = emb ? allow_lds<k_seg_fwd<true>>(seg_tile_bytes(SEG_MAX_NODES)) : allow_lds<k_seg_fwd<false>>(seg_tile_bytes(SEG_MAX_NODES));
+    hipError_t e = emb ? allow_lds<k_seg_fwd<true, false>>(slds_max) : allow_lds<k_seg_fwd<false, false>>(slds_max);
     if (e != hipSuccess) return hcg_hip_err(e);
   }
   if (emb)
-    hipLaunchKernelGGL((k_seg_fwd<true>), sgrid, sblk, slds, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,
-                       slope, apply_act, out, emb, status);
+    hipLaunchKernelGGL((k_seg_fwd<true, false>), sgrid, sblk, slds, stream, (const float*)ws.inter, (int)D, 0, (const short*)nullptr, b,
+                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
   else
-    hipLaunchKernelGGL((k_seg_fwd<false>), sgrid, sblk, slds, stream, ws.inter, b, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,
-                       slope, apply_act, out, emb, status);
+    hipLaunchKernelGGL((k_seg_fwd<false, false>), sgrid, sblk, slds, stream, (const float*)ws.inter, (int)D, 0, (const short*)nullptr, b,
+                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
