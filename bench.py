@@ -530,8 +530,11 @@ def main():
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
     mid = r0.sb.max_nodes > 32
-    entry = args.roofline_entry or (("hcg_mid_layer_fwd" if mid else "hcg_fused_stack2_fwd") if args.forward_only
-                                    else ("hcg_mid_layer_bwd" if mid else "hcg_fused_layer_bwd"))
+    # 128-wide layers over large graphs run through csrc/tall.hip (one entry point = up to three launches)
+    tall = mid and bool(lib.hcg_tall_supported(D, D, r0.sb.max_nodes, r0.sb.max_edges))
+    fam = "hcg_tall" if tall else "hcg_mid"
+    entry = args.roofline_entry or ((f"{fam}_layer_fwd" if mid else "hcg_fused_stack2_fwd") if args.forward_only
+                                    else (f"{fam}_layer_bwd" if mid else "hcg_fused_layer_bwd"))
     timer = EntryTimer(lib, entry)
     timer.install()
     timer.enabled = True
@@ -597,6 +600,8 @@ def main():
                    "hcg_fused_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
                    "hcg_mid_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
                    "hcg_mid_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
+                   "hcg_tall_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
+                   "hcg_tall_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
                    "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
                    "hcg_fused_stack2_fwd": bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]}.get(entry, float("nan"))
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
@@ -617,6 +622,13 @@ def main():
             traffic = sum(vals) / len(vals) if vals else None
             if traffic is not None and entry.startswith("hcg_mid_") and D > 64:
                 traffic *= D // 64            # one call of the entry point = one kernel launch per 64-column half
+            if entry.startswith("hcg_tall_layer_"):
+                # one call = several launches (bwd: k_seg_bwd + k_tall_dw + k_tall_mm; fwd: k_split_weight + k_seg_fwd):
+                # bytes of every launch of those kernels in the profiled run / calls of the entry point in it (2 per step)
+                fams = ("k_seg_bwd", "k_tall_dw", "k_tall_mm") if entry.endswith("bwd") else ("k_seg_fwd", "k_split_weight")
+                tot = sum(v["hbm_bytes"] * v["launches"] for k, v in tj.items() if k.startswith(fams))
+                calls = sum(v["launches"] for k, v in tj.items() if k.startswith("k_seg_bwd" if entry.endswith("bwd") else "k_seg_fwd"))
+                traffic = tot / calls if calls else None
             traffic_src = "profiles/traffic_latest.json: builder-run rocprofv3 PMC passes of this command, not measured in this run"
         except (OSError, ValueError, KeyError, AttributeError):
             traffic = None

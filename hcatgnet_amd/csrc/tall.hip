@@ -517,7 +517,11 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // Measured on C5 (tools/probe_seg.hip, per 200-node graph): CSR 2.3 us, MFMA phase 14 us (its MFMAs alone: 5.9 us -- the
 // barrier per k-step keeps all 16 waves in the same phase, so splitting, LDS traffic and MFMAs add up instead of
 // overlapping), sums + stores 9 us: 110 us per layer against 119 us for k_tall_mm + the unfused form, with half the HBM
-// traffic.  One workgroup per CU (the tile) is what bounds it; a second one does not fit 160 KB.
+// traffic.  What bounds the MFMA phase is vector issue, not the barriers or the matrix pipes: four waves per SIMD each spend
+// ~100 vector instructions per k-step (their own split of the A fragment, addressing, LDS reads) -- 32-column chunks (half
+// the barriers) changed nothing; one wave per row block with all four column blocks (one split per 24 MFMAs) needs 64
+// accumulator registers and spilled 145 at the 128 the 16-wave workgroup allows (1.5x slower).  An 8-wave form of these
+// kernels (256 registers) is the open lead; a second workgroup per CU does not fit 160 KB beside the tile.
 template <bool POOL, bool GEMM>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,

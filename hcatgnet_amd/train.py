@@ -112,7 +112,7 @@ class FusedTrainStep:
         if model.n_convolutions + 1 > 4:
             return "more than 3 conv layers"
         lib = _lib.load()
-        # (heads the one-launch kernel does not cover -- embedding_dim 128 -- run as five launches of the any-shape
+        # (heads the one-launch kernel does not cover -- widths other than 64 / 128 -- run as five launches of the any-shape
         #  kernels inside the same no-autograd step)
         if type(model.loss).__name__ != "MSELoss":
             return "loss other than MSE"
@@ -453,7 +453,7 @@ class FusedTrainStep:
                                                  g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job_d")
             njobs = 1
         else:
-            # any-shape head (embedding_dim 128): Linear + LeakyReLU, Linear, loss with its gradient, two Linear backwards
+            # any-shape head (widths other than 64 / 128): Linear + LeakyReLU, Linear, loss with its gradient, two Linear backwards
             # that write straight into the flat gradient buffer (reference model/gcn.py:70-71, utils/utils_model.py:64-65)
             hb = self._head_buffers(bufs, B, D, C, dev)
             z, out = bufs["z"], bufs["out"]
