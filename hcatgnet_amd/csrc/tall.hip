@@ -520,8 +520,12 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // traffic.  What bounds the MFMA phase is vector issue, not the barriers or the matrix pipes: four waves per SIMD each spend
 // ~100 vector instructions per k-step (their own split of the A fragment, addressing, LDS reads) -- 32-column chunks (half
 // the barriers) changed nothing; one wave per row block with all four column blocks (one split per 24 MFMAs) needs 64
-// accumulator registers and spilled 145 at the 128 the 16-wave workgroup allows (1.5x slower).  An 8-wave form of these
-// kernels (256 registers) is the open lead; a second workgroup per CU does not fit 160 KB beside the tile.
+// accumulator registers and spilled 145 at the 128 the 16-wave workgroup allows (1.5x slower); the same mapping as an 8-wave
+// kernel with 256 registers (no spills, 7 MFMA waves) measured 120 us per layer: its MFMA phase still took 16 us per graph
+// (9.5 us with the MFMAs removed, 14.5 us with the weight loads removed), its sums' phase 12 us on 8 waves -- with two waves
+// per SIMD the LDS latencies, the split and the MFMA chains of a k-step run in series.  A second workgroup per CU does not
+// fit 160 KB beside the tile.  PMC (profiles/r02_d_traffic_C5.txt): 307 MB per launch for 210 MB of operands -- the 9-33
+// spilled registers of this variant and the weight chunks that miss L2.
 template <bool POOL, bool GEMM>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,
