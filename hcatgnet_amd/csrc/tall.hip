@@ -164,14 +164,18 @@ constexpr int DWW = 8, DWT = DWW * 64;
 // columns of one 16-block: 36-dword stride) are conflict-free either way
 __device__ __forceinline__ constexpr int dw_oct(int c, int o) { return o ^ ((c >> 4) & 3); }
 
-template <int DB, int NBF>
-__global__ __launch_bounds__(DWT, 2) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
-                                                    float* __restrict__ slabs, int N) {
+// XVEC = false: X rows are not 16-byte aligned (F no multiple of 4, e.g. the reference's 25 node features): its stagers use
+// dword loads.  D = 64 (DB = 2): 55 KB of images, two workgroups per CU.
+template <int DB, int NBF, bool XVEC = true>
+__global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
+                                                                 float* __restrict__ slabs, int N) {
   constexpr int D = DB * 32, FP = NBF * 32, TR = 64, LDT = TR + 8;
   constexpr int NTILE = DB * NBF, TPW = NTILE >= DWW ? NTILE / DWW : 1, KPARTS = NTILE >= DWW ? 1 : DWW / NTILE;
   static_assert(NTILE * KPARTS == DWW * TPW, "block -> wave map");
   static_assert(TPW == 1 || NBF % TPW == 0, "a wave's blocks share the dH fragment");
-  static_assert(D == 128 && DWT == 512, "staging map: 256 threads per tensor, a (column quad, node octet) each");
+  static_assert(KPARTS <= TR / 16, "k-steps per tile");
+  constexpr int ZQ = D / 4, XQ = FP / 4, ZTH = ZQ * 8, XTH = XQ * 8;     // column quads / stager threads per tensor
+  static_assert(ZTH + XTH <= DWT && ZTH % 64 == 0, "staging map: a (column quad, node octet) per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* zp = reinterpret_cast<short*>(smem);          // 3 planes [D][LDT]
   short* xp = zp + 3 * D * LDT;                        // 3 planes [FP][LDT]
@@ -187,28 +191,42 @@ __global__ __launch_bounds__(DWT, 2) void k_tall_dw(const float* __restrict__ Z,
 #pragma unroll
     for (int i = 0; i < 16; ++i) dw[j][i] = 0.f;
 
-  // staging: threads 0..255 take dH, 256..511 take X; thread (cq, oct): columns 4 cq .. 4 cq + 3 of nodes 8 oct .. 8 oct + 7:
-  // eight float4 loads (a wave covers two whole 512-byte rows per instruction), four splits, twelve 16-byte LDS writes
-  const bool is_x = tid >= 256;
-  const int cq = tid & 31, oct = (tid >> 5) & 7;
-  const bool x_live = 4 * cq < FP;                     // (FP < 128: some X stagers idle)
+  // staging: the first ZTH threads take dH, the next XTH take X (the rest idle); thread (cq, oct): columns 4 cq .. 4 cq + 3 of
+  // nodes 8 oct .. 8 oct + 7: eight float4 loads (a wave covers whole rows per instruction), four splits, twelve 16-byte LDS writes
+  const bool is_x = tid >= ZTH;                        // (wave-uniform)
+  const bool live = tid < ZTH + XTH;
+  const int sidx = is_x ? tid - ZTH : tid;
+  const int cq = is_x ? sidx % XQ : sidx % ZQ, oct = (is_x ? sidx / XQ : sidx / ZQ) & 7;
   float4 sv[8];
   auto load_tile = [&](int t) {
     const int row0 = t * TR + oct * 8;
-    const float* src = is_x ? X : Z;
-    const int ldm = is_x ? F : D;
-    int c = 4 * cq;
-    if (c > ldm - 4) c = ldm - 4;
+    if (!is_x || XVEC) {
+      const float* src = is_x ? X : Z;
+      const int ldm = is_x ? F : D;
+      int c = 4 * cq;
+      if (c > ldm - 4) c = ldm - 4;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int node = row0 + u;
-      if (node > N - 1) node = N - 1;
-      sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
+      for (int u = 0; u < 8; ++u) {
+        int node = row0 + u;
+        if (node > N - 1) node = N - 1;
+        sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
+      }
+    } else {
+      int cc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cc[i] = 4 * cq + i < F ? 4 * cq + i : F - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int node = row0 + u;
+        if (node > N - 1) node = N - 1;
+        const float* rowp = X + (size_t)node * F;
+        sv[u] = make_float4(rowp[cc[0]], rowp[cc[1]], rowp[cc[2]], rowp[cc[3]]);
+      }
     }
   };
   auto store_tile = [&](int t) {                       // rows past N and columns past F become zeros (they are summed)
     const int row0 = t * TR + oct * 8;
-    if (is_x && !x_live) return;
+    if (!live) return;
     short* planes = is_x ? xp : zp;
     const int rows = is_x ? FP : D, lim = is_x ? F : D;
 #pragma unroll
@@ -807,6 +825,270 @@ __global__ __launch_bounds__(SN, 4) void k_seg_bwd(const float* __restrict__ dou
   }
 }
 
+// =====================================================================================================
+// graph part of the backward for 64-wide layers (the reference's own regime: 56-184 atoms, D = 64): the kernel above
+// with the layer width and the workgroup size as parameters
+// =====================================================================================================
+// A 64-wide tile of a <= 128-node graph is 35 KB: four workgroups of 4 waves fit a CU, so the per-graph phases of four
+// graphs overlap (the 128-wide form above runs one 16-wave workgroup per CU).  <= 224 nodes: 8 waves, two per CU.
+template <int D, int NT, int NMAX>
+struct GS {
+  static constexpr int LPR = D / 4, RPP = NT / LPR, RPT = (NMAX + RPP - 1) / RPP, TS = D + 4, NW = NT / 64;
+  static constexpr int EPT = SEG_MAX_EDGES / NT;
+  static_assert(NT % LPR == 0 && SEG_MAX_EDGES % NT == 0 && NT >= 128, "thread maps");
+  struct Lds {
+    int rowptr[NMAX + 4];
+    int cursor[NMAX];
+    int degin[NMAX];
+    float dinv[NMAX];
+    unsigned short col[SEG_MAX_EDGES];
+    float red[NW * D];
+  };
+  struct Edges {       // this thread's edges of the graph (loads only: unconditional, clamped)
+    long long s[EPT], d[EPT];
+    __device__ __forceinline__ void load(const SegGraph& gi, const int64_t* __restrict__ ei, int64_t E) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int e = threadIdx.x + j * NT;
+        int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
+        if (k > E - 1) k = E - 1;
+        s[j] = ei[k];
+        d[j] = ei[E + k];
+      }
+    }
+  };
+  // this thread's share of a graph's rows: rows rg, rg + RPP, ... (rg = tid / LPR), columns 4 c4 .. 4 c4 + 3 (c4 = tid % LPR)
+  struct Rows {
+    float4 v[RPT];
+    __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi) {
+      const int rg = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
+      const float* base = src + (size_t)gi.nld * D + 4 * c4;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        if (j * RPP < gi.n) {                     // block-uniform guard, clamped address: no per-lane branch around the load
+          const int row = rg + RPP * j;
+          v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * D);
+        }
+      }
+    }
+  };
+  // mid.hip's build_csr (see seg_build_csr above), any thread count
+  template <bool BY_SRC>
+  static __device__ __forceinline__ void build_csr(Lds& L, const SegGraph& gi, const Edges& er, int32_t* status) {
+    const int tid = threadIdx.x;
+    const int n = gi.n;
+    for (int i = tid; i < n; i += NT) { L.cursor[i] = 0; if (BY_SRC) L.degin[i] = 0; }
+    __syncthreads();
+    unsigned short es[EPT], ed[EPT];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      es[j] = 0xffff;
+      ed[j] = 0xffff;
+      if (tid + j * NT < gi.ne) {
+        const unsigned sl = (unsigned)((int)er.s[j] - gi.nbase), dl = (unsigned)((int)er.d[j] - gi.nbase);
+        const bool ok = sl < (unsigned)n && dl < (unsigned)n && (er.s[j] >> 31) == 0 && (er.d[j] >> 31) == 0;
+        bad |= !ok;
+        if (ok && sl != dl) {
+          es[j] = (unsigned short)sl;
+          ed[j] = (unsigned short)dl;
+          atomicAdd(&L.cursor[BY_SRC ? sl : dl], 1);
+          if (BY_SRC) atomicAdd(&L.degin[dl], 1);
+        }
+      }
+    }
+    if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);
+    __syncthreads();
+    if (tid < 64) {     // exclusive scan of the row sizes (<= 256 rows: 4 per lane)
+      constexpr int RPL = (NMAX + 63) / 64;
+      int v[RPL], tot = 0;
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+        const int i = tid * RPL + j;
+        v[j] = i < n ? L.cursor[i] : 0;
+        tot += v[j];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (tid >= off) incl += t;
+      }
+      int run = incl - tot;
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+        const int i = tid * RPL + j;
+        if (i < n) L.rowptr[i] = run;
+        run += v[j];
+      }
+      if (tid == 63) L.rowptr[n] = incl;
+    } else {                                     // (the other waves, meanwhile) dinv of every row
+      for (int i = tid - 64; i < n; i += NT - 64) L.dinv[i] = 1.0f / sqrtf(1.0f + (float)(BY_SRC ? L.degin[i] : L.cursor[i]));
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) L.cursor[i] = L.rowptr[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      if (es[j] != 0xffff) {
+        const int p = atomicAdd(&L.cursor[BY_SRC ? es[j] : ed[j]], 1);
+        L.col[p] = BY_SRC ? ed[j] : es[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+      const int kb = L.rowptr[i], ke = L.rowptr[i + 1], len = ke - kb;
+      if (len > 1 && len <= 4) {
+        unsigned a0 = L.col[kb], a1 = L.col[kb + 1], a2 = len > 2 ? L.col[kb + 2] : 0xffffu, a3 = len > 3 ? L.col[kb + 3] : 0xffffu;
+        unsigned t;
+        t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+        t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+        t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+        t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+        t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+        L.col[kb] = (unsigned short)a0;
+        L.col[kb + 1] = (unsigned short)a1;
+        if (len > 2) L.col[kb + 2] = (unsigned short)a2;
+        if (len > 3) L.col[kb + 3] = (unsigned short)a3;
+      } else if (len > 4) {
+        for (int a = kb + 1; a < ke; ++a) {
+          const unsigned short key = L.col[a];
+          int b = a - 1;
+          while (b >= kb && L.col[b] > key) { L.col[b + 1] = L.col[b]; --b; }
+          L.col[b + 1] = key;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  static __device__ __forceinline__ float4 row_sum(const float* t, const unsigned short* col, int row, int kb, int ke, int c4) {
+    float4 acc = *reinterpret_cast<const float4*>(t + row * TS + 4 * c4);
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = kb + j < ke ? col[kb + j] : row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(t + c[j] * TS + 4 * c4);
+      if (kb + j < ke) f4_add(acc, v);
+    }
+    for (int k = kb + 4; __any(k < ke); ++k) {
+      if (k < ke) f4_add(acc, *reinterpret_cast<const float4*>(t + col[k] * TS + 4 * c4));
+    }
+    return acc;
+  }
+  // the lanes of a wave that hold the same columns (64 / LPR of them) -> one value per column, fixed order
+  static __device__ __forceinline__ float4 fold(float4 v) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+    }
+    return v;
+  }
+};
+
+template <int D, int NT, int NMAX, bool POOLG, bool TWO>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
+    const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb, const float* __restrict__ a_out,
+    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr, int B,
+    int npad, float slope, int act_here, float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status) {
+  using G = GS<D, NT, NMAX>;
+  constexpr int LPR = G::LPR, RPP = G::RPP, RPT = G::RPT, TS = G::TS, NW = G::NW;
+  constexpr bool NEED_A = POOLG || TWO;
+  __shared__ typename G::Lds L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);          // [npad][TS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c4 = tid % LPR, rg = tid / LPR;
+  float4 dbacc = f4_zero();
+
+  SegGraph gnext;
+  typename G::Edges er;
+  typename G::Rows drows, arows;
+  float4 gmx = f4_zero(), dmx = f4_zero(), dmean = f4_zero();
+  auto request = [&](int g) {                          // everything of graph g this thread will need: loads only
+    gnext = seg_graph(g, graph_ptr, edge_ptr, npad, status);
+    er.load(gnext, ei, E);
+    if (!POOLG) drows.load(dout, gnext);
+    if (NEED_A) arows.load(a_out, gnext);
+    if (POOLG) {
+      const size_t eb = (size_t)g * 2 * D + 4 * c4;
+      gmx = *reinterpret_cast<const float4*>(emb + eb);
+      dmx = *reinterpret_cast<const float4*>(demb + eb);
+      dmean = *reinterpret_cast<const float4*>(demb + eb + D);
+    }
+  };
+  if ((int)blockIdx.x < B) request(blockIdx.x);
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const SegGraph gi = gnext;
+    G::template build_csr<true>(L, gi, er, status);
+    float4 share = f4_zero(), dmn = f4_zero();
+    const float4 gm = gmx;
+    if (POOLG) {
+      const float cntf = (float)(gi.n > 0 ? gi.n : 1);
+      dmn = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
+      float4 ties = f4_zero();                           // ties of the column maxima among this thread's rows
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        if (j * RPP < gi.n && rg + RPP * j < gi.n) {
+          const float4 a = arows.v[j];
+          ties.x += (a.x == gm.x); ties.y += (a.y == gm.y); ties.z += (a.z == gm.z); ties.w += (a.w == gm.w);
+        }
+      }
+      ties = G::fold(ties);
+      if (lane < LPR) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = ties;
+      __syncthreads();
+      float4 tot = f4_zero();
+#pragma unroll
+      for (int w = 0; w < NW; ++w) f4_add(tot, *reinterpret_cast<const float4*>(L.red + w * D + 4 * c4));   // (counts: exact)
+      share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int row = rg + RPP * j;
+      if (j * RPP < gi.n && row < gi.n) {
+        float4 a = f4_zero(), gq;
+        if (NEED_A) a = arows.v[j];
+        if (POOLG) {
+          gq = make_float4(dmn.x + (a.x == gm.x ? share.x : 0.f), dmn.y + (a.y == gm.y ? share.y : 0.f),
+                           dmn.z + (a.z == gm.z ? share.z : 0.f), dmn.w + (a.w == gm.w ? share.w : 0.f));
+        } else {
+          gq = drows.v[j];
+        }
+        if (NEED_A && act_here) {
+          gq.x *= hcg_leaky_grad(a.x, slope); gq.y *= hcg_leaky_grad(a.y, slope);
+          gq.z *= hcg_leaky_grad(a.z, slope); gq.w *= hcg_leaky_grad(a.w, slope);
+        }
+        f4_add(dbacc, gq);
+        *reinterpret_cast<float4*>(tile + row * TS + 4 * c4) = f4_scale(L.dinv[row], gq);
+      }
+    }
+    __syncthreads();
+    if (g + (int)gridDim.x < B) request(g + gridDim.x);   // the NEXT graph: in flight under this graph's sums
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      if (j * RPP < gi.n) {
+        const int row = rg + RPP * j;
+        const bool valid = row < gi.n;
+        const int rr = valid ? row : gi.n - 1;
+        const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
+        const float4 acc = G::row_sum(tile, L.col, rr, kb, ke, c4);
+        if (valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + row) * D + 4 * c4) = f4_scale(L.dinv[rr], acc);
+      }
+    }
+    __syncthreads();   // the tile, the CSR and the tie scratch are free for the next graph
+  }
+  // ---- this workgroup's bias-gradient slab [D]: lanes of a column -> wave -> workgroup (LDS), fixed order
+  dbacc = G::fold(dbacc);
+  if (lane < LPR) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = dbacc;
+  __syncthreads();
+  if (tid < D) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += L.red[w * D + tid];
+    db_slabs[(size_t)blockIdx.x * D + tid] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- host side
 int cu_count() {
   static int cus = 0;
@@ -828,9 +1110,15 @@ int mm_grid(int64_t N) {
   return g < 1 ? 1 : (int)g;
 }
 constexpr int DW_TILE = 64;
-int dw_grid(int64_t N) {             // one workgroup per CU (110 KB of operand images); every workgroup leaves a slab
+int dw_grid(int64_t N, int64_t D = 128) {   // one workgroup per CU (110 KB of operand images; D = 64: two); every workgroup leaves a slab
   int64_t g = hcg_cdiv(N, DW_TILE);
-  if (g > (int64_t)cu_count()) g = (int64_t)cu_count();
+  const int64_t cap = (int64_t)cu_count() * (D == 64 ? 2 : 1);
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : (int)g;
+}
+int seg_grid64(int64_t B) {          // 64-wide layers: up to four 4-wave workgroups per CU (two 8-wave ones for graphs > 128 nodes)
+  int64_t g = (int64_t)cu_count() * 4;
+  if (g > B) g = B;
   return g < 1 ? 1 : (int)g;
 }
 int seg_npad(int64_t max_nodes) { return (int)((max_nodes + 3) / 4 * 4); }
@@ -847,8 +1135,8 @@ struct TallWs { float* inter; float* dw_slabs; float* db_slabs; size_t total; };
 TallWs tall_carve(void* ws, int64_t N, int64_t B, int64_t F, int64_t D) {
   TallWs t;
   const size_t o1 = hcg_align_up((size_t)N * D * sizeof(float), 256);
-  const size_t o2 = o1 + hcg_align_up((size_t)dw_grid(N) * D * tall_fpad(F) * sizeof(float), 256);
-  const size_t o3 = o2 + hcg_align_up((size_t)seg_grid(B) * D * sizeof(float), 256);
+  const size_t o2 = o1 + hcg_align_up((size_t)dw_grid(N, D) * D * tall_fpad(F) * sizeof(float), 256);
+  const size_t o3 = o2 + hcg_align_up((size_t)(D == 64 ? seg_grid64(B) : seg_grid(B)) * D * sizeof(float), 256);
   char* p = (char*)ws;
   t.inter = (float*)p;
   t.dw_slabs = p ? (float*)(p + o1) : nullptr;
@@ -863,12 +1151,17 @@ TallWs tall_carve(void* ws, int64_t N, int64_t B, int64_t F, int64_t D) {
 // the one-graph-per-workgroup kernels, which hold the whole layer in LDS), F a multiple of 4 up to 128, the graph limits
 // of hcg_mid_supported
 extern "C" int hcg_tall_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph) {
-  return (D == 128 && F >= 4 && F <= 128 && (F % 4) == 0 && max_nodes_per_graph >= 1 && max_nodes_per_graph <= SEG_MAX_NODES &&
-          max_edges_per_graph >= 0 && max_edges_per_graph <= SEG_MAX_EDGES) ? 1 : 0;
+  if (max_nodes_per_graph < 1 || max_nodes_per_graph > SEG_MAX_NODES || max_edges_per_graph < 0 || max_edges_per_graph > SEG_MAX_EDGES)
+    return 0;
+  if (D == 128) return (F >= 4 && F <= 128 && (F % 4) == 0) ? 1 : 0;
+  // 64-wide layers over graphs of 65 .. 224 nodes (the reference's own sizes; up to 64 nodes the one-graph-per-wave kernels
+  // take the layer): the BACKWARD runs here, the forward stays with the one-graph-per-workgroup kernel (hcg_mid_layer_fwd)
+  if (D == 64) return (F >= 1 && F <= 64 && max_nodes_per_graph > 64 && hcg_mid_supported(F, D, max_nodes_per_graph, max_edges_per_graph)) ? 1 : 0;
+  return 0;
 }
 
 extern "C" size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int64_t D) {
-  if (N <= 0 || B <= 0 || D != 128 || F < 4 || F > 128) return 0;
+  if (N <= 0 || B <= 0 || (D != 128 && D != 64) || F < 1 || F > 128) return 0;
   return tall_carve(nullptr, N, B, F, D).total;
 }
 
@@ -878,6 +1171,9 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
                                   int32_t* status, void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_tall_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
+  if (D == 64)     // (64-wide layers: only the backward is cut this way)
+    return hcg_mid_layer_fwd(x, W, b, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, max_nodes, max_edges, slope, apply_act, out, emb,
+                             status, stream_);
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
@@ -957,6 +1253,60 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const TallWs ws = tall_carve(workspace, N, B, F, D);
   const int act_here = apply_act & 1;
+  if (D == 64) {
+    const int npad = seg_npad(max_nodes), fp = tall_fpad(F);
+    const dim3 sgrid(seg_grid64(B));
+    const size_t slds = (size_t)npad * (64 + 4) * sizeof(float);
+#define LAUNCH_GSEG(NTV, NMAXV, PG, TW2, AOUT)                                                                             \
+  do {                                                                                                                     \
+    hipError_t e = allow_lds<k_gseg_bwd<64, NTV, NMAXV, PG, TW2>>((size_t)NMAXV * 68 * sizeof(float));                    \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
+    hipLaunchKernelGGL((k_gseg_bwd<64, NTV, NMAXV, PG, TW2>), sgrid, dim3(NTV), slds, stream, dout, demb, emb, AOUT,       \
+                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);   \
+  } while (0)
+#define DISPATCH_GSEG(NTV, NMAXV)                                                                                          \
+  do {                                                                                                                     \
+    if (poolg) LAUNCH_GSEG(NTV, NMAXV, true, false, out);                                                                  \
+    else if (act_here) LAUNCH_GSEG(NTV, NMAXV, false, true, out);                                                          \
+    else LAUNCH_GSEG(NTV, NMAXV, false, false, (const float*)nullptr);                                                     \
+  } while (0)
+    if (npad <= 128) DISPATCH_GSEG(256, 128); else DISPATCH_GSEG(512, 224);
+#undef DISPATCH_GSEG
+#undef LAUNCH_GSEG
+    HCG_CHECK_LAUNCH();
+    {   // dW slabs = dH^T x
+      const dim3 grid(dw_grid(N, 64)), blk(DWT);
+      const bool xvec = (F % 4) == 0 && ((uintptr_t)x % 16) == 0;
+#define LAUNCH_DW64(NBF, XV)                                                                                          \
+  do {                                                                                                               \
+    const size_t lds = (size_t)3 * (64 + NBF * 32) * (DW_TILE + 8) * sizeof(short);                                  \
+    hipError_t e = allow_lds<k_tall_dw<2, NBF, XV>>(lds);                                                            \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                      \
+    hipLaunchKernelGGL((k_tall_dw<2, NBF, XV>), grid, blk, lds, stream, ws.inter, x, (int)F, ws.dw_slabs, (int)N);   \
+  } while (0)
+      if (fp == 32) { if (xvec) LAUNCH_DW64(1, true); else LAUNCH_DW64(1, false); }
+      else          { if (xvec) LAUNCH_DW64(2, true); else LAUNCH_DW64(2, false); }
+#undef LAUNCH_DW64
+      HCG_CHECK_LAUNCH();
+    }
+    if (dx) {   // dx = dH W
+      const dim3 grid(mm_grid(N)), blk(TT);
+      const size_t lds = (size_t)3 * fp * (64 + WPAD) * 2;
+      const bool pm = (apply_act & 2) != 0;
+#define LAUNCH_MM64(NOB, PM)                                                                                               \
+  do {                                                                                                                     \
+    hipError_t e = allow_lds<k_tall_mm<64, NOB, true, PM>>(lds);                                                           \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
+    hipLaunchKernelGGL((k_tall_mm<64, NOB, true, PM>), grid, blk, lds, stream, ws.inter, (int)D, W, (int)D, (int)F, dx,    \
+                       (int)F, x, slope, (int)N);                                                                          \
+  } while (0)
+      if (fp == 32) { if (pm) LAUNCH_MM64(1, true); else LAUNCH_MM64(1, false); }
+      else          { if (pm) LAUNCH_MM64(2, true); else LAUNCH_MM64(2, false); }
+#undef LAUNCH_MM64
+      HCG_CHECK_LAUNCH();
+    }
+    return HCG_OK;
+  }
   const dim3 sgrid(seg_grid(B)), sblk(SN);
   const int npad = seg_npad(max_nodes);
   const size_t slds = seg_tile_bytes(npad), slds_max = seg_tile_bytes(SEG_MAX_NODES);
@@ -1014,20 +1364,20 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
 // two jobs: job_host[0] = dW [D, F] from the k_tall_dw slabs, job_host[1] = db [D] from the k_seg_bwd slabs
 extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
                                     float* dW, float* db, hcg_reduce_job* job_host) {
-  if (D != 128 || F < 4 || F > 128 || N <= 0 || B <= 0 || !dW || !db || !job_host || !workspace) return HCG_ERR_INVALID_ARG;
+  if ((D != 128 && D != 64) || F < 1 || F > 128 || N <= 0 || B <= 0 || !dW || !db || !job_host || !workspace) return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
   const TallWs ws = tall_carve(const_cast<void*>(workspace), N, B, F, D);
   const int fp = tall_fpad(F);
   hcg_reduce_job* j = job_host;
   j->slabs = ws.dw_slabs;
-  j->nslabs = dw_grid(N);
+  j->nslabs = dw_grid(N, D);
   j->slab_floats = (int32_t)(D * fp);
   j->nseg = 1;
   j->reserved = 0;
   j->seg[0] = hcg_reduce_seg{0, (int32_t)(D * fp), fp, (int32_t)F, dW};
   j = job_host + 1;
   j->slabs = ws.db_slabs;
-  j->nslabs = seg_grid(B);
+  j->nslabs = D == 64 ? seg_grid64(B) : seg_grid(B);
   j->slab_floats = (int32_t)D;
   j->nseg = 1;
   j->reserved = 0;

@@ -313,8 +313,9 @@ def mid_gcn_layer(x, weight, bias, plan: BatchPlan, apply_act=True, slope=LEAKY_
 
 
 class _TallLayerFn(torch.autograd.Function):
-    """Wide layers (D = 128) over large graphs: dense row-streaming transform + per-graph segmented sum (csrc/tall.hip).
-    Same contract as `_MidLayerFn`; the forward's H = x W^T makes a round trip through a workspace."""
+    """Layers cut into dense row-streaming parts + per-graph segmented sums (csrc/tall.hip): D = 128 over large graphs
+    (forward and backward), D = 64 over graphs of 65 .. 224 nodes (backward; the forward is `hcg_mid_layer_fwd`).
+    Same contract as `_MidLayerFn`."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, plan: BatchPlan, apply_act: bool, slope: float, pool: bool):
@@ -328,8 +329,8 @@ class _TallLayerFn(torch.autograd.Function):
         dev = x.device
         out = torch.empty(N, D, dtype=torch.float32, device=dev)
         emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
-        wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D) if D != 64 else 0     # (64-wide: the forward needs none)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         rc = lib.hcg_tall_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
                                     _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, plan.max_nodes,
                                     plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
@@ -376,7 +377,7 @@ class _TallLayerFn(torch.autograd.Function):
 
 
 def tall_supported(plan: BatchPlan, F: int, D: int) -> bool:
-    """True when the wide-layer kernels (csrc/tall.hip: D = 128) apply to this plan / layer shape."""
+    """True when the kernels of csrc/tall.hip apply to this plan / layer shape (D = 128; D = 64 over graphs > 64 nodes)."""
     if (plan.mode != "blocked" or plan.ew_csr is not None or plan.max_nodes is None or plan.max_edges is None
             or plan.B == 0 or plan.N == 0):
         return False

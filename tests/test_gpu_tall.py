@@ -17,15 +17,19 @@ def _convs(m):
     return [m.conv1] + list(m.conv_layers)
 
 
-@pytest.mark.parametrize("nodes,jitter,feat,extra,deg,B,seed", [(200, 0, 128, 13, 6, 24, 10), (100, 60, 100, 6, 4, 40, 1),
-                                                                (50, 10, 64, 3, 4, 40, 2), (120, 40, 28, 6, 4, 40, 6),
-                                                                (40, 30, 8, 2, 4, 70, 3)])
-def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, nodes, jitter, feat, extra, deg, B, seed):
+@pytest.mark.parametrize("nodes,jitter,feat,extra,deg,B,seed,D", [(200, 0, 128, 13, 6, 24, 10, 128), (100, 60, 100, 6, 4, 40, 1, 128),
+                                                                  (50, 10, 64, 3, 4, 40, 2, 128), (120, 40, 28, 6, 4, 40, 6, 128),
+                                                                  (40, 30, 8, 2, 4, 70, 3, 128),
+                                                                  # 64-wide layers (the reference's own regime): the backward only
+                                                                  (87, 30, 25, 5, 4, 131, 12, 64), (150, 34, 32, 8, 4, 131, 9, 64),
+                                                                  (60, 27, 64, 4, 4, 131, 15, 64), (100, 92, 25, 6, 6, 131, 12, 64)])
+def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, nodes, jitter, feat, extra, deg, B, seed, D):
     """Forward with the pooled epilogue, both backward variants (pooled gradient + dx, dout without dx), every K padding
-    (32 / 64 / 128, incl. widths that are no multiple of 32), ragged batches (graphs of 10 .. 200 nodes side by side)."""
+    (32 / 64 / 128, incl. widths that are no multiple of 32 or of 4), ragged batches (graphs of 8 .. 200 nodes side by side);
+    D = 64: 4-wave workgroups up to 128 nodes, 8-wave ones above."""
     from hcatgnet_amd import functional as HF, synth
     sb = synth.make_batch(num_graphs=B, nodes=nodes, extra_bonds=extra, max_degree=deg, feat=feat, nodes_jitter=jitter, seed=seed)
-    params = _rand_params(feat, 128, seed=31)
+    params = _rand_params(feat, D, seed=31)
     _, _, acts0 = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
     assert _near_ties(acts0[-1], sb.batch, sb.num_graphs) == 0, "pick another seed: this batch has a near-tie in the max pooling"
     m = _model_from_params(H, params)
@@ -33,7 +37,7 @@ def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, nodes, jitter, fe
     plan = H.BatchPlan.build(batch.edge_index, batch.batch, batch.x.shape[0], num_graphs=sb.num_graphs, mode="blocked",
                              max_nodes=sb.max_nodes, max_edges=sb.max_edges)
     batch._hcg_plan = plan
-    assert HF.tall_supported(plan, feat, 128) and HF.tall_supported(plan, 128, 128)
+    assert HF.tall_supported(plan, feat, D) and HF.tall_supported(plan, D, D)
     m.use_fused = True
     out_t, emb_t, g_t = _step_grads(m, batch, batch.y)
     assert plan.check_status() == 0
