@@ -193,14 +193,21 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
 
   // staging: the first ZTH threads take dH, the next XTH take X (the rest idle); thread (cq, oct): columns 4 cq .. 4 cq + 3 of
   // nodes 8 oct .. 8 oct + 7: eight float4 loads (a wave covers whole rows per instruction), four splits, twelve 16-byte LDS writes
-  const bool is_x = tid >= ZTH;                        // (wave-uniform)
-  const bool live = tid < ZTH + XTH;
+  // XVEC = false (rows of X not 16-byte aligned): X is staged per (column, node octet) instead -- thread t takes column
+  // t % FP of octet t / FP with eight dword loads (a wave's lanes on consecutive columns), one split, three writes; the dH
+  // stagers do that on top of their own share.
+  const bool is_x = XVEC && tid >= ZTH;                // (wave-uniform)
+  const bool live = XVEC ? tid < ZTH + XTH : tid < ZTH;
   const int sidx = is_x ? tid - ZTH : tid;
   const int cq = is_x ? sidx % XQ : sidx % ZQ, oct = (is_x ? sidx / XQ : sidx / ZQ) & 7;
+  const int xc = tid % FP, xo = tid / FP;              // XVEC = false: this thread's X item
+  const bool x_item = !XVEC && xo < 8;
+  static_assert(XVEC || FP * 8 <= DWT, "one X item per thread");
   float4 sv[8];
+  float xs[XVEC ? 1 : 8];
   auto load_tile = [&](int t) {
-    const int row0 = t * TR + oct * 8;
-    if (!is_x || XVEC) {
+    if (live) {
+      const int row0 = t * TR + oct * 8;
       const float* src = is_x ? X : Z;
       const int ldm = is_x ? F : D;
       int c = 4 * cq;
@@ -211,38 +218,48 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
         if (node > N - 1) node = N - 1;
         sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
       }
-    } else {
-      int cc[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cc[i] = 4 * cq + i < F ? 4 * cq + i : F - 1;
+    }
+    if (x_item) {                                       // (wave-uniform: FP * 8 is a multiple of 64)
+      const int row0 = t * TR + xo * 8, cc = xc < F ? xc : F - 1;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         int node = row0 + u;
         if (node > N - 1) node = N - 1;
-        const float* rowp = X + (size_t)node * F;
-        sv[u] = make_float4(rowp[cc[0]], rowp[cc[1]], rowp[cc[2]], rowp[cc[3]]);
+        xs[u] = X[(size_t)node * F + cc];
       }
     }
   };
   auto store_tile = [&](int t) {                       // rows past N and columns past F become zeros (they are summed)
-    const int row0 = t * TR + oct * 8;
-    if (!live) return;
-    short* planes = is_x ? xp : zp;
-    const int rows = is_x ? FP : D, lim = is_x ? F : D;
+    if (live) {
+      const int row0 = t * TR + oct * 8;
+      short* planes = is_x ? xp : zp;
+      const int rows = is_x ? FP : D, lim = is_x ? F : D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = 4 * cq + i;
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * cq + i;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
+          v[u] = (row0 + u < N && c < lim) ? e : 0.f;
+        }
+        const Split3 sp = split3(v);
+        short* dst = planes + c * LDT + dw_oct(c, oct) * 8;
+        *reinterpret_cast<bf16x8*>(dst) = sp.p1;
+        *reinterpret_cast<bf16x8*>(dst + rows * LDT) = sp.p2;
+        *reinterpret_cast<bf16x8*>(dst + 2 * rows * LDT) = sp.p3;
+      }
+    }
+    if (x_item) {
+      const int row0 = t * TR + xo * 8;
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
-        v[u] = (row0 + u < N && c < lim) ? e : 0.f;
-      }
+      for (int u = 0; u < 8; ++u) v[u] = (row0 + u < N && xc < F) ? xs[u] : 0.f;
       const Split3 sp = split3(v);
-      short* dst = planes + c * LDT + dw_oct(c, oct) * 8;
+      short* dst = xp + xc * LDT + dw_oct(xc, xo) * 8;
       *reinterpret_cast<bf16x8*>(dst) = sp.p1;
-      *reinterpret_cast<bf16x8*>(dst + rows * LDT) = sp.p2;
-      *reinterpret_cast<bf16x8*>(dst + 2 * rows * LDT) = sp.p3;
+      *reinterpret_cast<bf16x8*>(dst + FP * LDT) = sp.p2;
+      *reinterpret_cast<bf16x8*>(dst + 2 * FP * LDT) = sp.p3;
     }
   };
 
