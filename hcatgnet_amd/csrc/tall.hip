@@ -10,8 +10,8 @@
 // meets a barrier after the prologue.  The graph part keeps only the CSR in LDS (~10 KB: 8+ workgroups per CU), gathers
 // neighbour rows from L2 (a graph's rows are touched ~3x within microseconds) and carries the fused epilogues:
 //
-//   forward   H  = X W^T                              k_tall_mm   (split-bf16 MFMAs, f32 accuracy: split_mfma.h)
-//             out = LeakyReLU(Ahat H + b), [max, mean] pool       k_seg_fwd
+//   forward   H  = X W^T (LDS tile only), out = LeakyReLU(Ahat H + b), [max, mean] pool      k_split_weight + k_seg_fwd
+//             (split-bf16 MFMAs, f32 accuracy: split_mfma.h)
 //   backward  dH = Ahat^T (dA (.) leaky'(A)),  db slabs           k_seg_bwd  (dA = dout, or the pooled gradient expanded on chip)
 //             dX = dH W  (optionally premasked with leaky'(X))    k_tall_mm  (transposed image)
 //             dW slabs = dH^T X                                   k_tall_dw
@@ -31,7 +31,8 @@ namespace {
 constexpr int TW = 16;                // waves per workgroup: the whole CU, four per SIMD, 128 VGPRs each
 constexpr int TT = TW * 64;
 
-// TRANS = false: B[k][n] = W[n][k]  (H = X W^T;  W is [NO x K] row-major = the layer's weight)
+// TRANS = false: B[k][n] = W[n][k]  (H = X W^T;  W is [NO x K] row-major = the layer's weight; kept for tools/probe_tall.hip:
+//                the forward fuses this product into k_seg_fwd)
 // TRANS = true : B[k][n] = W[k][n]  (dX = dH W;  W is [K x NO] row-major = the same weight)
 // KP / NOB * 32: K and NO padded to the image extent; lda / ldo: the real row lengths of A / out (multiples of 4).
 // A wave owns one 32-row block x NBW 32-column blocks (NOB = 4: two waves share a row block, each re-reading its A rows
@@ -544,9 +545,10 @@ __global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ 
 
 constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (three planes, unpadded rows, XOR-swizzled halves)
 
-// GEMM = false: H = x W^T comes from k_tall_mm (`src` = H).  GEMM = true (`src` = x [N, F], `gW` = k_split_weight's image):
-// the graph's H tile is produced here, on the matrix cores, straight into LDS -- H never exists in global memory (420 MB
-// less traffic per C5 layer pair).  The 98 KB weight image cannot sit in LDS beside the 106-118 KB tile, so it streams: one
+// `src` = x [N, F], `gW` = k_split_weight's image: the graph's H tile is produced here, on the matrix cores, straight into LDS --
+// H never exists in global memory (420 MB less traffic per C5 layer pair than a dense H = x W^T launch in front of the sums,
+// which measured 63 + 55 = 119 us per layer).  The 98 KB weight image cannot sit in LDS beside the 106-118 KB tile, so it
+// streams: one
 // 16-column chunk (12 KB, double buffered) per k-step, requested from L2 two k-steps ahead; wave (row block, column half)
 // keeps 2 accumulator blocks; the A fragments come from the graph's x rows staged through the same LDS tile.
 // Measured on C5 (tools/probe_seg.hip, per 200-node graph): CSR 2.3 us, MFMA phase 14 us (its MFMAs alone: 5.9 us -- the
@@ -561,19 +563,18 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // per SIMD the LDS latencies, the split and the MFMA chains of a k-step run in series.  A second workgroup per CU does not
 // fit 160 KB beside the tile.  PMC (profiles/r02_d_traffic_C5.txt): 307 MB per launch for 210 MB of operands -- the 9-33
 // spilled registers of this variant and the weight chunks that miss L2.
-template <bool POOL, bool GEMM>
+template <bool POOL>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,
                                                    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
                                                    const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int apply_act,
                                                    float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
   constexpr int D = SEG_D;
-  __shared__ SegLdsT<!GEMM> L;
+  __shared__ SegLdsT<false> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);          // [npad][SEG_TS]
-  short* wl = reinterpret_cast<short*>(tile + (size_t)npad * SEG_TS);     // GEMM: two weight chunks (2 x 12 KB), later the combine scratch
-  float* red = GEMM ? reinterpret_cast<float*>(wl) : L.red;
-  const float* H = src;
+  float* tile = reinterpret_cast<float*>(smem);          // [npad][SEG_TS]: the graph's x rows, then its H' rows
+  short* wl = reinterpret_cast<short*>(tile + (size_t)npad * SEG_TS);     // two weight chunks (2 x 12 KB), later the combine scratch
+  float* red = reinterpret_cast<float*>(wl);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c4 = tid & 31, rg = tid >> 5;
   const int r = lane & 31, h = lane >> 5;
@@ -581,13 +582,11 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
 
   SegGraph gnext;
   SegEdge er;
-  SegRows rows;
   SegRowsF xrows;
   if ((int)blockIdx.x < B) {
     gnext = seg_graph(blockIdx.x, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
-    if (!GEMM) rows.load(H, gnext);
-    else xrows.load(src, F, gnext);
+    xrows.load(src, F, gnext);
   }
   // (Per graph on C5, s_memtime stamps of tools/probe_seg.hip: CSR build 1.3 us, tile write 0.85 us, sums + stores 10 us -- the
   //  last phase is the memory system draining 102 KB of loads and 102 KB of stores per CU at ~20 KB/us, i.e. ~5 TB/s over the
@@ -599,13 +598,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
     SSTAMP(sit, 0);
     seg_build_csr<false>(L, gi, er, status);
     SSTAMP(sit, 1);
-    if (!GEMM) {
-#pragma unroll
-      for (int j = 0; j < SEG_RPT; ++j) {
-        const int row = rg + 32 * j;
-        if (j * 32 < gi.n && row < gi.n) *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], rows.v[j]);
-      }
-    } else {
+    {
       // ---- H' = dinv . (x W^T) -> tile.  The graph's x rows (requested a graph ahead, row-contiguous) go through the SAME
       // LDS tile first: the A fragments are then conflict-free ds_read_b128 instead of 16-byte global loads of 32 different
       // rows per instruction (measured: those loads were ~10 k of the phase's 33 k cycles on C5, and both waves of a row
@@ -681,8 +674,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
     if (g + (int)gridDim.x < B) {                     // the NEXT graph's scalars, edge and rows: in flight under this graph's sums
       gnext = seg_graph(g + gridDim.x, graph_ptr, edge_ptr, npad, status);
       er.load(gnext, ei, E);
-      if (!GEMM) rows.load(H, gnext);
-      else xrows.load(src, F, gnext);                 // (requested before the MFMA loop instead: the same ~5 us of exposed load
+      xrows.load(src, F, gnext);                      // (requested before the MFMA loop instead: the same ~5 us of exposed load
     }                                                 //  time per graph moves into that phase -- measured equal, more spills)
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = f4_zero();
 #pragma unroll
@@ -1199,53 +1191,28 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
   if (N > (int64_t)INT32_MAX / 2) return HCG_ERR_UNSUPPORTED;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const TallWs ws = tall_carve(workspace, N, B, F, D);
-  const int fp = tall_fpad(F);
   const dim3 sgrid(seg_grid(B)), sblk(SN);
   const int npad = seg_npad(max_nodes);
-  const size_t slds = seg_tile_bytes(npad), slds_max = seg_tile_bytes(SEG_MAX_NODES);
+  const size_t slds = seg_tile_bytes(npad);
   const size_t wbuf = (size_t)2 * WCH * sizeof(short);
-  // fused form: x -> (MFMA) -> H tile in LDS -> sums.  Needs the tile, two weight chunks and the CSR in 160 KB of LDS
-  const bool fuse = sizeof(SegLdsT<false>) + slds + wbuf <= 160 * 1024 - 512;
-  if (fuse) {
+  // x -> (MFMA) -> H tile in LDS -> sums: the tile (<= 224 rows), two weight chunks and the CSR fit 160 KB of LDS
+  {
     const int KP = (int)((F + 15) / 16 * 16);
-    short* img = reinterpret_cast<short*>(ws.inter);                 // 3 x 128 x KP bf16 (the H buffer is not needed)
+    short* img = reinterpret_cast<short*>(ws.inter);                 // 3 x 128 x KP bf16
     hipLaunchKernelGGL(k_split_weight, dim3((128 * KP + 255) / 256), dim3(256), 0, stream, W, (int)D, (int)F, KP, img);
     HCG_CHECK_LAUNCH();
     const size_t lds = slds + wbuf, lds_max = 160 * 1024 - 512 - sizeof(SegLdsT<false>);
-    hipError_t e = emb ? allow_lds<k_seg_fwd<true, true>>(lds_max) : allow_lds<k_seg_fwd<false, true>>(lds_max);
+    if (lds > lds_max) return HCG_ERR_UNSUPPORTED;
+    hipError_t e = emb ? allow_lds<k_seg_fwd<true>>(lds_max) : allow_lds<k_seg_fwd<false>>(lds_max);
     if (e != hipSuccess) return hcg_hip_err(e);
     if (emb)
-      hipLaunchKernelGGL((k_seg_fwd<true, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
+      hipLaunchKernelGGL((k_seg_fwd<true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
                          graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
     else
-      hipLaunchKernelGGL((k_seg_fwd<false, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
+      hipLaunchKernelGGL((k_seg_fwd<false>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
                          graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
     HCG_CHECK_LAUNCH();
-    return HCG_OK;
   }
-  const dim3 grid(mm_grid(N)), blk(TT);
-#define LAUNCH_MM_FWD(KP)                                                                                                  \
-  do {                                                                                                                     \
-    const size_t lds = (size_t)3 * 128 * (KP + WPAD) * 2;                                                                  \
-    hipError_t e = allow_lds<k_tall_mm<KP, 4, false, false>>(lds);                                                         \
-    if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
-    hipLaunchKernelGGL((k_tall_mm<KP, 4, false, false>), grid, blk, lds, stream, x, (int)F, W, (int)D, (int)F, ws.inter,   \
-                       (int)D, (const float*)nullptr, slope, (int)N);                                                      \
-  } while (0)
-  if (fp == 32) LAUNCH_MM_FWD(32); else if (fp == 64) LAUNCH_MM_FWD(64); else LAUNCH_MM_FWD(128);
-#undef LAUNCH_MM_FWD
-  HCG_CHECK_LAUNCH();
-  {
-    hipError_t e = emb ? allow_lds<k_seg_fwd<true, false>>(slds_max) : allow_lds<k_seg_fwd<false, false>>(slds_max);
-    if (e != hipSuccess) return hcg_hip_err(e);
-  }
-  if (emb)
-    hipLaunchKernelGGL((k_seg_fwd<true, false>), sgrid, sblk, slds, stream, (const float*)ws.inter, (int)D, 0, (const short*)nullptr, b,
-                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
-  else
-    hipLaunchKernelGGL((k_seg_fwd<false, false>), sgrid, sblk, slds, stream, (const float*)ws.inter, (int)D, 0, (const short*)nullptr, b,
-                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
-  HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
 

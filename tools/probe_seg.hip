@@ -1,5 +1,5 @@
 // Dev probe (not product): phase stamps (s_memtime: shader clock, printed in units of 100 ticks ~ 0.05 us) of k_seg_fwd on a C5-like batch (1024 ring graphs of 200 nodes,
-// 424 directed edges, 128-d).  Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DHCG_SEG_STAMP -o tools/probe_tall_seg tools/probe_seg.hip
+// 424 directed edges, 128-d).  Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DHCG_SEG_STAMP -o tools/probe_tall_seg tools/probe_seg.hip -L hcatgnet_amd/csrc -lhcatgnet_hip '-Wl,-rpath,$ORIGIN/../hcatgnet_amd/csrc'
 #include "../hcatgnet_amd/csrc/tall.hip"
 #include <cstdio>
 #include <vector>
@@ -34,18 +34,10 @@ int main() {
   short* img; CKH(hipMalloc(&img, 3 * 128 * 128 * 2));
   float* W; CKH(hipMalloc(&W, 128 * 128 * 4)); CKH(hipMemcpy(W, h.data(), 128 * 128 * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_split_weight, dim3(64), dim3(256), 0, 0, W, 128, 128, 128, img);
-#ifdef PROBE_FUSED
-  CKH(hipFuncSetAttribute((const void*)k_seg_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512 - sizeof(SegLdsT<false>))));
-#else
-  CKH(hipFuncSetAttribute((const void*)k_seg_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_tile_bytes(SEG_MAX_NODES)));
-#endif
+  CKH(hipFuncSetAttribute((const void*)k_seg_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512 - sizeof(SegLdsT<false>))));
   hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
   auto launch = [&]() {
-#ifdef PROBE_FUSED
-    hipLaunchKernelGGL((k_seg_fwd<true, true>), dim3(seg_grid(B)), dim3(SN), slds + wbuf, 0, H, D, 128, (const short*)img, bias, (const int64_t*)dei, (int64_t)E, dgp, dep, B, npad, 0.01f, 1, out, emb, dstatus);
-#else
-    hipLaunchKernelGGL((k_seg_fwd<true, false>), dim3(seg_grid(B)), dim3(SN), slds, 0, H, D, 0, (const short*)nullptr, bias, (const int64_t*)dei, (int64_t)E, dgp, dep, B, npad, 0.01f, 1, out, emb, dstatus);
-#endif
+    hipLaunchKernelGGL((k_seg_fwd<true>), dim3(seg_grid(B)), dim3(SN), slds + wbuf, 0, H, D, 128, (const short*)img, bias, (const int64_t*)dei, (int64_t)E, dgp, dep, B, npad, 0.01f, 1, out, emb, dstatus);
   };
   for (int i = 0; i < 5; ++i) launch();
   CKH(hipDeviceSynchronize());

@@ -1,6 +1,6 @@
 // Dev probe (not product): times the dense kernels of csrc/tall.hip on C5's layer shape (204800 x 128 x 128) with parts
 // of the work removed (-DHCG_PROBE_NOLOAD / NOSTORE / NOMFMA), to see what bounds them.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize [-DHCG_PROBE_...] -o tools/probe_tall_x tools/probe_tall.hip
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize [-DHCG_PROBE_...] -o tools/probe_tall_x tools/probe_tall.hip -L hcatgnet_amd/csrc -lhcatgnet_hip '-Wl,-rpath,$ORIGIN/../hcatgnet_amd/csrc'
 #include "../hcatgnet_amd/csrc/tall.hip"
 #include <cstdio>
 #include <vector>
