@@ -625,9 +625,11 @@ def main():
             if entry.startswith("hcg_tall_layer_"):
                 # one call = several launches (bwd: k_seg_bwd + k_tall_dw + k_tall_mm; fwd: k_split_weight + k_seg_fwd):
                 # bytes of every launch of those kernels in the profiled run / calls of the entry point in it (2 per step)
-                fams = ("k_seg_bwd", "k_tall_dw", "k_tall_mm") if entry.endswith("bwd") else ("k_seg_fwd", "k_split_weight")
+                bwd = entry.endswith("bwd")
+                fams = ("k_seg_bwd", "k_gseg_bwd", "k_tall_dw", "k_tall_mm") if bwd else ("k_seg_fwd", "k_split_weight", "k_mid_layer_fwd")
                 tot = sum(v["hbm_bytes"] * v["launches"] for k, v in tj.items() if k.startswith(fams))
-                calls = sum(v["launches"] for k, v in tj.items() if k.startswith("k_seg_bwd" if entry.endswith("bwd") else "k_seg_fwd"))
+                calls = sum(v["launches"] for k, v in tj.items()
+                            if k.startswith(("k_seg_bwd", "k_gseg_bwd") if bwd else ("k_seg_fwd", "k_mid_layer_fwd")))
                 traffic = tot / calls if calls else None
             traffic_src = "profiles/traffic_latest.json: builder-run rocprofv3 PMC passes of this command, not measured in this run"
         except (OSError, ValueError, KeyError, AttributeError):
