@@ -350,7 +350,6 @@ struct SegLdsT {
   unsigned short col[SEG_MAX_EDGES];
   float red[WITH_RED ? SW * 2 * SEG_D : 4];       // combine scratch (the fused forward keeps it in its weight-chunk buffers)
 };
-using SegLds = SegLdsT<true>;
 
 struct SegGraph { int nbase, n, ebase, ne, nld; };
 
@@ -381,23 +380,8 @@ struct SegEdge {       // this thread's edge of the graph (loads only: unconditi
   }
 };
 
-// this thread's share of a graph's rows: rows rg, rg + 32, ... (rg = tid / 32), columns 4 c4 .. 4 c4 + 3 (c4 = tid % 32)
-struct SegRows {
-  float4 v[SEG_RPT];
-  __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi) {
-    const int rg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
-    const float* base = src + (size_t)gi.nld * SEG_D + 4 * c4;
-#pragma unroll
-    for (int j = 0; j < SEG_RPT; ++j) {
-      if (j * 32 < gi.n) {                      // block-uniform guard, clamped address: no per-lane branch around the load
-        const int row = rg + 32 * j;
-        v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * SEG_D);
-      }
-    }
-  }
-};
-
-// the same share of a graph's rows of a [N, F] tensor, F <= 128 a multiple of 4 (columns past F: clamped loads, zeroed by the user)
+// this thread's share of a graph's rows of a [N, F] tensor, F <= 128 a multiple of 4: rows rg, rg + 32, ... (rg = tid / 32),
+// columns 4 c4 .. 4 c4 + 3 (c4 = tid % 32; columns past F: clamped loads, zeroed by the user)
 struct SegRowsF {
   float4 v[SEG_RPT];
   __device__ __forceinline__ void load(const float* __restrict__ src, int F, const SegGraph& gi) {
@@ -725,121 +709,19 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
   }
 }
 
-// ---- backward: G = dA (.) leaky'(A);  db += colsum G;  dY' = dinv . G;  dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_k)
+// =====================================================================================================
+// graph part of the backward: G = dA (.) leaky'(A);  db += colsum G;  dY' = dinv . G;
+//                             dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_k)
+// =====================================================================================================
 // POOLG: dA is the pooled gradient expanded on chip (mean share + the max's share split evenly over ties, as
 // global_max_pool's backward does through torch.max).  TWO: both dout and a_out are read (activation derivative applied
-// here); otherwise exactly one tensor is read.
-template <bool POOLG, bool TWO>
-__global__ __launch_bounds__(SN, 4) void k_seg_bwd(const float* __restrict__ dout, const float* __restrict__ demb,
-                                                   const float* __restrict__ emb, const float* __restrict__ a_out,
-                                                   const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
-                                                   const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int act_here,
-                                                   float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status) {
-  constexpr int D = SEG_D;
-  constexpr bool NEED_A = POOLG || TWO;
-  __shared__ SegLds L;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c4 = tid & 31, rg = tid >> 5;
-  float4 dbacc = f4_zero();
-
-  SegGraph gnext;
-  SegEdge er;
-  SegRows drows, arows;
-  float4 gmx = f4_zero(), dmx = f4_zero(), dmean = f4_zero();
-  auto request = [&](int g) {                          // everything of graph g this thread will need: loads only
-    gnext = seg_graph(g, graph_ptr, edge_ptr, npad, status);
-    er.load(gnext, ei, E);
-    if (!POOLG) drows.load(dout, gnext);
-    if (NEED_A) arows.load(a_out, gnext);
-    if (POOLG) {
-      const size_t eb = (size_t)g * 2 * D + 4 * c4;
-      gmx = *reinterpret_cast<const float4*>(emb + eb);
-      dmx = *reinterpret_cast<const float4*>(demb + eb);
-      dmean = *reinterpret_cast<const float4*>(demb + eb + D);
-    }
-  };
-  if ((int)blockIdx.x < B) request(blockIdx.x);
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
-    const SegGraph gi = gnext;
-    seg_build_csr<true>(L, gi, er, status);
-    float4 share = f4_zero(), dmn = f4_zero();
-    const float4 gm = gmx;
-    if (POOLG) {
-      const float cntf = (float)(gi.n > 0 ? gi.n : 1);
-      dmn = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
-      float4 ties = f4_zero();                           // ties of the column maxima among this thread's rows
-#pragma unroll
-      for (int j = 0; j < SEG_RPT; ++j) {
-        if (j * 32 < gi.n && rg + 32 * j < gi.n) {
-          const float4 a = arows.v[j];
-          ties.x += (a.x == gm.x); ties.y += (a.y == gm.y); ties.z += (a.z == gm.z); ties.w += (a.w == gm.w);
-        }
-      }
-      ties.x += __shfl_xor(ties.x, 32, 64); ties.y += __shfl_xor(ties.y, 32, 64);
-      ties.z += __shfl_xor(ties.z, 32, 64); ties.w += __shfl_xor(ties.w, 32, 64);
-      if (lane < 32) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = ties;
-      __syncthreads();
-      float4 tot = f4_zero();
-#pragma unroll
-      for (int w = 0; w < SW; ++w) f4_add(tot, *reinterpret_cast<const float4*>(L.red + w * D + 4 * c4));   // (counts: exact)
-      share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
-    }
-#pragma unroll
-    for (int j = 0; j < SEG_RPT; ++j) {
-      const int row = rg + 32 * j;
-      if (j * 32 < gi.n && row < gi.n) {
-        float4 a = f4_zero(), gq;
-        if (NEED_A) a = arows.v[j];
-        if (POOLG) {
-          gq = make_float4(dmn.x + (a.x == gm.x ? share.x : 0.f), dmn.y + (a.y == gm.y ? share.y : 0.f),
-                           dmn.z + (a.z == gm.z ? share.z : 0.f), dmn.w + (a.w == gm.w ? share.w : 0.f));
-        } else {
-          gq = drows.v[j];
-        }
-        if (NEED_A && act_here) {
-          gq.x *= hcg_leaky_grad(a.x, slope); gq.y *= hcg_leaky_grad(a.y, slope);
-          gq.z *= hcg_leaky_grad(a.z, slope); gq.w *= hcg_leaky_grad(a.w, slope);
-        }
-        f4_add(dbacc, gq);
-        *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = f4_scale(L.dinv[row], gq);
-      }
-    }
-    __syncthreads();
-    if (g + (int)gridDim.x < B) request(g + gridDim.x);   // the NEXT graph: in flight under this graph's sums
-#pragma unroll
-    for (int j = 0; j < SEG_RPT; ++j) {
-      if (j * 32 < gi.n) {
-        const int row = rg + 32 * j;
-        const bool valid = row < gi.n;
-        const int rr = valid ? row : gi.n - 1;
-        const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
-        const float4 acc = seg_row_sum(tile, L.col, rr, kb, ke, c4);
-        if (valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + row) * D + 4 * c4) = f4_scale(L.dinv[rr], acc);
-      }
-    }
-    __syncthreads();   // the tile, the CSR and the tie scratch are free for the next graph
-  }
-  // ---- this workgroup's bias-gradient slab [D]: a wave's two row slots (xor 32) -> workgroup (LDS), fixed order
-  dbacc.x += __shfl_xor(dbacc.x, 32, 64); dbacc.y += __shfl_xor(dbacc.y, 32, 64);
-  dbacc.z += __shfl_xor(dbacc.z, 32, 64); dbacc.w += __shfl_xor(dbacc.w, 32, 64);
-  if (lane < 32) *reinterpret_cast<float4*>(L.red + wave * D + 4 * c4) = dbacc;
-  __syncthreads();
-  if (tid < D) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < SW; ++w) s += L.red[w * D + tid];
-    db_slabs[(size_t)blockIdx.x * D + tid] = s;
-  }
-}
-
-// =====================================================================================================
-// graph part of the backward for 64-wide layers (the reference's own regime: 56-184 atoms, D = 64): the kernel above
-// with the layer width and the workgroup size as parameters
-// =====================================================================================================
-// A 64-wide tile of a <= 128-node graph is 35 KB: four workgroups of 4 waves fit a CU, so the per-graph phases of four
-// graphs overlap (the 128-wide form above runs one 16-wave workgroup per CU).  <= 224 nodes: 8 waves, two per CU.
+// here); otherwise exactly one tensor is read.  Per graph: rows -> registers (requested one graph ahead), CSR build of the
+// transpose, G rows scaled by dinv into an LDS tile, wavefront segmented sum out of LDS, row-contiguous stores.
+// The sums never mix columns, so a layer is handled in independent 64-column groups (blockIdx.y): a 64-wide tile of a
+// <= 128-node graph is 35 KB -- four workgroups of 4 waves share a CU and the per-graph phases of four graphs overlap
+// (<= 224 nodes: 8 waves, two per CU).  (The first form kept a 128-wide tile, 106 KB = ONE 16-wave workgroup per CU whose
+// phases ran back to back: 70 us per launch on C5 against ~55 now; a second register slot for the rows of graph g + 1,
+// requested before graph g's CSR build, only moved its wait: the load issue blocks behind the previous graph's stores.)
 template <int D, int NT, int NMAX>
 struct GS {
   static constexpr int LPR = D / 4, RPP = NT / LPR, RPT = (NMAX + RPP - 1) / RPP, TS = D + 4, NW = NT / 64;
@@ -869,14 +751,14 @@ struct GS {
   // this thread's share of a graph's rows: rows rg, rg + RPP, ... (rg = tid / LPR), columns 4 c4 .. 4 c4 + 3 (c4 = tid % LPR)
   struct Rows {
     float4 v[RPT];
-    __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi) {
+    __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi, int ld) {
       const int rg = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
-      const float* base = src + (size_t)gi.nld * D + 4 * c4;
+      const float* base = src + (size_t)gi.nld * ld + 4 * c4;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
         if (j * RPP < gi.n) {                     // block-uniform guard, clamped address: no per-lane branch around the load
           const int row = rg + RPP * j;
-          v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * D);
+          v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * ld);
         }
       }
     }
@@ -999,7 +881,10 @@ template <int D, int NT, int NMAX, bool POOLG, bool TWO>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb, const float* __restrict__ a_out,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr, int B,
-    int npad, float slope, int act_here, float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status) {
+    int npad, float slope, int act_here, float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status, int ld) {
+  // `ld` = row length of the tensors (a layer `ld` columns wide is handled as ld / D independent column groups, blockIdx.y:
+  // the sums never mix columns, and D = 64 column groups of a 128-wide layer leave room for two workgroups per CU)
+  const int coff = blockIdx.y * D;
   using G = GS<D, NT, NMAX>;
   constexpr int LPR = G::LPR, RPP = G::RPP, RPT = G::RPT, TS = G::TS, NW = G::NW;
   constexpr bool NEED_A = POOLG || TWO;
@@ -1017,13 +902,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
   auto request = [&](int g) {                          // everything of graph g this thread will need: loads only
     gnext = seg_graph(g, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
-    if (!POOLG) drows.load(dout, gnext);
-    if (NEED_A) arows.load(a_out, gnext);
+    if (!POOLG) drows.load(dout + coff, gnext, ld);
+    if (NEED_A) arows.load(a_out + coff, gnext, ld);
     if (POOLG) {
-      const size_t eb = (size_t)g * 2 * D + 4 * c4;
+      const size_t eb = (size_t)g * 2 * ld + coff + 4 * c4;      // [max | mean], each ld wide
       gmx = *reinterpret_cast<const float4*>(emb + eb);
       dmx = *reinterpret_cast<const float4*>(demb + eb);
-      dmean = *reinterpret_cast<const float4*>(demb + eb + D);
+      dmean = *reinterpret_cast<const float4*>(demb + eb + ld);
     }
   };
   if ((int)blockIdx.x < B) request(blockIdx.x);
@@ -1081,7 +966,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
         const int rr = valid ? row : gi.n - 1;
         const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
         const float4 acc = G::row_sum(tile, L.col, rr, kb, ke, c4);
-        if (valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + row) * D + 4 * c4) = f4_scale(L.dinv[rr], acc);
+        if (valid) *reinterpret_cast<float4*>(Z + (size_t)(gi.nbase + row) * ld + coff + 4 * c4) = f4_scale(L.dinv[rr], acc);
       }
     }
     __syncthreads();   // the tile, the CSR and the tie scratch are free for the next graph
@@ -1094,7 +979,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += L.red[w * D + tid];
-    db_slabs[(size_t)blockIdx.x * D + tid] = s;
+    db_slabs[(size_t)blockIdx.x * ld + coff + tid] = s;
   }
 }
 
@@ -1145,7 +1030,7 @@ TallWs tall_carve(void* ws, int64_t N, int64_t B, int64_t F, int64_t D) {
   TallWs t;
   const size_t o1 = hcg_align_up((size_t)N * D * sizeof(float), 256);
   const size_t o2 = o1 + hcg_align_up((size_t)dw_grid(N, D) * D * tall_fpad(F) * sizeof(float), 256);
-  const size_t o3 = o2 + hcg_align_up((size_t)(D == 64 ? seg_grid64(B) : seg_grid(B)) * D * sizeof(float), 256);
+  const size_t o3 = o2 + hcg_align_up((size_t)seg_grid64(B) * D * sizeof(float), 256);
   char* p = (char*)ws;
   t.inter = (float*)p;
   t.dw_slabs = p ? (float*)(p + o1) : nullptr;
@@ -1237,16 +1122,17 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const TallWs ws = tall_carve(workspace, N, B, F, D);
   const int act_here = apply_act & 1;
-  if (D == 64) {
-    const int npad = seg_npad(max_nodes), fp = tall_fpad(F);
-    const dim3 sgrid(seg_grid64(B));
+  {   // ---- dH = Ahat^T (dA . leaky'), db slabs: 64-column groups (one for D = 64, two for D = 128: blockIdx.y)
+    const int npad = seg_npad(max_nodes);
+    const dim3 sgrid(seg_grid64(B), (unsigned)(D / 64));
     const size_t slds = (size_t)npad * (64 + 4) * sizeof(float);
 #define LAUNCH_GSEG(NTV, NMAXV, PG, TW2, AOUT)                                                                             \
   do {                                                                                                                     \
     hipError_t e = allow_lds<k_gseg_bwd<64, NTV, NMAXV, PG, TW2>>((size_t)NMAXV * 68 * sizeof(float));                    \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
     hipLaunchKernelGGL((k_gseg_bwd<64, NTV, NMAXV, PG, TW2>), sgrid, dim3(NTV), slds, stream, dout, demb, emb, AOUT,       \
-                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);   \
+                       edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status,   \
+                       (int)D);                                                                                            \
   } while (0)
 #define DISPATCH_GSEG(NTV, NMAXV)                                                                                          \
   do {                                                                                                                     \
@@ -1258,6 +1144,9 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
 #undef DISPATCH_GSEG
 #undef LAUNCH_GSEG
     HCG_CHECK_LAUNCH();
+  }
+  if (D == 64) {
+    const int fp = tall_fpad(F);
     {   // dW slabs = dH^T x
       const dim3 grid(dw_grid(N, 64)), blk(DWT);
       const bool xvec = (F % 4) == 0 && ((uintptr_t)x % 16) == 0;
@@ -1291,24 +1180,6 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
     }
     return HCG_OK;
   }
-  const dim3 sgrid(seg_grid(B)), sblk(SN);
-  const int npad = seg_npad(max_nodes);
-  const size_t slds = seg_tile_bytes(npad), slds_max = seg_tile_bytes(SEG_MAX_NODES);
-  {
-    hipError_t e = poolg ? allow_lds<k_seg_bwd<true, false>>(slds_max)
-                         : (act_here ? allow_lds<k_seg_bwd<false, true>>(slds_max) : allow_lds<k_seg_bwd<false, false>>(slds_max));
-    if (e != hipSuccess) return hcg_hip_err(e);
-  }
-  if (poolg)
-    hipLaunchKernelGGL((k_seg_bwd<true, false>), sgrid, sblk, slds, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
-                       edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);
-  else if (act_here)
-    hipLaunchKernelGGL((k_seg_bwd<false, true>), sgrid, sblk, slds, stream, dout, demb, emb, out, edge_index, E, graph_ptr,
-                       edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status);
-  else
-    hipLaunchKernelGGL((k_seg_bwd<false, false>), sgrid, sblk, slds, stream, dout, demb, emb, (const float*)nullptr, edge_index,
-                       E, graph_ptr, edge_ptr, (int)B, npad, slope, 0, ws.inter, ws.db_slabs, status);
-  HCG_CHECK_LAUNCH();
   const int fp = tall_fpad(F);
   // dW slabs = dH^T x
   {
@@ -1361,7 +1232,7 @@ extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_byte
   j->seg[0] = hcg_reduce_seg{0, (int32_t)(D * fp), fp, (int32_t)F, dW};
   j = job_host + 1;
   j->slabs = ws.db_slabs;
-  j->nslabs = D == 64 ? seg_grid64(B) : seg_grid(B);
+  j->nslabs = seg_grid64(B);
   j->slab_floats = (int32_t)D;
   j->nseg = 1;
   j->reserved = 0;
