@@ -531,7 +531,8 @@ def main():
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
     mid = r0.sb.max_nodes > 32
     # 128-wide layers over large graphs run through csrc/tall.hip (one entry point = up to three launches)
-    tall = mid and bool(lib.hcg_tall_supported(D, D, r0.sb.max_nodes, r0.sb.max_edges))
+    from hcatgnet_amd import functional as _HF
+    tall = mid and bool(lib.hcg_tall_supported(D, D, r0.sb.max_nodes, r0.sb.max_edges)) and (D != 64 or N >= _HF.TALL_MIN_NODES_D64)
     fam = "hcg_tall" if tall else "hcg_mid"
     entry = args.roofline_entry or ((f"{fam}_layer_fwd" if mid else "hcg_fused_stack2_fwd") if args.forward_only
                                     else (f"{fam}_layer_bwd" if mid else "hcg_fused_layer_bwd"))

@@ -376,10 +376,18 @@ class _TallLayerFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None
 
 
+# 64-wide layers: the three-launch backward of csrc/tall.hip pays off once a batch fills the chip; the reference's own
+# batch of 40 graphs (3.5 k nodes: launch-bound) is 11 % faster on the one-launch kernel of csrc/mid.hip (measured: 0.072
+# vs 0.080 ms/step, profiles/r02_c vs r02_e REAL40)
+TALL_MIN_NODES_D64 = 32768
+
+
 def tall_supported(plan: BatchPlan, F: int, D: int) -> bool:
     """True when the kernels of csrc/tall.hip apply to this plan / layer shape (D = 128; D = 64 over graphs > 64 nodes)."""
     if (plan.mode != "blocked" or plan.ew_csr is not None or plan.max_nodes is None or plan.max_edges is None
             or plan.B == 0 or plan.N == 0):
+        return False
+    if D == 64 and plan.N < TALL_MIN_NODES_D64:
         return False
     return bool(_lib.load().hcg_tall_supported(F, D, plan.max_nodes, plan.max_edges))
 

@@ -23,11 +23,12 @@ def _convs(m):
                                                                   # 64-wide layers (the reference's own regime): the backward only
                                                                   (87, 30, 25, 5, 4, 131, 12, 64), (150, 34, 32, 8, 4, 131, 9, 64),
                                                                   (60, 27, 64, 4, 4, 131, 15, 64), (100, 92, 25, 6, 6, 131, 12, 64)])
-def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, nodes, jitter, feat, extra, deg, B, seed, D):
+def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, monkeypatch, nodes, jitter, feat, extra, deg, B, seed, D):
     """Forward with the pooled epilogue, both backward variants (pooled gradient + dx, dout without dx), every K padding
     (32 / 64 / 128, incl. widths that are no multiple of 32 or of 4), ragged batches (graphs of 8 .. 200 nodes side by side);
     D = 64: 4-wave workgroups up to 128 nodes, 8-wave ones above."""
     from hcatgnet_amd import functional as HF, synth
+    monkeypatch.setattr(HF, "TALL_MIN_NODES_D64", 0)      # (these batches are small: the host would keep 64-wide layers on mid.hip)
     sb = synth.make_batch(num_graphs=B, nodes=nodes, extra_bonds=extra, max_degree=deg, feat=feat, nodes_jitter=jitter, seed=seed)
     params = _rand_params(feat, D, seed=31)
     _, _, acts0 = oracle.gcn_forward(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, return_intermediates=True)
