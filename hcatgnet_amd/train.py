@@ -637,6 +637,10 @@ class FusedTrainStep:
         the optimiser's flat parameter / moment storages."""
         cap = self._bufs.get("cap")
         fp = [t.data_ptr() for t in cap["acts"] + cap["dacts"]] if cap else []
+        if cap:      # kernel workspaces (slabs, pooled bits, the wide-layer kernels' dH buffer): they grow on demand
+            fp += [(k if isinstance(k, (str, int)) else str(k), t.data_ptr()) for k, t in sorted(cap["ws"].items(), key=lambda kv: str(kv[0]))
+                   if torch.is_tensor(t)]
+            fp.append(cap["ws_head"].data_ptr())
         fp.append(self._flat.data_ptr() if getattr(self, "_flat", None) is not None else 0)
         fl = getattr(self.model.optimizer, "_flat", {}).get(0) if self.optimizer_step else None
         if fl is not None:

@@ -95,13 +95,13 @@ def test_tall_input_gradient_and_edge_cases(H, oracle):
         assert rel_inf(v.grad, o_grads[k]) <= TOL, k
 
 
-def test_tall_backward_hands_down_a_premasked_dx(H):
+@pytest.mark.parametrize("D,feat", [(128, 128), (64, 64)])
+def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
     """apply_act bit 1 of hcg_tall_layer_bwd: dx leaves multiplied by LeakyReLU'(x); the layer below then runs with bit 0
     clear and out = NULL.  One f32 multiply moved across a launch boundary: bitwise the plain sequence."""
     from hcatgnet_amd import synth, _lib
     from hcatgnet_amd.plan import BatchPlan
     lib, p = _lib.load(), _lib.ptr
-    D, feat = 128, 128
     sb = synth.make_config("C2", num_graphs=70, nodes=90, seed=4)
     b = sb.as_batch("cuda")
     plan = BatchPlan.build(b.edge_index, b.batch, b.x.shape[0], num_graphs=b.num_graphs, mode="blocked",
