@@ -66,12 +66,14 @@ def test_tall_layers_vs_oracle_mid_and_general_path(H, oracle, monkeypatch, node
     assert torch.equal(out_t, out_2) and torch.equal(emb_t, emb_2) and all(torch.equal(g_t[k], g_2[k]) for k in g_t)
 
 
-def test_tall_input_gradient_and_edge_cases(H, oracle):
+@pytest.mark.parametrize("D,F", [(128, 32), (64, 25)])
+def test_tall_input_gradient_and_edge_cases(H, oracle, monkeypatch, D, F):
     """dx of the first layer, multi-edges, explicit self loops, an isolated node, a one-node graph and empty graph slots
     (one of them LAST in the batch) next to a 150-node graph."""
     from hcatgnet_amd import synth, functional as HF
+    monkeypatch.setattr(HF, "TALL_MIN_NODES_D64", 0)
     g = torch.Generator().manual_seed(4)
-    nbig, F = 150, 32
+    nbig = 150
     big = synth.make_batch(num_graphs=1, nodes=nbig, extra_bonds=6, max_degree=4, feat=F, seed=2)
     xs = [big.x, torch.randn(1, F, generator=g), torch.randn(5, F, generator=g)]
     e_small = torch.tensor([[0, 1, 1, 2, 2, 2, 3], [1, 0, 2, 1, 2, 1, 3]], dtype=torch.int64)   # multi-edge, two self loops; node 4 isolated
@@ -80,11 +82,11 @@ def test_tall_input_gradient_and_edge_cases(H, oracle):
     bv = torch.cat([torch.zeros(nbig, dtype=torch.int64), torch.ones(1, dtype=torch.int64), torch.full((5,), 3, dtype=torch.int64)])
     B = 5                                              # graphs 2 and 4 are empty slots
     y = torch.randn(B, generator=g)
-    params = _rand_params(F, 128, seed=37)
+    params = _rand_params(F, D, seed=37)
     m = _model_from_params(H, params)
     xd = x.cuda().requires_grad_(True)
     plan = H.BatchPlan.build(ei.cuda(), bv.cuda(), x.shape[0], num_graphs=B, mode="blocked")
-    assert HF.tall_supported(plan, F, 128)
+    assert HF.tall_supported(plan, F, D)
     out = m(x=xd, edge_index=ei.cuda(), batch_index=bv.cuda(), plan=plan)
     torch.sqrt(m.loss(out, y.cuda().unsqueeze(1))).backward()
     assert plan.check_status() == 0
