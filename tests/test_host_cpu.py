@@ -132,12 +132,34 @@ def test_fused_train_step_support_check_is_host_only():
     assert "shape" in FusedTrainStep.unsupported_reason(m, mk(max_nodes=300, max_edges=700, edges_grouped=True))
     assert "metadata" in FusedTrainStep.unsupported_reason(m, mk())
     assert "targets" in FusedTrainStep.unsupported_reason(m, H.Batch(x, ei, bv, 1, max_nodes=30, max_edges=64, edges_grouped=True))
-    wide = H.make_network("GCN", H.default_options(embedding_dim=128), 25)       # 128-d: any-shape head inside the same step
+    wide = H.make_network("GCN", H.default_options(embedding_dim=128), 25)       # 128-d: one-launch head since round 2
     assert FusedTrainStep.unsupported_reason(wide, mk(max_nodes=200, max_edges=424, edges_grouped=True)) is None
     odd = H.make_network("GCN", H.default_options(embedding_dim=96), 25)         # no conv kernel family covers D = 96
     assert "shape" in FusedTrainStep.unsupported_reason(odd, mk(max_nodes=30, max_edges=64, edges_grouped=True))
     deep = H.make_network("GCN", H.default_options(readout_layers=3), 25)
     assert "readout" in FusedTrainStep.unsupported_reason(deep)
+
+
+def test_kernel_family_selection_is_host_only():
+    """Which kernel family takes a layer is decided on the host from (F, D, largest graph): 128-wide layers over graphs up
+    to 224 nodes -> csrc/tall.hip when F is a multiple of 4; 64-wide layers over graphs of 65 .. 224 nodes -> its backward,
+    but only for batches that fill the chip (`functional.TALL_MIN_NODES_D64`); everything up to 64 nodes stays with the
+    one-graph-per-wave kernels."""
+    from types import SimpleNamespace
+    from hcatgnet_amd import _lib, functional as HF
+    lib = _lib.load()
+    assert lib.hcg_tall_supported(128, 128, 200, 424) == 1 and lib.hcg_tall_supported(28, 128, 159, 330) == 1
+    assert lib.hcg_tall_supported(126, 128, 200, 424) == 0          # rows of x not 16-byte aligned: the forward needs float4 rows
+    assert lib.hcg_tall_supported(25, 64, 117, 250) == 1 and lib.hcg_tall_supported(64, 64, 184, 390) == 1
+    assert lib.hcg_tall_supported(25, 64, 60, 130) == 0             # <= 64 nodes: one graph per wave
+    assert lib.hcg_tall_supported(25, 64, 225, 500) == 0 and lib.hcg_tall_supported(25, 64, 117, 1025) == 0
+    assert lib.hcg_tall_supported(25, 96, 117, 250) == 0
+    assert lib.hcg_tall_workspace_bytes(1000, 10, 25, 64) > 1000 * 64 * 4 and lib.hcg_tall_workspace_bytes(1000, 10, 25, 96) == 0
+    plan = lambda N: SimpleNamespace(mode="blocked", ew_csr=None, max_nodes=117, max_edges=250, B=40, N=N)
+    assert not HF.tall_supported(plan(3473), 25, 64)                # the reference's batch of 40 graphs: launch-bound, stays on mid.hip
+    assert HF.tall_supported(plan(356553), 25, 64)
+    assert HF.tall_supported(SimpleNamespace(mode="blocked", ew_csr=None, max_nodes=200, max_edges=424, B=24, N=4800), 128, 128)
+    assert lib.hcg_head_supported(64, 1) == 1 and lib.hcg_head_supported(128, 8) == 1 and lib.hcg_head_supported(96, 1) == 0
 
 
 def test_base_network_dispatch_mirrors_the_reference():
