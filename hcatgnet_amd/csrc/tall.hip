@@ -538,15 +538,14 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // Measured on C5 (tools/probe_seg.hip, per 200-node graph): CSR 2.3 us, MFMA phase 14 us (its MFMAs alone: 5.9 us -- the
 // barrier per k-step keeps all 16 waves in the same phase, so splitting, LDS traffic and MFMAs add up instead of
 // overlapping), sums + stores 9 us: 110 us per layer against 119 us for k_tall_mm + the unfused form, with half the HBM
-// traffic.  What bounds the MFMA phase is vector issue, not the barriers or the matrix pipes: four waves per SIMD each spend
-// ~100 vector instructions per k-step (their own split of the A fragment, addressing, LDS reads) -- 32-column chunks (half
-// the barriers) changed nothing; one wave per row block with all four column blocks (one split per 24 MFMAs) needs 64
-// accumulator registers and spilled 145 at the 128 the 16-wave workgroup allows (1.5x slower); the same mapping as an 8-wave
-// kernel with 256 registers (no spills, 7 MFMA waves) measured 120 us per layer: its MFMA phase still took 16 us per graph
-// (9.5 us with the MFMAs removed, 14.5 us with the weight loads removed), its sums' phase 12 us on 8 waves -- with two waves
-// per SIMD the LDS latencies, the split and the MFMA chains of a k-step run in series.  A second workgroup per CU does not
-// fit 160 KB beside the tile.  PMC (profiles/r02_d_traffic_C5.txt): 307 MB per launch for 210 MB of operands -- the 9-33
-// spilled registers of this variant and the weight chunks that miss L2.
+// traffic.  The MFMA phase costs ~3.5 k cycles per k-step against 1.3 k of matrix-pipe time, whatever was tried:
+// 32-column chunks (half the barriers); one wave per row block with all four column blocks (one split per 24 MFMAs) -- 145
+// spilled registers at the 128 the 16-wave workgroup allows (1.5x slower), and as an 8-wave kernel with 256 registers
+// 120 us per layer (phase: 16 us per graph, 9.5 with the MFMAs compiled out, 14.5 with the weight loads compiled out); two
+// 64-column groups per graph in two 8-wave workgroups per CU with the A fragments from global memory: 109 / 115 us.
+// The chain barrier -> LDS turn-around of the next weight chunk -> dependent MFMA chains per k-step is what they share; a
+// resident weight image would remove it and does not fit beside the tile.  PMC (profiles/r02_e_traffic_C5.txt): ~300 MB
+// per launch for 210 MB of operands -- the 9-33 spilled registers of this kernel and weight chunks that miss L2.
 template <bool POOL>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,
