@@ -1,24 +1,25 @@
-// Wide layers over LARGE graphs (embedding_dim 128, ~200-atom ligands: BASELINE configs[4]): the layer as a DENSE
-// row-streaming transform over all nodes of the batch + a per-graph segmented sum, instead of one graph per workgroup.
+// Layers cut by what needs the graph and what does not: dense row-streaming parts over ALL nodes of the batch + per-graph
+// parts that keep a whole tile in LDS.  Two uses:
+//   * 128-wide layers over large graphs (embedding_dim 128, ~200-atom ligands: BASELINE configs[4]), forward and backward;
+//   * the BACKWARD of 64-wide layers over graphs of 65 .. 224 nodes (the reference's own regime: 56-184 atoms, F = 25 / 32).
 //
 // Why a second family beside mid.hip.  A 200-node x 128-d graph does not fit a workgroup's LDS with its weights (x tile
 // 102 KB + H' tile 102 KB + the pre-split weight image 98 KB of 160 KB), so mid.hip runs such a layer as two 64-column
 // launches of ONE workgroup per CU whose phases (stage x, CSR, MFMA, segmented sum, store) run back to back: ~10 us per
-// graph and half, 16-18 % of the step's HBM roofline (profiles/r02_c_*).  Here the dense part has no graph structure at
-// all, so it streams: every wave owns 32 consecutive node rows, keeps the whole 128 x 128 weight image in LDS, reads its
-// A fragments straight from global memory (the next chunk's loads in flight under the current chunk's MFMAs) and never
-// meets a barrier after the prologue.  The graph part keeps only the CSR in LDS (~10 KB: 8+ workgroups per CU), gathers
-// neighbour rows from L2 (a graph's rows are touched ~3x within microseconds) and carries the fused epilogues:
+// graph and half, 16-18 % of the step's HBM roofline on C5 (profiles/r02_c_*); its backward (dY' tile, dH tile, dW and dX
+// on the matrix cores, all per graph) is the same chain at 23-24 % on the reference's graph sizes.
 //
-//   forward   H  = X W^T (LDS tile only), out = LeakyReLU(Ahat H + b), [max, mean] pool      k_split_weight + k_seg_fwd
-//             (split-bf16 MFMAs, f32 accuracy: split_mfma.h)
-//   backward  dH = Ahat^T (dA (.) leaky'(A)),  db slabs           k_seg_bwd  (dA = dout, or the pooled gradient expanded on chip)
-//             dX = dH W  (optionally premasked with leaky'(X))    k_tall_mm  (transposed image)
-//             dW slabs = dH^T X                                   k_tall_dw
+//   forward   H' = dinv . (x W^T) into an LDS tile, out = LeakyReLU(Ahat H' + b), [max, mean] pool   k_split_weight + k_seg_fwd
+//   backward  dH = Ahat^T (dA (.) leaky'(A)),  db slabs     k_gseg_bwd  (dA = dout, or the pooled gradient expanded on chip;
+//                                                                        independent 64-column groups, 2-4 workgroups per CU)
+//             dW slabs = dH^T X                             k_tall_dw   (no graph structure: 64-row tiles of all nodes)
+//             dX = dH W  (optionally premasked)             k_tall_mm   (no graph structure: 32-row blocks, image resident)
 //
-// Arithmetic per element is the one of mid.hip (H' = dinv . H, self term first, neighbours by ascending id, one scale by
-// dinv_i at the end), so both families agree to f32 rounding of the GEMM only.  The price is HBM traffic: H and dH make a
-// round trip (they mostly hit the 256 MB Infinity Cache: written and read back within ~100 us).
+// All contractions are split-bf16 MFMAs at f32 accuracy (split_mfma.h).  Arithmetic per element is the one of mid.hip
+// (H' = dinv . H, self term first, neighbours by ascending id, one scale by dinv_i at the end), so both families agree to
+// f32 rounding of the GEMM only; every reduction has a fixed order (run-to-run bitwise).  The price of the cut is HBM
+// traffic in the backward: dH makes a round trip (written once, read by both dense kernels).  What bounds each kernel and
+// what was tried: DESIGN.md 4.2c.
 // Reference: the same PyG GCNConv call sites as mid.hip (model/gcn.py:58-63), `loss.backward()` utils/utils_model.py:65.
 #include "common.h"
 #include "split_mfma.h"
@@ -321,13 +322,14 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
 }
 
 // =====================================================================================================
-// graph part: one graph per workgroup iteration, 16 waves (the whole CU); the graph's rows sit in ONE LDS tile
+// graph part of the 128-wide forward: one graph per workgroup iteration, 16 waves (the whole CU); the graph's rows sit in ONE
+// LDS tile
 // =====================================================================================================
-// A 200-node x 128-d graph is 102 KB: it fits LDS once (not twice, and not beside a weight image -- which is why the dense
-// part runs apart).  Per graph: rows -> registers (requested one graph AHEAD, under the previous graph's sums), CSR build,
-// rows scaled by dinv into the tile, wavefront segmented sum out of LDS (32 lanes x float4 per row, 32 rows per pass),
-// epilogue, row-contiguous 512-byte stores.  Gathering the neighbour rows from L2 instead (one workgroup of 4 waves per
-// graph, 4 workgroups per CU) was measured first: 59-93 us per launch on C5, every pass a dependent L2 round trip.
+// A 200-node x 128-d graph is 102 KB: it fits LDS once (not twice, and not beside a weight image).  Per graph: x rows ->
+// registers (requested one graph AHEAD, under the previous graph's sums), CSR build, x rows -> tile, H' on the matrix cores
+// back into the tile, wavefront segmented sum out of LDS (32 lanes x float4 per row, 32 rows per pass), epilogue,
+// row-contiguous 512-byte stores.  (Gathering neighbour rows of a dense H = x W^T from L2 instead -- one workgroup of 4
+// waves per graph, 4 per CU -- was the first form: 59-93 us per launch on C5, every pass a dependent L2 round trip.)
 #ifdef HCG_SEG_STAMP      // tools/probe_seg.hip: s_memtime stamps of the per-graph phases
 __device__ unsigned long long g_seg_stamp[8 * 8 * 8];      // [block < 8][graph iteration < 8][phase < 8]
 #define SSTAMP(it, ph) do { if (threadIdx.x == 0 && blockIdx.x < 8 && (it) < 8) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); g_seg_stamp[(blockIdx.x * 8 + (it)) * 8 + (ph)] = _t; } } while (0)
@@ -341,7 +343,7 @@ constexpr int SEG_D = 128, SEG_TS = SEG_D + 4;
 constexpr int SEG_RPT = SEG_MAX_NODES * (SEG_D / 4) / SN;      // float4 per thread to hold one graph's rows (7)
 static_assert(SEG_MAX_EDGES == SN && SEG_MAX_NODES * (SEG_D / 4) % SN == 0, "thread maps");
 
-template <bool WITH_RED>
+template <bool WITH_RED>      // (k_seg_fwd keeps its combine scratch in the weight-chunk buffers: WITH_RED = false)
 struct SegLdsT {
   int rowptr[SEG_MAX_NODES + 4];
   int cursor[SEG_MAX_NODES];
