@@ -463,6 +463,8 @@ def test_fused_train_step_embedding_dim_128(H, oracle, combine):
     assert rel_inf(step.last_out, out_ref, floor=1.0) <= TOL
     for name, prm in m.named_parameters():
         assert rel_inf(prm.grad, g_ref[name]) <= TOL, name
+    l_eval = step.evaluate(sb.as_batch("cuda"))              # forward + loss only (the reference's eval_network body)
+    assert abs(float(l_eval) - float(l_ref)) <= TOL * abs(float(l_ref))
     # with the update, captured: three replays follow three eager steps of a twin
     twin = H.make_network("GCN", H.default_options(embedding_dim=128), 128).cuda()
     twin.load_state_dict(m.state_dict())
