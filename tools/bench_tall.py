@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hcatgnet_amd as H
 from hcatgnet_amd import synth, _lib
+if os.environ.get("HCG_LIB"):          # a library variant (A/B runs on one box)
+    _lib.LIB_PATH = os.path.abspath(os.environ["HCG_LIB"])
 from hcatgnet_amd.plan import BatchPlan
 name = sys.argv[1] if len(sys.argv) > 1 else "C5"
 ng = int(sys.argv[2]) if len(sys.argv) > 2 else None
