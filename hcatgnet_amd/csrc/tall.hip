@@ -336,6 +336,12 @@ __device__ unsigned long long g_seg_stamp[8 * 8 * 8];      // [block < 8][graph 
 #else
 #define SSTAMP(it, ph) do { } while (0)
 #endif
+#ifdef HCG_SEG_KSTAMP     // tools/probe_seg.hip: stamps inside the k-loop of the first workgroups (wave 0)
+__device__ unsigned long long g_seg_kstamp[4 * 2 * 8 * 6];   // [block < 4][graph iteration < 2][k-step < 8][point < 6]
+#define KSTAMP(it, ks, pt) do { if (threadIdx.x == 0 && blockIdx.x < 4 && (it) < 2 && (ks) < 8) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); g_seg_kstamp[((blockIdx.x * 2 + (it)) * 8 + (ks)) * 6 + (pt)] = _t; } } while (0)
+#else
+#define KSTAMP(it, ks, pt) do { } while (0)
+#endif
 constexpr int SN = 1024, SW = SN / 64;
 constexpr int SEG_MAX_NODES = 224;    // (same limits as mid.hip: every batch one family takes, the other takes too)
 constexpr int SEG_MAX_EDGES = 1024;   // one edge per thread
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
       // instructions of splitting at the same time, with the matrix pipes idle
       Split3 As = split_a(0);
       for (int ks = 0; ks < KS; ++ks) {
+        KSTAMP(sit, ks, 0);
         if (ks + 2 < KS && wcopy) wreg2 = *reinterpret_cast<const u32x4*>(wsrc + (size_t)(ks + 2) * WCH);
         if (active) {
           const short* wb = wl + (ks & 1) * WCH + (ch * 64 + r) * 16 + ((h ^ ((r >> 3) & 1)) * 8);
@@ -635,10 +642,14 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
             mfma_split(acc[nb], As, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + 128 * 16),
                        *reinterpret_cast<const bf16x8*>(w0 + 2 * 128 * 16));
           }
+          KSTAMP(sit, ks, 1);
           if (ks + 1 < KS) As = split_a(ks + 1);
+          KSTAMP(sit, ks, 2);
         }
         if (ks + 1 < KS && wcopy) *reinterpret_cast<u32x4*>(wdst + ((ks + 1) & 1) * WCH) = wreg;   // (that buffer's readers passed the last barrier)
+        KSTAMP(sit, ks, 3);
         __syncthreads();
+        KSTAMP(sit, ks, 4);
         wreg = wreg2;
       }
       // (the loop's last barrier: every A fragment has been read -- the accumulators may now overwrite the tile)

@@ -47,6 +47,20 @@ int main() {
   float ms; CKH(hipEventElapsedTime(&ms, e0, e1));
   int st; CKH(hipMemcpy(&st, dstatus, 4, hipMemcpyDeviceToHost));
   printf("k_seg_fwd<pool>: %.1f us (status %d, E %d)\n", ms * 1000.f / 50, st, E);
+#ifdef HCG_SEG_KSTAMP
+  {
+    unsigned long long ks[4 * 2 * 8 * 6];
+    CKH(hipMemcpyFromSymbol(ks, HIP_SYMBOL(g_seg_kstamp), sizeof(ks)));
+    for (int b = 0; b < 2; ++b)
+      for (int it = 0; it < 2; ++it) {
+        printf("block %d graph %d k-steps (ticks: top -> MFMAs issued -> next A split -> chunk stored -> barrier passed):\n", b, it);
+        for (int k = 0; k < 8; ++k) {
+          const unsigned long long* q = ks + ((b * 2 + it) * 8 + k) * 6;
+          printf("   ks %d: %6llu %6llu %6llu %6llu   (k-step total %llu)\n", k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[4] - q[0]);
+        }
+      }
+  }
+#endif
 #ifdef HCG_SEG_STAMP
   unsigned long long stamp[8 * 8 * 8];
   CKH(hipMemcpyFromSymbol(stamp, HIP_SYMBOL(g_seg_stamp), sizeof(stamp)));
