@@ -1,0 +1,26 @@
+"""Random shapes around the kernels' own boundaries through whichever kernel family the host picks (tools/fuzz_families.py),
+one training step each, against the any-shape GPU path: fixed seeds, so the cases are the same on every run."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tool():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_families.py")
+    spec = importlib.util.spec_from_file_location("fuzz_families", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("small,seed", [(False, 3), (True, 5)])
+def test_random_shapes_match_the_any_shape_path(small, seed):
+    """`small`: 64-wide layers over 1..130-node graphs (fused.hip / wave.hip / mid.hip); else 65..224-node graphs, 64- and
+    128-wide (tall.hip).  Batches the screens throw out (near-ties, activations at the LeakyReLU kink) do not count."""
+    lines = []
+    ran, skipped, failed = _tool().run(cases=60, seed=seed, small=small, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert not failed, "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert ran >= 25, (ran, skipped)
