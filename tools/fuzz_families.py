@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool: random shapes through the wide-layer kernels (csrc/tall.hip) against the any-shape GPU path -- forward, pooled
-embedding and every gradient of one training step.  Shapes are drawn around the kernels' own boundaries (64 / 65 / 128 / 129 /
+embedding and every gradient of one training step, through the autograd path AND through `train.FusedTrainStep`.  Shapes are drawn around the kernels' own boundaries (64 / 65 / 128 / 129 /
 224 nodes per graph, node counts that are no multiple of the 32- and 64-row tiles, 1..33 graphs, every K padding).  Batches
 with a near-tie in the max pooling or an activation within rounding of the LeakyReLU kink are skipped (there the arg-max / the
 slope may legitimately differ between two summation orders: seed 0's case 14 was one such activation, 8e-9 in fp64).
@@ -15,6 +15,7 @@ from hcatgnet_amd import functional as HF, synth
 from tests.helpers import rel_inf
 from tests.test_gpu_parity import _model_from_params, _rand_params, _step_grads, TOL_DW
 from tests.test_gpu_mid import _near_ties
+from hcatgnet_amd.train import FusedTrainStep
 
 def run(cases=60, seed=0, small=False, log=print):
     """-> (cases run, cases skipped, tags of the failed ones)."""
@@ -74,6 +75,18 @@ def _run(cases, rng, small, log, failed):
         errs.update({k: rel_inf(g_t[k], g_g[k]) for k in g_t})
         ok = st == 0 and errs["emb"] <= 2e-6 and errs["out"] <= 2e-6 and all(errs[k] <= TOL_DW for k in g_t)
         ok = ok and all(torch.isfinite(v).all() for v in g_t.values())
+        # the same batch through the no-autograd training step (train.FusedTrainStep: its own dispatch, workspaces, jobs)
+        step = FusedTrainStep(m, optimizer_step=False)
+        if step.unsupported_reason(m, batch) is None:
+            m.zero_grad()
+            loss = step(batch)
+            st |= plan.check_status()
+            errs["step:out"] = rel_inf(step.last_out, out_g, floor=1.0)
+            errs.update({"step:" + k: rel_inf(v.grad, g_g[k]) for k, v in m.named_parameters()})
+            ok = ok and st == 0 and bool(torch.isfinite(loss)) and errs["step:out"] <= 2e-6 and all(
+                errs["step:" + k] <= TOL_DW for k in g_g)
+        else:
+            log(tag, "-- FusedTrainStep:", step.unsupported_reason(m, batch))
         ran += 1
         if not ok:
             failed.append(tag)
