@@ -265,6 +265,8 @@ def main():
         FusedTrainStep.POOLBITS = False
     if os.environ.get("HCG_NO_PREMASK") == "1":
         FusedTrainStep.PREMASK = False
+    if os.environ.get("HCG_NO_OVERLAP") == "1":
+        FusedTrainStep.OVERLAP_GROUPS = False
     log(f"rank {rank}/{world}: library loaded")
 
     cfg_name = args.config

@@ -57,6 +57,7 @@ class FusedTrainStep:
     # activation derivative to the layer that owns it
     POOLBITS = True
     PREMASK = True
+    OVERLAP_GROUPS = True          # captured size-grouped steps: the two kernel families as two branches of the hipGraph
 
     def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None, combine: str = "mean"):
         if combine not in ("mean", "sse"):
@@ -71,6 +72,7 @@ class FusedTrainStep:
         self._graph = None
         self._sync = {}
         self._capturing_split = False
+        self._side_streams = {}
         # pipelined loaders: a pointers-only `BatchPlan` of the NEXT batch (built once with validate=False); the step's last
         # launch (slab reduction + Adam) re-derives its graph_ptr / edge_ptr from the tensors' current contents, so the next
         # step -- on a batch object that carries that plan (`batch._hcg_plan = plan`) -- starts without a plan launch
@@ -132,6 +134,12 @@ class FusedTrainStep:
                     return "graph / layer shape outside the fused kernels (small-graph tiles and one-graph-per-workgroup)"
         return None
 
+    def _side_stream(self, dev):
+        st = self._side_streams.get(dev)
+        if st is None:
+            st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        return st
+
     # ------------------------------------------------------------------ size-grouped batches: two kernel families per layer
     def _size_groups(self, batch, plan, convs, D, C, n_conv):
         """-> n_small when the batch is size-grouped (`collate(..., group_by_size=True)`: the first n_small graphs have <= 32
@@ -160,6 +168,22 @@ class FusedTrainStep:
         dev, stream, slope = x.device, _lib.stream_ptr(), HF.LEAKY_SLOPE
         mxn, mxe = plan.max_nodes, plan.max_edges
         Bs, Bb = n_small, B - n_small
+        # The two groups' launches touch disjoint rows, graphs and slabs.  While the step is being CAPTURED the larger graphs'
+        # launches go to a second stream, forked before each conv phase and joined behind it = two branches of the hipGraph:
+        # each family's last workgroups fill the CUs the other has already left (neither fills the chip: ~1.4 tiles per wave /
+        # ~0.6 graphs per wave slot at 4096 graphs).  Measured on the ragged bench: replay 0.1975 -> 0.188 ms/step; the eager
+        # step is host-bound and the four extra event calls cost it 0.196 -> 0.215, so eager steps stay on one stream.
+        main_s = torch.cuda.current_stream(dev)
+        side_s = self._side_stream(dev) if (self.OVERLAP_GROUPS and torch.cuda.is_current_stream_capturing()) else None
+        stream_b = ctypes.c_void_p(side_s.cuda_stream) if side_s is not None else stream
+
+        def fork():
+            if side_s is not None:
+                side_s.wait_stream(main_s)
+
+        def join():
+            if side_s is not None:
+                main_s.wait_stream(side_s)
         gp, ep = plan.graph_ptr, plan.edge_ptr
         gp_b, ep_b = gp.data_ptr() + 4 * Bs, ep.data_ptr() + 4 * Bs
         acts, emb, demb = bufs["acts"], bufs["emb"], bufs["demb"]
@@ -172,13 +196,15 @@ class FusedTrainStep:
         poolbits = bufs["ws"].get("poolbits_r")
         if poolbits is None or poolbits.numel() < nb:
             poolbits = bufs["ws"]["poolbits_r"] = torch.empty(int(nb * 1.25), dtype=torch.uint8, device=dev)
+        fork()
         _lib.check(lib.hcg_fused_stack2_fwd_train(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, p(gp), p(ep),
                                                   N, Bs, F, D, gpt, slope, 1, p(acts[0]), p(emb), p(poolbits), p(plan.status), stream),
                    "hcg_fused_stack2_fwd_train")
         _lib.check(lib.hcg_mid_layer_fwd(p(x), p(W[0]), p(bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, F, D, mxn, mxe,
-                                         slope, 1, p(acts[0]), None, p(plan.status), stream), "hcg_mid_layer_fwd")
+                                         slope, 1, p(acts[0]), None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
         _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, D, D, mxn, mxe,
-                                         slope, 1, p(acts[1]), emb_b, p(plan.status), stream), "hcg_mid_layer_fwd")
+                                         slope, 1, p(acts[1]), emb_b, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+        join()
         # ---- head over all graphs
         opt = model.optimizer
         step_word, flat, g = None, None, None
@@ -213,6 +239,7 @@ class FusedTrainStep:
         # ---- conv stack backward, last layer first; each layer: tiles on the small graphs, waves on the others
         premask = bool(self.PREMASK)
         dx = bufs["dacts"][0]
+        fork()
         for l in (1, 0):
             inp = x if l == 0 else acts[0]
             Fl = inp.shape[1]
@@ -230,7 +257,7 @@ class FusedTrainStep:
                                                             off_b, stream), "hcg_fused_layer_bwd_poolbits")
                 _lib.check(lib.hcg_mid_layer_bwd(None, demb_b, emb_b, p(acts[1]), p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b,
                                                  ep_b, N, Bb, Fl, D, mxn, mxe, slope, flags, p(dx), p(plan.status), wsb_ptr, ws_b,
-                                                 stream), "hcg_mid_layer_bwd")
+                                                 stream_b), "hcg_mid_layer_bwd")
             else:
                 act = 0 if premask else 1
                 a_out = p(acts[0]) if act else None
@@ -238,7 +265,7 @@ class FusedTrainStep:
                                                    N, Bs, Fl, D, gpt, slope, act, None, p(plan.status), p(ws), off_b, stream),
                            "hcg_fused_layer_bwd")
                 _lib.check(lib.hcg_mid_layer_bwd(p(dx), None, None, a_out, p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b, ep_b, N,
-                                                 Bb, Fl, D, mxn, mxe, slope, act, None, p(plan.status), wsb_ptr, ws_b, stream),
+                                                 Bb, Fl, D, mxn, mxe, slope, act, None, p(plan.status), wsb_ptr, ws_b, stream_b),
                            "hcg_mid_layer_bwd")
             _lib.check(lib.hcg_fused_reduce_job(p(ws), off_b, N, Bs, Fl, D, gpt, g(convs[l].lin.weight), g(convs[l].bias),
                                                 jaddr + njobs * jb), "hcg_fused_reduce_job")
@@ -246,6 +273,7 @@ class FusedTrainStep:
                        "hcg_mid_reduce_job")
             _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
             njobs += 1
+        join()
         if step_word is not None:
             if self.exchange is not None and self.pre_exchange_hook is not None:
                 self.pre_exchange_hook()

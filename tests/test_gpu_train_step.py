@@ -521,3 +521,6 @@ def test_size_grouped_batch_runs_two_kernel_families(H, oracle, feat, seed):
     for _ in range(3):
         la, lb = float(full.replay()), float(eager(batch))
         assert abs(la - lb) <= 1e-5 * abs(lb)
+    # (the captured step runs the two families as two branches of the graph: same launches, same results)
+    for pa, pb in zip(m.parameters(), twin.parameters()):
+        assert rel_inf(pa, pb) <= 1e-6
