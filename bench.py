@@ -644,10 +644,16 @@ def main():
         try:
             rr = [Resident(100 + i, **ragged_cfg) for i in range(NB)]
             rtr = [FusedTrainStep(model, optimizer_step=True) for _ in rr]
-            for tr, r in zip(rtr, rr):
+            for r in rr:
+                r.make_plan()
+            for i, (tr, r) in enumerate(zip(rtr, rr)):
                 for _ in range(2):
                     tr(r.fresh())
-                tr.capture(r.fresh)
+                # the headline's pipeline: the step's last launch also derives the NEXT batch's plan (--plan-overlap fused)
+                if args.plan_overlap == "fused":
+                    tr.capture(r.planned, next_plan=rr[(i + 1) % NB].plan)
+                else:
+                    tr.capture(r.fresh)
             rfn = lambda i: rtr[i].replay()
             timed(4 * NB, rfn)
             rdt = timed(max(args.steps, 200), rfn)
