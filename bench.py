@@ -109,6 +109,39 @@ def self_launch(args) -> int:
     return rc
 
 
+def isolated_probe(world, rehearsal, combine, timeout_s=300.0):
+    """The one-shot exchange tried once in a CHILD process per rank (`python -m hcatgnet_amd.xgmi`: its own process group on
+    the next port, set-up, self test, 64 free-running real steps) before THIS process touches the GPU.  A failure no `try`
+    can catch -- a GPU memory fault on a peer mapping aborts the process, a wedged launch never returns -- then ends the
+    child, not the bench: -> False, and the RCCL form is what gets measured.  Stdlib only (nothing here may initialise HIP)."""
+    env = dict(os.environ)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child group's rank 0 hosts its own store ...
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) - 1024 + 1) % (65535 - 1024) + 1024)   # ... on the next port
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "hcatgnet_amd.xgmi", "--combine", combine]
+    if rehearsal:
+        cmd += ["--one-device", "--soak-steps", "0"]      # (two ranks on one device starve each other in a free-running soak)
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=sys.stderr, stderr=sys.stderr, start_new_session=True)
+    except OSError as exc:
+        log(f"one-shot exchange probe could not start ({exc}): RCCL form")
+        return False
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, 9)                         # exactly the process group started above
+        except OSError:
+            pass
+        proc.wait()
+        rc = -9
+    log(f"one-shot exchange probe (child process, world {world}): exit {rc} after {time.perf_counter() - t0:.1f} s")
+    return rc == 0
+
+
 class EntryTimer:
     """HIP-event timing of ONE C-ABI entry point on the stream it launches on (torch's current
     stream: the library only enqueues on the stream it is handed)."""
@@ -239,6 +272,12 @@ def main():
                          f"(or run `python bench.py --gpus {args.gpus}` from a bare shell: it starts its own ranks)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1, --exchange auto: the one-shot exchange has to survive a sacrificial child process group first (before anything
+    # here touches the GPU); the ranks combine their verdicts once the real process group is up
+    probe_ok = None
+    if (world > 1 and args.exchange == "auto" and not args.forward_only
+            and (os.environ.get("HCG_BENCH_REHEARSAL") != "1" or os.environ.get("HCG_PROBE_IN_REHEARSAL") == "1")):
+        probe_ok = isolated_probe(world, os.environ.get("HCG_BENCH_REHEARSAL") == "1", args.combine)
 
     import torch
     import torch.distributed as dist
@@ -481,7 +520,13 @@ def main():
         if fused_ok:
             for tr in trainers + [fwdbwd]:
                 dp.attach(tr)
-            if rehearsal and args.exchange == "auto":
+            if probe_ok is not None:       # every rank's child verdict, combined: one failure anywhere = RCCL form everywhere
+                pv = torch.tensor([1 if probe_ok else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(pv, op=dist.ReduceOp.MIN)
+                probe_ok = bool(int(pv.item()))
+            if probe_ok is False:
+                log("one-shot exchange: its probe in a child process group did not pass on every rank -- RCCL all-reduce stays")
+            elif rehearsal and args.exchange == "auto":
                 log("rehearsal (ranks share one device): a polling launch of one rank leaves no room for the other rank's conv "
                     "kernels on the same GPU -- the one-shot exchange needs one GPU per rank; RCCL-form exchange (gloo) here")
             elif args.exchange != "rccl":
@@ -691,6 +736,7 @@ def main():
                        "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
                                       f"of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "rccl_world": rccl_world, "exchange": exchange_mode,
+            "exchange_probe": (None if probe_ok is None else ("passed" if probe_ok else "failed")),   # the child-process trial of the one-shot exchange
             "distinct_batches": NB, "bytes_touched_between_reuse": touched,
             "sustained_s": sus_s, "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3,
                                                 "value": world * B * sus_steps / sus_s if sus_s > 0 else None,

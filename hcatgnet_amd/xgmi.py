@@ -187,3 +187,60 @@ class OneShotExchange:
         if self.inbox:
             self.lib.hcg_xchg_free(self.inbox)
             self.inbox = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the probe: the whole exchange tried once in a SACRIFICIAL process group (`python -m hcatgnet_amd.xgmi`, one per rank)
+# ---------------------------------------------------------------------------------------------------------------------
+def probe_main(argv=None) -> int:
+    """What a caller runs in a child process per rank BEFORE its own process touches the GPU (`bench.py: isolated_probe`):
+    process group, set-up, self test and a free-running soak of real steps.  Exit code 0 = every rank passed.  What a
+    `try` cannot catch in the caller's own process -- a GPU memory fault on a peer mapping aborts the process -- ends
+    this child instead, and the caller keeps the RCCL form.  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
+    import argparse
+    import os
+    ap = argparse.ArgumentParser(prog="python -m hcatgnet_amd.xgmi")
+    ap.add_argument("--soak-steps", type=int, default=64)
+    ap.add_argument("--graphs", type=int, default=512)
+    ap.add_argument("--combine", default="sse", choices=("sse", "mean"))
+    ap.add_argument("--one-device", action="store_true", help="every rank on device 0 over gloo (one-GPU rehearsal)")
+    a = ap.parse_args(argv)
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if a.one_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if a.one_device:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    import hcatgnet_amd as H
+    from . import synth
+    from .ddp import DataParallelGCN
+    cfg = synth.CONFIGS["C3"]
+    opt = H.default_options(embedding_dim=cfg["hidden"])
+    model = H.make_network("GCN", opt, cfg["feat"]).to(dev)
+    dp = DataParallelGCN(model, combine=a.combine)
+    xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
+    ok = xchg.ok and xchg.self_test()
+    if ok and a.soak_steps > 0:
+        sb = synth.make_config("C3", rank=rank, num_graphs=a.graphs)
+        x, ei, bvec, y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
+        step = xchg.attach(dp.make_train_step())
+        last = None
+        for _ in range(a.soak_steps):
+            last = step(H.Batch(x, ei, bvec, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
+                                edges_grouped=True, n_small=sb.n_small))
+        torch.cuda.synchronize()
+        good = int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item())
+        verdict = torch.tensor([1 if good else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        ok = bool(int(verdict.item()))
+    print(f"[xgmi probe] rank {rank}: {'PASS' if ok else 'FAIL'}", flush=True)
+    xchg.close()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
+if __name__ == "__main__":
+    raise SystemExit(probe_main())
