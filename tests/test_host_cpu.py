@@ -189,3 +189,21 @@ def test_base_network_dispatch_mirrors_the_reference():
     with pytest.raises(ValueError):
         H.make_network("GAT", H.default_options(), 25)                        # call_methods.py:7-12
     assert m.name == "GCN"
+
+
+def test_exchange_probe_failure_in_the_child_is_a_verdict_not_an_exception(monkeypatch):
+    """bench.py tries the one-shot xGMI exchange in a sacrificial child process per rank first.  Here (no GPU) the child
+    dies at its first device call: the caller gets False and carries on with the RCCL form."""
+    import importlib.util
+    import socket
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for k, v in {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": str(port)}.items():
+        monkeypatch.setenv(k, v)
+    if torch.cuda.is_available():
+        pytest.skip("the point is a child that cannot reach a GPU")
+    assert bench.isolated_probe(1, False, "sse", timeout_s=240.0) is False
