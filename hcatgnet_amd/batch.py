@@ -54,6 +54,10 @@ class Batch:
         return int(self.x.shape[0])
 
     def to(self, device, non_blocking: bool = False) -> "Batch":
+        want = torch.device(device)
+        if all(t.device.type == want.type and (want.index is None or t.device.index == want.index)
+               for t in (getattr(self, f, None) for f in _TENSOR_FIELDS) if torch.is_tensor(t)):
+            return self                          # already there (a DeviceLoader's batches): nothing to move, nothing to rebuild
         kw = {}
         for f in _TENSOR_FIELDS:
             t = getattr(self, f, None)

@@ -48,8 +48,10 @@ class DeviceGraphStore:
     def __len__(self):
         return self.num_graphs
 
-    def collate(self, graph_ids: Iterable[int]) -> Batch:
-        """Batch of the given graphs (host list / array of indices), gathered on the device."""
+    def collate(self, graph_ids: Iterable[int], _uploaded=None) -> Batch:
+        """Batch of the given graphs (host list / array of indices), gathered on the device.
+        `_uploaded` (DeviceLoader): device views (ids, graph_ptr, edge_ptr) of this batch inside ONE upload for the whole
+        epoch -- otherwise the three index arrays of the batch go up here, one small copy each."""
         lib = _lib.load()
         ids = np.asarray(list(graph_ids) if not isinstance(graph_ids, np.ndarray) else graph_ids, np.int64)
         if ids.size == 0:
@@ -62,9 +64,12 @@ class DeviceGraphStore:
         ep = np.zeros(B + 1, np.int32); ep[1:] = np.cumsum(e)
         N, E = int(gp[-1]), int(ep[-1])
         dev = self.device
-        ids_d = torch.from_numpy(ids).to(dev, non_blocking=True)
-        gp_d = torch.from_numpy(gp).to(dev, non_blocking=True)
-        ep_d = torch.from_numpy(ep).to(dev, non_blocking=True)
+        if _uploaded is not None:
+            ids_d, gp_d, ep_d = _uploaded
+        else:
+            ids_d = torch.from_numpy(ids).to(dev, non_blocking=True)
+            gp_d = torch.from_numpy(gp).to(dev, non_blocking=True)
+            ep_d = torch.from_numpy(ep).to(dev, non_blocking=True)
         x = torch.empty(N, self.F, dtype=torch.float32, device=dev)
         ei = torch.empty(2, E, dtype=torch.int64, device=dev)
         bvec = torch.empty(N, dtype=torch.int64, device=dev)
@@ -104,9 +109,29 @@ class DeviceLoader:
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        order = self.rng.permutation(len(self.store)) if self.shuffle else np.arange(len(self.store))
-        for i in range(0, len(order), self.batch_size):
+        st = self.store
+        order = self.rng.permutation(len(st)) if self.shuffle else np.arange(len(st))
+        starts = [i for i in range(0, len(order), self.batch_size)
+                  if not (self.drop_last and len(order) - i < self.batch_size)]
+        # the epoch's index arrays in ONE upload: [ids of every batch | graph_ptr of every batch | edge_ptr of every batch]
+        # as int64 words (graph_ptr / edge_ptr are int32: two per word, every batch's block starts on a word) -- a batch
+        # then costs its gather launch and no host-to-device copy of its own (three ~10 us copies per step otherwise)
+        G = len(order)
+        words = lambda B: (B + 2) // 2                       # int64 words that hold B + 1 int32
+        tot = sum(words(min(self.batch_size, G - i)) for i in starts)
+        buf = np.zeros(G + 2 * tot, np.int64)
+        buf[:G] = order
+        ptr32 = buf[G:].view(np.int32)
+        spans, off = [], 0
+        for i in starts:
             ids = order[i:i + self.batch_size]
-            if self.drop_last and ids.size < self.batch_size:
-                return
-            yield self.store.collate(ids)
+            B = ids.size
+            ptr32[off + 1:off + B + 1] = np.cumsum(st.n_host[ids])
+            ptr32[2 * tot + off + 1:2 * tot + off + B + 1] = np.cumsum(st.e_host[ids])
+            spans.append((i, B, off))
+            off += 2 * words(B)
+        dbuf = torch.from_numpy(buf).to(st.device)
+        d32 = dbuf[G:].view(torch.int32)
+        for i, B, off in spans:
+            yield st.collate(order[i:i + B], _uploaded=(dbuf[i:i + B], d32[off:off + B + 1],
+                                                         d32[2 * tot + off:2 * tot + off + B + 1]))

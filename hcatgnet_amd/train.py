@@ -85,6 +85,28 @@ class FusedTrainStep:
         # workgroup) cannot be placed beside it, so on one device the ranks must meet (synchronize + barrier) before that
         # launch; on one GPU per rank nothing of another process ever runs on the device and this stays None
         self.pre_exchange_hook = None
+        self._pcache = None
+
+    def _trainable(self):
+        """The model's parameters in `model.parameters()` order, from a cache: the module walk of `nn.Module.parameters()`
+        costs ~20 us and a step needs the list four times (a quarter of the host time of a step at the reference's batch
+        size 40).  The cache is checked on every use -- each (module, name) slot still holds the same Parameter object and
+        the model's direct children are the same modules -- and rebuilt when not."""
+        model, c = self.model, self._pcache
+        key = tuple(map(id, model._modules.values()))
+        if c is None or c[0] != key or any(m._parameters.get(n) is not q for m, n, q in c[1]):
+            entries, seen = [], set()
+            for m in model.modules():
+                for n, q in m._parameters.items():
+                    if q is not None and id(q) not in seen:
+                        seen.add(id(q))
+                        entries.append((m, n, q))
+            c = self._pcache = (key, entries, [q for _, _, q in entries])
+        return c[2]
+
+    def reason(self, batch=None) -> Optional[str]:
+        """`unsupported_reason(self.model, batch)` with the cached parameter list."""
+        return self.unsupported_reason(self.model, batch, self._trainable())
 
     def _sync_words(self, dev: torch.device) -> torch.Tensor:
         """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
@@ -106,7 +128,7 @@ class FusedTrainStep:
 
     # ------------------------------------------------------------------ support check (host only)
     @staticmethod
-    def unsupported_reason(model, batch=None) -> Optional[str]:
+    def unsupported_reason(model, batch=None, _params=None) -> Optional[str]:
         if getattr(model, "readout_layers", None) != 2:
             return "readout depth other than 2"
         if not bool(getattr(model, "use_fused", True)):
@@ -118,7 +140,7 @@ class FusedTrainStep:
         #  kernels inside the same no-autograd step)
         if type(model.loss).__name__ != "MSELoss":
             return "loss other than MSE"
-        if not all(q.requires_grad for q in model.parameters()):
+        if not all(q.requires_grad for q in (model.parameters() if _params is None else _params)):
             return "frozen parameters (the fused backward writes every gradient)"
         if batch is not None:
             if getattr(batch, "y", None) is None:
@@ -209,7 +231,7 @@ class FusedTrainStep:
         opt = model.optimizer
         step_word, flat, g = None, None, None
         if not _forward_only:
-            params = [q for q in model.parameters() if q.requires_grad]
+            params = self._trainable()
             flat = self._flat_grads(params, dev)
             views, off = {}, 0
             for q in params:
@@ -361,16 +383,17 @@ class FusedTrainStep:
                 off += p.numel()
         return flat
 
-    def evaluate(self, batch):
+    def evaluate(self, batch, _checked: bool = False):
         """Forward + loss only (the reference's `eval_network` body, utils/utils_model.py:75-78): plan, conv stack, head
         -- 3 launches; the head kernel's backward half runs too (a few us) but nothing is reduced or updated."""
-        return self(batch, _forward_only=True)
+        return self(batch, _forward_only=True, _checked=_checked)
 
-    def __call__(self, batch, _forward_only: bool = False):
+    def __call__(self, batch, _forward_only: bool = False, _checked: bool = False):
         model = self.model
-        why = self.unsupported_reason(model, batch)
-        if why is not None:
-            raise _lib.HcgError(f"FusedTrainStep does not cover this model/batch: {why}")
+        if not _checked:                 # (the epoch loops below have just asked `reason(batch)` themselves)
+            why = self.reason(batch)
+            if why is not None:
+                raise _lib.HcgError(f"FusedTrainStep does not cover this model/batch: {why}")
         lib = _lib.load()
         x, y = batch.x, batch.y
         _lib.require_gpu(x, y, batch.edge_index)
@@ -448,7 +471,7 @@ class FusedTrainStep:
         opt = model.optimizer
         step_word, flat, g = None, None, None
         if not _forward_only:
-            params = [q for q in model.parameters() if q.requires_grad]
+            params = self._trainable()
             flat = self._flat_grads(params, dev)
             views, off = {}, 0
             for q in params:
@@ -583,7 +606,7 @@ class FusedTrainStep:
             if self.grad_sync is not None:
                 self.grad_sync(ext)                          # SUM of [gradients | SSE | count] over the ranks
             if self.optimizer_step and hasattr(opt, "step_sse"):
-                self._flat_grads([q for q in self.model.parameters() if q.requires_grad], flat.device)
+                self._flat_grads(self._trainable(), flat.device)
                 opt.step_sse(ext, loss_buf)                  # scale + update, one launch
             else:
                 _lib.check(lib.hcg_sse_finalize(_lib.ptr(ext), flat.numel(), _lib.ptr(loss_buf), _lib.stream_ptr()),
@@ -596,7 +619,7 @@ class FusedTrainStep:
         if self.optimizer_step:
             # the update reads the parameters' `.grad`: they must be views of THIS trainer's buffer (another trainer on
             # the same model may have re-pointed them since)
-            self._flat_grads([q for q in self.model.parameters() if q.requires_grad], flat.device)
+            self._flat_grads(self._trainable(), flat.device)
             opt.step()
 
     # ------------------------------------------------------------------ hipGraph
@@ -693,7 +716,7 @@ class FusedTrainStep:
         elif not self.optimizer_step:
             # gradients-only step: the parameters' `.grad` must be THIS trainer's buffer (another trainer on the same model
             # may have re-pointed them since the capture)
-            self._flat_grads([q for q in self.model.parameters() if q.requires_grad], self._flat.device)
+            self._flat_grads(self._trainable(), self._flat.device)
         return loss
 
 
@@ -726,8 +749,8 @@ def train_network(model, train_loader, device):
     total = None
     for batch in train_loader:
         batch = batch.to(device)
-        if FusedTrainStep.unsupported_reason(model, batch) is None:
-            loss = fused(batch)
+        if fused.reason(batch) is None:
+            loss = fused(batch, _checked=True)
         else:
             model.optimizer.zero_grad()
             loss = _rmse_autograd(model, batch)
@@ -754,8 +777,8 @@ def eval_network(model, loader, device):
     with torch.no_grad():
         for batch in loader:
             batch = batch.to(device)
-            if FusedTrainStep.unsupported_reason(model, batch) is None:
-                loss = fused.evaluate(batch)
+            if fused.reason(batch) is None:
+                loss = fused.evaluate(batch, _checked=True)
             else:
                 loss = _rmse_autograd(model, batch)
             total = _accumulate(total, loss, batch.num_graphs)

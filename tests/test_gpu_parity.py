@@ -675,10 +675,24 @@ def test_device_collate_equals_host_collate_and_feeds_the_model(H):
     with torch.no_grad():
         o_any = m(store.collate(ids))
     assert rel_inf(o_any, o_dev, floor=1.0) <= 2e-6
+    # a loader's batches carry their index arrays as views of ONE upload per epoch: every batch still equals the host
+    # collate of the same graphs bitwise, plan pointers included (odd and even batch sizes, the short last batch)
     seen = []
-    for bt in H.DeviceLoader(store, batch_size=8, shuffle=True, seed=1):
-        seen += bt.idx.cpu().tolist()
-    assert sorted(seen) == [1000 + i for i in range(37)]
+    for bs, drop in ((8, False), (7, False), (5, True)):
+        seen = []
+        for bt in H.DeviceLoader(store, batch_size=bs, shuffle=True, seed=1, drop_last=drop):
+            ids_b = [int(v) - 1000 for v in bt.idx.cpu().tolist()]
+            hb = H.collate([graphs[i] for i in ids_b])
+            assert torch.equal(bt.x.cpu(), hb.x) and torch.equal(bt.edge_index.cpu(), hb.edge_index)
+            assert torch.equal(bt.batch.cpu(), hb.batch) and torch.equal(bt.y.cpu(), hb.y)
+            assert torch.equal(bt._hcg_plan.graph_ptr.cpu().long(), hb.ptr)
+            assert torch.equal(bt._hcg_plan.edge_ptr.cpu().long(), hb.edge_ptr)
+            assert bt.to("cuda") is bt                      # already on the device: nothing is rebuilt
+            seen += bt.idx.cpu().tolist()
+        if drop:
+            assert len(seen) == 35 and len(set(seen)) == 35
+        else:
+            assert sorted(seen) == [1000 + i for i in range(37)]
 
 
 @pytest.mark.parametrize("apply_sigmoid", [True, False])

@@ -207,3 +207,20 @@ def test_exchange_probe_failure_in_the_child_is_a_verdict_not_an_exception(monke
     if torch.cuda.is_available():
         pytest.skip("the point is a child that cannot reach a GPU")
     assert bench.isolated_probe(1, False, "sse", timeout_s=240.0) is False
+
+
+def test_trainer_parameter_cache_follows_the_model():
+    """`FusedTrainStep._trainable()` caches `model.parameters()` (the module walk is a quarter of a small step's host time):
+    same objects in the same order, and the cache notices a replaced Parameter, a replaced child module and a frozen one."""
+    from hcatgnet_amd.train import FusedTrainStep
+    m = H.make_network("GCN", H.default_options(), 25)
+    t = FusedTrainStep(m, optimizer_step=False)
+    same = lambda: all(a is b for a, b in zip(t._trainable(), m.parameters())) and len(t._trainable()) == len(list(m.parameters()))
+    assert same() and t._trainable() is t._trainable()
+    m.conv1.bias = torch.nn.Parameter(torch.zeros_like(m.conv1.bias))
+    assert same()
+    m.conv1 = H.make_network("GCN", H.default_options(), 25).conv1
+    assert same()
+    assert t.reason() is None
+    m.conv1.bias.requires_grad_(False)
+    assert "frozen" in t.reason()
