@@ -24,6 +24,7 @@ external torch.distributed.run it is one of the ranks.  Prints ONE JSON line on 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -446,15 +447,25 @@ def main():
         return dt
 
     def timed(k, fn, start=0):
-        """K calls fn(i), i = start, start + 1, ... (mod NB), bracketed by barrier + synchronize; MAX over ranks."""
+        """K calls fn(i), i = start, start + 1, ... (mod NB), bracketed by barrier + synchronize; MAX over ranks.
+        The interpreter's cyclic garbage collector is off inside the bracket: a full collection of a process that has
+        imported torch takes ~80 ms -- four hundred steps' worth -- and lands wherever the allocation counters say (seen:
+        once in the 200-step burst loop, 0.106 -> 0.50 ms/step).  Nothing of the step is skipped by that."""
         barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for j in range(k):
-            fn((start + j) % NB)
-        torch.cuda.synchronize()
-        barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            for j in range(k):
+                fn((start + j) % NB)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            if gc_was:
+                gc.enable()
+        return max_over_ranks(dt)
 
     def sustain(seconds, fn):
         """The rotation for at least `seconds`: chunks of steps, one synchronize per chunk.  -> (steps, seconds, next index)"""
@@ -574,6 +585,13 @@ def main():
             replay.clear()
             graph_err = f"{type(exc).__name__}: {exc}"
             log(f"graph capture failed, keeping eager launches: {graph_err}")
+
+    # set-up is over: collect once and move everything alive now (torch, the model, 17 trainers, the captured graphs) out of
+    # the collector's sight, so that a later collection -- the sustained run keeps the collector on -- walks little
+    t_gc = time.perf_counter()
+    gc.collect()
+    gc.freeze()
+    log(f"gc.collect + gc.freeze after set-up: {(time.perf_counter() - t_gc) * 1e3:.0f} ms")
 
     # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
     mid = r0.sb.max_nodes > 32

@@ -696,7 +696,7 @@ class FusedTrainStep:
         fl = getattr(self.model.optimizer, "_flat", {}).get(0) if self.optimizer_step else None
         if fl is not None:
             fp += [fl["p"].data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr()]
-        fp += [q.data_ptr() for q in self.model.parameters()]
+        fp += [q.data_ptr() for q in self._trainable()]      # (cached walk: this runs on every replay)
         return tuple(fp)
 
     def replay(self):
