@@ -52,6 +52,11 @@ def main(argv=None):
 
     model = H.make_network("GCN", opt, F).to(device)
     val_best, best_epoch, stall, best_params = float("inf"), 0, 0, deepcopy(model.state_dict())
+    # an epoch here is ~2 ms of host work; a full cyclic-GC pass over a process that imported torch is ~85 ms: keep what
+    # exists now (torch, the datasets, the model) out of the collector's sight
+    import gc
+    gc.collect()
+    gc.freeze()
     t0 = time.time()
     for epoch in range(args.epochs):
         if stall > args.early_stopping:
