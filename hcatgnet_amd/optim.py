@@ -127,6 +127,7 @@ class FusedAdam(torch.optim.Optimizer):
         if grads[0].data_ptr() != flat_grad.data_ptr() or flat_grad.numel() != fl["n"]:
             return None
         self._make_dev_state(fl, group)
+        self._ready = (flat_grad.data_ptr(), fl)       # `step_with_reduction` of the same step need not ask again
         return fl["step_dev"]
 
     def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor, next_plan=None, exchange=None,
@@ -137,22 +138,29 @@ class FusedAdam(torch.optim.Optimizer):
         advanced earlier in this step (the head kernel does).  Returns False -- nothing launched -- when the
         preconditions do not hold; the caller then issues the two launches.  `next_plan` (a pointers-only blocked
         `BatchPlan` of the NEXT batch): its graph_ptr / edge_ptr are re-derived by the same launch."""
-        if not self.capturable or len(self.param_groups) != 1:
-            return False
-        group = self.param_groups[0]
-        ps = [p for p in group["params"] if p.requires_grad]
-        if not ps or not all(p.is_cuda for p in ps):
-            return False
-        fl = self._flat.get(0)
-        if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
-            with torch.no_grad():
-                fl = self._rebase(0, group)
-        grads = [p.grad for p in ps]
-        if any(g is None for g in grads) or not self._grads_flat(grads):
-            return False
-        if grads[0].data_ptr() != flat_grad.data_ptr() or flat_grad.numel() != fl["n"]:
-            return False
-        self._make_dev_state(fl, group)
+        ready, self._ready = getattr(self, "_ready", None), None
+        if (ready is not None and ready[0] == flat_grad.data_ptr() and self._flat.get(0) is ready[1]
+                and self.capturable and len(self.param_groups) == 1):
+            # `fused_update_ready(flat_grad)` answered earlier in this very step (the head launch in between advanced the
+            # step word): same parameters, same flat buffers -- the walk over them is not repeated
+            group, fl = self.param_groups[0], ready[1]
+        else:
+            if not self.capturable or len(self.param_groups) != 1:
+                return False
+            group = self.param_groups[0]
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps or not all(p.is_cuda for p in ps):
+                return False
+            fl = self._flat.get(0)
+            if fl is None or fl["params"] != ps or fl["p"].device != ps[0].device or ps[0].data_ptr() != fl["p"].data_ptr():
+                with torch.no_grad():
+                    fl = self._rebase(0, group)
+            grads = [p.grad for p in ps]
+            if any(g is None for g in grads) or not self._grads_flat(grads):
+                return False
+            if grads[0].data_ptr() != flat_grad.data_ptr() or flat_grad.numel() != fl["n"]:
+                return False
+            self._make_dev_state(fl, group)
         (b1, b2), eps, lr = group["betas"], float(group["eps"]), float(group["lr"])
         if fl["lr_host"] != lr:
             fl["lr_host"] = lr

@@ -233,11 +233,16 @@ class FusedTrainStep:
         if not _forward_only:
             params = self._trainable()
             flat = self._flat_grads(params, dev)
-            views, off = {}, 0
-            for q in params:
-                views[id(q)] = flat[off:off + q.numel()]
-                off += q.numel()
-            g = lambda prm: p(views[id(prm)])
+            # address of every parameter's slice of the flat gradient buffer (cached per buffer: eight tensor slices per
+            # step otherwise)
+            ga = getattr(self, "_gaddr", None)
+            if ga is None or ga[0] != flat.data_ptr() or ga[1] is not params:
+                addr, off = {}, 0
+                for q in params:
+                    addr[id(q)] = flat.data_ptr() + 4 * off
+                    off += q.numel()
+                ga = self._gaddr = (flat.data_ptr(), params, addr)
+            g = (lambda prm, _a=ga[2]: _a[id(prm)])
             if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
                     and (self.combine == "mean" or self.exchange is not None) and hasattr(opt, "fused_update_ready")):
                 step_word = opt.fused_update_ready(flat)
@@ -473,11 +478,14 @@ class FusedTrainStep:
         if not _forward_only:
             params = self._trainable()
             flat = self._flat_grads(params, dev)
-            views, off = {}, 0
-            for q in params:
-                views[id(q)] = flat[off:off + q.numel()]
-                off += q.numel()
-            g = lambda prm: p(views[id(prm)])
+            ga = getattr(self, "_gaddr", None)         # (see _routed_step)
+            if ga is None or ga[0] != flat.data_ptr() or ga[1] is not params:
+                addr, off = {}, 0
+                for q in params:
+                    addr[id(q)] = flat.data_ptr() + 4 * off
+                    off += q.numel()
+                ga = self._gaddr = (flat.data_ptr(), params, addr)
+            g = (lambda prm, _a=ga[2]: _a[id(prm)])
             # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
             # advances the step number that launch reads
             if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
