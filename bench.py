@@ -65,6 +65,7 @@ def parse():
                     help="captured step: 'none' = the step's own plan build in front of its forward; 'fused' = every step derives "
                          "the NEXT batch's plan inside its last launch (slab reduction + Adam; -2.5 % at C3); 'fork' = on a forked "
                          "branch of the graph (measured SLOWER on ROCm 7.2)")
+    ap.add_argument("--no-window", action="store_true", help="one hipGraph per step even where a whole rotation could be one graph launch")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph (eager launches)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE configs[1] (C2): plan build + forward only, no loss / backward (not the headline metric)")
@@ -446,8 +447,9 @@ def main():
             dt = float(t.item())
         return dt
 
-    def timed(k, fn, start=0):
-        """K calls fn(i), i = start, start + 1, ... (mod NB), bracketed by barrier + synchronize; MAX over ranks.
+    def timed(k, fn, start=0, runner=None):
+        """K calls fn(i), i = start, start + 1, ... (mod NB) -- or runner(start, K), which issues exactly those K steps, several per
+        graph launch where it can -- bracketed by barrier + synchronize; MAX over ranks.
         The interpreter's cyclic garbage collector is off inside the bracket: a full collection of a process that has
         imported torch takes ~80 ms -- four hundred steps' worth -- and lands wherever the allocation counters say (seen:
         once in the 200-step burst loop, 0.106 -> 0.50 ms/step).  Nothing of the step is skipped by that."""
@@ -457,8 +459,11 @@ def main():
         gc.disable()
         try:
             t0 = time.perf_counter()
-            for j in range(k):
-                fn((start + j) % NB)
+            if runner is not None:
+                runner(start, k)
+            else:
+                for j in range(k):
+                    fn((start + j) % NB)
             torch.cuda.synchronize()
             barrier()
             dt = time.perf_counter() - t0
@@ -467,14 +472,17 @@ def main():
                 gc.enable()
         return max_over_ranks(dt)
 
-    def sustain(seconds, fn):
+    def sustain(seconds, fn, runner=None):
         """The rotation for at least `seconds`: chunks of steps, one synchronize per chunk.  -> (steps, seconds, next index)"""
         barrier()
         torch.cuda.synchronize()
         t0, n, chunk = time.perf_counter(), 0, 256
         while True:
-            for j in range(chunk):
-                fn((n + j) % NB)
+            if runner is not None:
+                runner(n % NB, chunk)
+            else:
+                for j in range(chunk):
+                    fn((n + j) % NB)
             n += chunk
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
@@ -586,6 +594,33 @@ def main():
             graph_err = f"{type(exc).__name__}: {exc}"
             log(f"graph capture failed, keeping eager launches: {graph_err}")
 
+    # ---- a window: the NB steps of one rotation as ONE hipGraph (train.StepWindow) -- saves the bubble between two graph
+    #      launches.  Only where a whole step is one graph (one GPU, or the one-shot exchange inside the update launch) and every
+    #      step derives the next batch's plan itself (--plan-overlap fused).
+    window, window_err = None, None
+    if ("full" in replay and fused_ok and not args.forward_only and args.plan_overlap == "fused" and not args.no_window
+            and exchange_mode in ("none", "oneshot") and NB > 1):
+        try:
+            from hcatgnet_amd.train import StepWindow
+            window = StepWindow(trainers, [r.planned for r in res])
+            log(f"window captured: {NB} steps per graph launch")
+        except Exception as exc:          # report, never hide: the per-step graphs stand
+            window, window_err = None, f"{type(exc).__name__}: {exc}"
+            log(f"window capture failed, one graph per step stays: {window_err}")
+
+    def window_runner(start, k):
+        """Exactly k consecutive steps of the rotation from index `start`: whole rotations as one window launch, the rest as
+        single-step graphs (the same captured launches either way)."""
+        j = 0
+        while j < k:
+            i = (start + j) % NB
+            if i == 0 and k - j >= NB:
+                window.replay()
+                j += NB
+            else:
+                replay["full"][i]()
+                j += 1
+
     # set-up is over: collect once and move everything alive now (torch, the model, 17 trainers, the captured graphs) out of
     # the collector's sight, so that a later collection -- the sustained run keeps the collector on -- walks little
     t_gc = time.perf_counter()
@@ -648,10 +683,24 @@ def main():
         log(f"rotation probe: hipGraph {tg / max(args.steps, 4 * NB) * 1e3:.4f} vs eager {te / max(args.steps, 4 * NB) * 1e3:.4f} ms/step")
     launch_mode = "hipgraph" if use_graph else "eager"
     step_fn = (lambda i: replay["full"][i]()) if use_graph else eager_step
-    sus_steps, sus_s, nxt = sustain(args.sustain, step_fn) if args.sustain > 0 else (0, 0.0, 0)
-    dt_best = timed(args.steps, step_fn, start=nxt)
+    runner, steps_per_graph, per_step_graph_ms = None, (1 if use_graph else None), None
+    if window is not None:        # (also when the eager launches edged out the per-step graphs above)
+        kp = max(args.steps, 4 * NB) // NB * NB
+        timed(kp, None, runner=window_runner)
+        tw, tg1, te1 = (timed(kp, None, runner=window_runner), timed(kp, lambda i: replay["full"][i]()),
+                        timed(kp, eager_step))
+        log(f"rotation probe: {NB} steps per graph launch {tw / kp * 1e3:.4f} vs one graph per step {tg1 / kp * 1e3:.4f} "
+            f"vs eager {te1 / kp * 1e3:.4f} ms/step")
+        per_step_graph_ms = tg1 / kp * 1e3
+        if tw <= min(tg1, te1):
+            use_graph, launch_mode = True, "hipgraph"
+            step_fn = lambda i: replay["full"][i]()
+            runner, steps_per_graph = window_runner, NB
+    sus_steps, sus_s, nxt = sustain(args.sustain, step_fn, runner) if args.sustain > 0 else (0, 0.0, 0)
+    dt_best = timed(args.steps, step_fn, start=nxt, runner=runner)
     log(f"sustained {sus_s:.2f} s / {sus_steps} steps = {sus_s / max(sus_steps, 1) * 1e3:.4f} ms/step; "
-        f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode})")
+        f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode}"
+        f"{', ' + str(steps_per_graph) + ' steps per graph launch' if steps_per_graph and steps_per_graph > 1 else ''})")
     for tr in trainers:
         tr.check_health()
     if xchg is not None and exchange_mode == "oneshot":
@@ -718,15 +767,31 @@ def main():
                 else:
                     tr.capture(r.fresh)
             rfn = lambda i: rtr[i].replay()
-            timed(4 * NB, rfn)
-            rdt = timed(max(args.steps, 200), rfn)
+            rrun = None
+            if runner is not None and args.plan_overlap == "fused":         # the headline's launch form
+                from hcatgnet_amd.train import StepWindow
+                rwin = StepWindow(rtr, [r.planned for r in rr])
+
+                def rrun(start, k):
+                    j = 0
+                    while j < k:
+                        i = (start + j) % NB
+                        if i == 0 and k - j >= NB:
+                            rwin.replay()
+                            j += NB
+                        else:
+                            rtr[i].replay()
+                            j += 1
+            timed(4 * NB, rfn, runner=rrun)
+            rdt = timed(max(args.steps, 200), rfn, runner=rrun)
             k = max(args.steps, 200)
             gpt = lib.hcg_fused_graphs_per_tile(F, D, rr[0].sb.max_nodes)
             ragged = {"value": rr[0].B * k / rdt, "unit": "graphs/s", "ms_per_step": rdt / k * 1e3, "steps": k,
                       "graphs": rr[0].B, "nodes": rr[0].N, "edges": rr[0].E, "max_nodes": rr[0].sb.max_nodes,
                       "kernel_family": "small-graph tiles" if gpt > 0 else ("size-grouped batch: tiles for graphs <= 32 nodes + one graph per wave"
                                                                            if rr[0].sb.n_small else "one graph per wave / workgroup"),
-                      "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, hipGraph replay"}
+                      "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, hipGraph replay"
+                              f"{' (' + str(NB) + ' steps per graph launch)' if rrun is not None else ''}"}
             log(f"ragged variant: {rdt / k * 1e3:.4f} ms/step")
             del rr, rtr
         except Exception as exc:
@@ -749,6 +814,7 @@ def main():
                                    f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
                                    f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
+                                   f"{' (' + str(steps_per_graph) + ' consecutive steps per graph launch)' if steps_per_graph and steps_per_graph > 1 else ''}"
                                    f"{'' if (launch_mode != 'hipgraph' or args.plan_overlap == 'none' or not fused_ok) else ', plan build of the NEXT batch ' + ('inside the last launch of the step' if args.plan_overlap == 'fused' else 'on a forked graph branch')}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
@@ -779,7 +845,8 @@ def main():
             "library_launching_calls_per_step": {"total": sum(launch_counts.values()), "by_entry_point": launch_counts},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "eager_step_ms_percentiles_hip_events": pct,
-            "launch": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3,
+            "launch": launch_mode, "steps_per_graph_launch": steps_per_graph, "one_graph_per_step_ms": per_step_graph_ms,
+            "window_error": window_err, "eager_ms_per_step": dt_eager / args.steps * 1e3,
             "graph_capture_error": graph_err,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -728,6 +728,58 @@ class FusedTrainStep:
         return loss
 
 
+class StepWindow:
+    """Several consecutive training steps as ONE hipGraph: `steps[i]` (a `FusedTrainStep`, all on the same model) run on
+    `batches[i]` (a Batch, or a callable returning one), in order, the weights carried from step to step exactly as
+    separate launches would.  What a window saves is the bubble between two graph launches (~3.7 us on MI355X / ROCm 7.2:
+    C3 0.1152 -> 0.1115 ms/step, the reference's batch size 40 0.0713 -> 0.0675; `tools/exp_multistep_graph.py`) -- for a
+    loader whose batches are known ahead (a resident dataset visited in a fixed or pre-drawn order), an epoch is one launch.
+    Each step must be capturable on its own first (`FusedTrainStep.capture` has run, or would succeed): same launches, same
+    device-side step count / learning rate, the next batch's plan inside each step's last launch if `next_plan` is set.
+    A step whose gradient exchange is a separate collective (`grad_sync`) cannot sit inside a window.
+
+        for i, st in enumerate(steps): st.capture(batch_fn[i], next_plan=plans[(i + 1) % n])
+        window = StepWindow(steps, batch_fn);  losses = window.replay()      # one launch = n steps"""
+
+    def __init__(self, steps, batches):
+        steps, batches = list(steps), list(batches)
+        if not steps or len(steps) != len(batches):
+            raise ValueError("StepWindow needs as many batches as steps (at least one)")
+        model = steps[0].model
+        for st in steps:
+            if st.model is not model:
+                raise ValueError("the steps of a window train ONE model")
+            if st.grad_sync is not None:
+                raise _lib.HcgError("a step with a separate gradient collective (grad_sync) cannot be captured into a window")
+            if st.optimizer_step and not hasattr(model.optimizer, "enable_capturable"):
+                raise _lib.HcgError("StepWindow with optimizer_step needs hcatgnet_amd.optim.FusedAdam")
+        if steps[0].optimizer_step:
+            model.optimizer.enable_capturable()
+        self.steps, self.model = steps, model
+        get = lambda b: b() if callable(b) else b
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up: every buffer allocated, optimiser state re-based
+            for st, b in zip(steps, batches):
+                st(get(b))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            self.losses = [st(get(b)) for st, b in zip(steps, batches)]
+        self._fp = [st._graph_fingerprint() for st in steps]
+
+    def replay(self):
+        """-> the steps' loss tensors (device scalars, overwritten by the next replay)."""
+        if self._fp != [st._graph_fingerprint() for st in self.steps]:
+            raise _lib.HcgError("StepWindow.replay(): parameter / optimiser / step buffers changed since the capture: build it again")
+        if self.steps[0].optimizer_step:
+            self.model.optimizer.sync_lr()
+        self.graph.replay()
+        return self.losses
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the reference's loops (same names / arguments / return values)
 # ---------------------------------------------------------------------------------------------------------------

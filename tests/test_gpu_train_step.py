@@ -155,6 +155,39 @@ def test_captured_step_replays_like_eager_steps(H):
     assert b.optimizer.state_dict()["state"][0]["step"].item() == 7
 
 
+def test_step_window_equals_the_same_steps_one_by_one(H):
+    """`train.StepWindow`: three consecutive steps on three distinct batches (two kernel families: 30-atom tiles and the
+    reference's graph sizes) captured as ONE hipGraph.  Two replays of the window == the same six steps issued eagerly
+    on a twin model: losses and weights bitwise (same launches in the same order), step count included; a step with a
+    separate gradient collective is refused."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep, StepWindow
+    for cfg, feat, ng in (("C2", 64, 192), ("REAL", 25, 48)):
+        sbs = [synth.make_config(cfg, num_graphs=ng, rank=r) for r in range(3)]
+        dev = [(sb, sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.y.cuda()) for sb in sbs]
+        fresh = [(lambda t=t: H.Batch(t[1], t[2], t[3], t[0].num_graphs, y=t[4], max_nodes=t[0].max_nodes,
+                                      max_edges=t[0].max_edges, edges_grouped=True)) for t in dev]
+        torch.manual_seed(0)
+        a = H.make_network("GCN", H.default_options(), feat).cuda()
+        b = H.make_network("GCN", H.default_options(), feat).cuda()
+        b.load_state_dict(a.state_dict())
+        sa = [FusedTrainStep(a) for _ in range(3)]
+        sb_ = [FusedTrainStep(b) for _ in range(3)]
+        win = StepWindow(sb_, fresh)                                    # its warm-up runs the three steps once
+        la = [float(sa[i](fresh[i]())) for i in range(3)]               # the twin follows the warm-up (the capture runs nothing)
+        lb = []
+        for _ in range(2):
+            la += [float(sa[i](fresh[i]())) for i in range(3)]
+            lb += [float(v) for v in win.replay()]
+        assert lb == la[3:], (cfg, lb, la[3:])
+        assert b.optimizer.steps_done() == a.optimizer.steps_done() == 9
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb), cfg
+    from hcatgnet_amd._lib import HcgError
+    with pytest.raises(HcgError):
+        StepWindow([FusedTrainStep(a, grad_sync=lambda flat: None)], [fresh[0]])
+
+
 def test_train_network_mirror_runs_an_epoch_and_learns(H):
     """hcatgnet_amd.train.train_network / eval_network / predict_network: the reference's loop signatures
     (utils/utils_model.py:55-111) over a DeviceLoader; fused step for 30-atom graphs, autograd fallback for graphs
