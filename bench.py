@@ -597,15 +597,20 @@ def main():
     # ---- a window: the NB steps of one rotation as ONE hipGraph (train.StepWindow) -- saves the bubble between two graph
     #      launches.  Only where a whole step is one graph (one GPU, or the one-shot exchange inside the update launch) and every
     #      step derives the next batch's plan itself (--plan-overlap fused).
-    window, window_err = None, None
+    window, window_err, tail_window, tail_n = None, None, None, 0
     if ("full" in replay and fused_ok and not args.forward_only and args.plan_overlap == "fused" and not args.no_window
             and exchange_mode in ("none", "oneshot") and NB > 1):
         try:
             from hcatgnet_amd.train import StepWindow
             window = StepWindow(trainers, [r.planned for r in res])
-            log(f"window captured: {NB} steps per graph launch")
+            # the timed K steps = ONE shorter window for K mod NB steps (the LAST batches of a rotation, issued first: a short graph
+            # reaches the GPU sooner after the bracket's synchronize, and the launch of the long one behind it is hidden) + whole rotations
+            tail_n = args.steps % NB
+            if tail_n >= 2:
+                tail_window = StepWindow(trainers[NB - tail_n:], [r.planned for r in res[NB - tail_n:]])
+            log(f"window captured: {NB} steps per graph launch" + (f" (+ one of {tail_n} for the remainder of {args.steps})" if tail_window else ""))
         except Exception as exc:          # report, never hide: the per-step graphs stand
-            window, window_err = None, f"{type(exc).__name__}: {exc}"
+            window, tail_window, window_err = None, None, f"{type(exc).__name__}: {exc}"
             log(f"window capture failed, one graph per step stays: {window_err}")
 
     def window_runner(start, k):
@@ -617,6 +622,9 @@ def main():
             if i == 0 and k - j >= NB:
                 window.replay()
                 j += NB
+            elif i == NB - tail_n and tail_window is not None and k - j >= tail_n:
+                tail_window.replay()
+                j += tail_n
             else:
                 replay["full"][i]()
                 j += 1
@@ -697,6 +705,10 @@ def main():
             step_fn = lambda i: replay["full"][i]()
             runner, steps_per_graph = window_runner, NB
     sus_steps, sus_s, nxt = sustain(args.sustain, step_fn, runner) if args.sustain > 0 else (0, 0.0, 0)
+    if runner is not None and tail_window is not None and nxt != NB - tail_n:
+        # (untimed) walk the rotation on to where the remainder window starts: the K timed steps are then that window + whole rotations
+        runner(nxt, (NB - tail_n - nxt) % NB)
+        nxt = NB - tail_n
     dt_best = timed(args.steps, step_fn, start=nxt, runner=runner)
     log(f"sustained {sus_s:.2f} s / {sus_steps} steps = {sus_s / max(sus_steps, 1) * 1e3:.4f} ms/step; "
         f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode}"
