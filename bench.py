@@ -112,25 +112,32 @@ def self_launch(args) -> int:
 
 
 def isolated_probe(world, rehearsal, combine, timeout_s=300.0):
-    """The one-shot exchange tried once in a CHILD process per rank (`python -m hcatgnet_amd.xgmi`: its own process group on
-    the next port, set-up, self test, 64 free-running real steps) before THIS process touches the GPU.  A failure no `try`
-    can catch -- a GPU memory fault on a peer mapping aborts the process, a wedged launch never returns -- then ends the
-    child, not the bench: -> False, and the RCCL form is what gets measured.  Stdlib only (nothing here may initialise HIP)."""
+    """Both data-parallel graph forms tried once in a CHILD process per rank (`python -m hcatgnet_amd.xgmi`: its own process
+    group on the next port; the one-shot exchange with set-up, self test and 64 free-running real steps; then the RCCL
+    collective recorded into the step's hipGraph, 32 replays) before THIS process touches the GPU.  A failure no `try` can
+    catch -- a GPU memory fault on a peer mapping aborts the process, a wedged launch or collective never returns -- then ends
+    the child, not the bench.  -> {"oneshot": bool, "captured": bool}: what the child had recorded when it ended (a phase it
+    never finished counts as failed); the plain RCCL form needs neither.  Stdlib only (nothing here may initialise HIP)."""
+    import tempfile
     env = dict(os.environ)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child group's rank 0 hosts its own store ...
     env["MASTER_ADDR"] = "127.0.0.1"
     env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) - 1024 + 1) % (65535 - 1024) + 1024)   # ... on the next port
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    fd, out_path = tempfile.mkstemp(prefix="hcg_probe_", suffix=".json")
+    os.close(fd)
+    env["HCG_PROBE_OUT"] = out_path
     cmd = [sys.executable, "-m", "hcatgnet_amd.xgmi", "--combine", combine]
     if rehearsal:
         cmd += ["--one-device", "--soak-steps", "0"]      # (two ranks on one device starve each other in a free-running soak)
     t0 = time.perf_counter()
+    verdicts = {"oneshot": False, "captured": False}
     try:
         proc = subprocess.Popen(cmd, env=env, stdout=sys.stderr, stderr=sys.stderr, start_new_session=True)
     except OSError as exc:
-        log(f"one-shot exchange probe could not start ({exc}): RCCL form")
-        return False
+        log(f"data-parallel probe could not start ({exc}): plain RCCL form")
+        return verdicts
     try:
         rc = proc.wait(timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -140,8 +147,17 @@ def isolated_probe(world, rehearsal, combine, timeout_s=300.0):
             pass
         proc.wait()
         rc = -9
-    log(f"one-shot exchange probe (child process, world {world}): exit {rc} after {time.perf_counter() - t0:.1f} s")
-    return rc == 0
+    try:
+        got = json.load(open(out_path))
+        verdicts.update({k: bool(got.get(k, False)) for k in verdicts})
+    except (OSError, ValueError):
+        pass
+    try:
+        os.unlink(out_path)
+    except OSError:
+        pass
+    log(f"data-parallel probe (child process, world {world}): exit {rc} after {time.perf_counter() - t0:.1f} s -> {verdicts}")
+    return verdicts
 
 
 class EntryTimer:
@@ -274,9 +290,14 @@ def main():
                          f"(or run `python bench.py --gpus {args.gpus}` from a bare shell: it starts its own ranks)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, the JSON record: whatever libraries print there (RCCL announces its version on stdout at
+    # communicator set-up, gloo its peers) goes to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # N > 1, --exchange auto: the one-shot exchange has to survive a sacrificial child process group first (before anything
     # here touches the GPU); the ranks combine their verdicts once the real process group is up
-    probe_ok = None
+    probe_ok, probe_captured = None, False
     if (world > 1 and args.exchange == "auto" and not args.forward_only
             and (os.environ.get("HCG_BENCH_REHEARSAL") != "1" or os.environ.get("HCG_PROBE_IN_REHEARSAL") == "1")):
         probe_ok = isolated_probe(world, os.environ.get("HCG_BENCH_REHEARSAL") == "1", args.combine)
@@ -539,10 +560,11 @@ def main():
         if fused_ok:
             for tr in trainers + [fwdbwd]:
                 dp.attach(tr)
-            if probe_ok is not None:       # every rank's child verdict, combined: one failure anywhere = RCCL form everywhere
-                pv = torch.tensor([1 if probe_ok else 0], device=dev, dtype=torch.int32)
+            probe_captured = False
+            if probe_ok is not None:       # every rank's child verdicts, combined: one failure anywhere = that form nowhere
+                pv = torch.tensor([1 if probe_ok["oneshot"] else 0, 1 if probe_ok["captured"] else 0], device=dev, dtype=torch.int32)
                 dist.all_reduce(pv, op=dist.ReduceOp.MIN)
-                probe_ok = bool(int(pv.item()))
+                probe_ok, probe_captured = bool(int(pv[0].item())), bool(int(pv[1].item()))
             if probe_ok is False:
                 log("one-shot exchange: its probe in a child process group did not pass on every rank -- RCCL all-reduce stays")
             elif rehearsal and args.exchange == "auto":
@@ -578,6 +600,13 @@ def main():
                 elif args.exchange == "oneshot":
                     raise SystemExit("bench.py: --exchange oneshot, but the one-shot exchange failed its set-up / self test")
                 log(f"one-shot exchange: {'in use' if exchange_mode == 'oneshot' else 'not usable here, RCCL all-reduce stays'}")
+            if exchange_mode == "rccl" and probe_captured and not rehearsal and args.exchange == "auto":
+                # the RCCL form with the collective and the update recorded INTO the step's graph (passed in the child process
+                # group on every rank): the data-parallel step is one graph, and whole rotations one graph launch
+                for tr in trainers + [fwdbwd]:
+                    tr.capture_exchange = True
+                exchange_mode = "rccl-captured"
+                log("RCCL all-reduce recorded into the step's hipGraph (its probe in a child process group passed on every rank)")
         for j in range(max(3, NB)):
             eager_step(j % NB)
         torch.cuda.synchronize()
@@ -599,7 +628,7 @@ def main():
     #      step derives the next batch's plan itself (--plan-overlap fused).
     window, window_err, tail_window, tail_n = None, None, None, 0
     if ("full" in replay and fused_ok and not args.forward_only and args.plan_overlap == "fused" and not args.no_window
-            and exchange_mode in ("none", "oneshot") and NB > 1):
+            and exchange_mode in ("none", "oneshot", "rccl-captured") and NB > 1):
         try:
             from hcatgnet_amd.train import StepWindow
             window = StepWindow(trainers, [r.planned for r in res])
@@ -815,7 +844,7 @@ def main():
                                               if fused_ok else 0))
         fwd_only_note = "plan/gcn_norm build + forward (conv stack, pool, readout) only" if args.forward_only else \
             (f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
-             f"{('one-shot xGMI exchange inside the update launch (' if exchange_mode == 'oneshot' else 'RCCL all-reduce (') + args.combine + '), ' if world > 1 else ''}Adam update")
+             f"{('one-shot xGMI exchange inside the update launch (' if exchange_mode == 'oneshot' else ('RCCL all-reduce recorded in the step graph (' if exchange_mode == 'rccl-captured' else 'RCCL all-reduce (')) + args.combine + '), ' if world > 1 else ''}Adam update")
         rec = {
             "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s" if not args.forward_only
                       else "molecular graphs/sec FORWARD ONLY (configs[1]; not the headline metric)",
@@ -832,7 +861,9 @@ def main():
                        "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
                                       f"of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "rccl_world": rccl_world, "exchange": exchange_mode,
-            "exchange_probe": (None if probe_ok is None else ("passed" if probe_ok else "failed")),   # the child-process trial of the one-shot exchange
+            # the child-process trials: of the one-shot exchange, and of the RCCL collective recorded into the step's graph
+            "exchange_probe": (None if probe_ok is None else ("passed" if probe_ok else "failed")),
+            "captured_collective_probe": (None if probe_ok is None or world == 1 else ("passed" if probe_captured else "failed")),
             "distinct_batches": NB, "bytes_touched_between_reuse": touched,
             "sustained_s": sus_s, "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3,
                                                 "value": world * B * sus_steps / sus_s if sus_s > 0 else None,
@@ -863,7 +894,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg_name, args.num_graphs, args.cpu_steps)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

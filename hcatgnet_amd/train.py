@@ -85,6 +85,10 @@ class FusedTrainStep:
         # workgroup) cannot be placed beside it, so on one device the ranks must meet (synchronize + barrier) before that
         # launch; on one GPU per rank nothing of another process ever runs on the device and this stays None
         self.pre_exchange_hook = None
+        # data parallel, RCCL form: True = `capture()` / `StepWindow` record the collective and the update launch too (RCCL
+        # collectives survive hipGraph capture: tools/exp_rccl_capture.py), so the whole data-parallel step is ONE graph.
+        # Default False: the graph ends after the slab reduction, `replay()` issues collective + update eagerly behind it
+        self.capture_exchange = False
         self._pcache = None
 
     def _trainable(self):
@@ -669,10 +673,12 @@ class FusedTrainStep:
                 self(get())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        split = sync is not None
+        split = sync is not None and not self.capture_exchange
         try:
-            self.grad_sync = None
+            if split or sync is None:
+                self.grad_sync = None
             self._capturing_split = split              # with an exchange, the graph ends after the slab reduction
+                                                       # (unless `capture_exchange`: collective + update are recorded too)
             g_main = torch.cuda.CUDAGraph()
             fork = torch.cuda.Stream() if prefetch is not None else None
             # (a live process group has helper threads that query events: their calls must not fail this capture)
@@ -749,8 +755,9 @@ class StepWindow:
         for st in steps:
             if st.model is not model:
                 raise ValueError("the steps of a window train ONE model")
-            if st.grad_sync is not None:
-                raise _lib.HcgError("a step with a separate gradient collective (grad_sync) cannot be captured into a window")
+            if st.grad_sync is not None and not st.capture_exchange:
+                raise _lib.HcgError("a step with a separate gradient collective (grad_sync) cannot be captured into a window "
+                                    "(unless its `capture_exchange` is set: the collective is then recorded with the step)")
             if st.optimizer_step and not hasattr(model.optimizer, "enable_capturable"):
                 raise _lib.HcgError("StepWindow with optimizer_step needs hcatgnet_amd.optim.FusedAdam")
         if steps[0].optimizer_step:

@@ -190,14 +190,18 @@ class OneShotExchange:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# the probe: the whole exchange tried once in a SACRIFICIAL process group (`python -m hcatgnet_amd.xgmi`, one per rank)
+# the probe: both data-parallel graph forms tried once in a SACRIFICIAL process group (`python -m hcatgnet_amd.xgmi`, one per rank)
 # ---------------------------------------------------------------------------------------------------------------------
 def probe_main(argv=None) -> int:
-    """What a caller runs in a child process per rank BEFORE its own process touches the GPU (`bench.py: isolated_probe`):
-    process group, set-up, self test and a free-running soak of real steps.  Exit code 0 = every rank passed.  What a
-    `try` cannot catch in the caller's own process -- a GPU memory fault on a peer mapping aborts the process -- ends
-    this child instead, and the caller keeps the RCCL form.  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
+    """What a caller runs in a child process per rank BEFORE its own process touches the GPU (`bench.py: isolated_probe`).
+    Phase 1, the one-shot exchange: process group, set-up, self test and a free-running soak of real steps.  Phase 2, the
+    RCCL form with the collective recorded into the step's hipGraph (`FusedTrainStep.capture_exchange`): capture, 32
+    replays, finite loss and bitwise-equal weights on every rank.  Verdicts go to the JSON file named by HCG_PROBE_OUT as
+    soon as a phase ends ({"oneshot": bool, "captured": bool}); exit code 0 = both passed.  What a `try` cannot catch in the
+    caller's own process -- a GPU memory fault on a peer mapping aborts the process, a wedged collective never returns --
+    ends this child instead, and the caller keeps the plain RCCL form.  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
     import argparse
+    import json
     import os
     ap = argparse.ArgumentParser(prog="python -m hcatgnet_amd.xgmi")
     ap.add_argument("--soak-steps", type=int, default=64)
@@ -206,6 +210,16 @@ def probe_main(argv=None) -> int:
     ap.add_argument("--one-device", action="store_true", help="every rank on device 0 over gloo (one-GPU rehearsal)")
     a = ap.parse_args(argv)
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    out_path, verdicts = os.environ.get("HCG_PROBE_OUT"), {}
+
+    def record(key, ok):
+        verdicts[key] = bool(ok)
+        print(f"[xgmi probe] rank {rank}: {key} {'PASS' if ok else 'FAIL'}", flush=True)
+        if out_path:
+            with open(out_path + ".tmp", "w") as f:
+                json.dump(verdicts, f)
+            os.replace(out_path + ".tmp", out_path)
+
     if a.one_device:
         local = 0
     torch.cuda.set_device(local)
@@ -214,32 +228,63 @@ def probe_main(argv=None) -> int:
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("nccl", device_id=dev)
+    world = dist.get_world_size()
     import hcatgnet_amd as H
     from . import synth
     from .ddp import DataParallelGCN
     cfg = synth.CONFIGS["C3"]
     opt = H.default_options(embedding_dim=cfg["hidden"])
+    sb = synth.make_config("C3", rank=rank, num_graphs=a.graphs)
+    x, ei, bvec, y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
+    fresh = lambda: H.Batch(x, ei, bvec, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
+                            edges_grouped=True, n_small=sb.n_small)
+
+    def all_agree(good):
+        v = torch.tensor([1 if good else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(int(v.item()))
+
+    # ---- phase 1: the one-shot exchange
     model = H.make_network("GCN", opt, cfg["feat"]).to(dev)
     dp = DataParallelGCN(model, combine=a.combine)
     xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
     ok = xchg.ok and xchg.self_test()
     if ok and a.soak_steps > 0:
-        sb = synth.make_config("C3", rank=rank, num_graphs=a.graphs)
-        x, ei, bvec, y = sb.x.to(dev), sb.edge_index.to(dev), sb.batch.to(dev), sb.y.to(dev)
         step = xchg.attach(dp.make_train_step())
         last = None
         for _ in range(a.soak_steps):
-            last = step(H.Batch(x, ei, bvec, sb.num_graphs, y=y, max_nodes=sb.max_nodes, max_edges=sb.max_edges,
-                                edges_grouped=True, n_small=sb.n_small))
+            last = step(fresh())
         torch.cuda.synchronize()
-        good = int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item())
-        verdict = torch.tensor([1 if good else 0], device=dev, dtype=torch.int32)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-        ok = bool(int(verdict.item()))
-    print(f"[xgmi probe] rank {rank}: {'PASS' if ok else 'FAIL'}", flush=True)
+        ok = all_agree(int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item()))
+    record("oneshot", ok)
     xchg.close()
+
+    # ---- phase 2: the RCCL collective recorded into the step's graph (gloo collectives run on the host: nothing to record)
+    cap = False
+    if not a.one_device:
+        model2 = H.make_network("GCN", opt, cfg["feat"]).to(dev)
+        dp2 = DataParallelGCN(model2, combine=a.combine, force_collective=world == 1)
+        st = dp2.make_train_step()
+        st.capture_exchange = True
+        good = True
+        try:
+            st.capture(fresh)
+            last = None
+            for _ in range(32):
+                last = st.replay()
+            torch.cuda.synchronize()
+            good = bool(torch.isfinite(last).item())
+        except Exception as exc:                       # noqa: BLE001  (every rank still issues the collectives below)
+            print(f"[xgmi probe] rank {rank}: captured form raised {type(exc).__name__}: {exc}", flush=True)
+            good = False
+        chk = torch.cat([p.detach().reshape(-1) for p in model2.parameters()]).double().sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        cap = all_agree(good and bool((hi == lo).item()) and bool(torch.isfinite(chk).item()))
+    record("captured", cap)
     dist.destroy_process_group()
-    return 0 if ok else 3
+    return 0 if (ok and (cap or a.one_device)) else 3
 
 
 if __name__ == "__main__":

@@ -484,6 +484,66 @@ def test_rccl_gradient_allreduce_world1(H):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("combine", ["sse", "mean"])
+def test_rccl_exchange_captured_with_the_step_world1(H, combine):
+    """`FusedTrainStep.capture_exchange`: the RCCL all-reduce and the update launch are recorded INTO the step's hipGraph
+    (backend "nccl", world size 1, collective forced), alone and inside a `StepWindow`: replays == the eager
+    data-parallel steps of a twin model, bitwise (same launches in the same order)."""
+    import socket
+    import torch.distributed as dist
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.ddp import DataParallelGCN
+    from hcatgnet_amd.train import StepWindow
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        sbs = [synth.make_config("C2", num_graphs=128, rank=r) for r in range(2)]
+        dev = [(sb, sb.x.cuda(), sb.edge_index.cuda(), sb.batch.cuda(), sb.y.cuda()) for sb in sbs]
+        fresh = [(lambda t=t: H.Batch(t[1], t[2], t[3], t[0].num_graphs, y=t[4], max_nodes=t[0].max_nodes,
+                                      max_edges=t[0].max_edges, edges_grouped=True)) for t in dev]
+        torch.manual_seed(0)
+        models = [H.make_network("GCN", H.default_options(), 64).cuda() for _ in range(3)]
+        for m in models[1:]:
+            m.load_state_dict(models[0].state_dict())
+        dps = [DataParallelGCN(m, force_collective=True, combine=combine) for m in models]
+        eager = [dps[0].make_train_step() for _ in range(2)]
+        single = [dps[1].make_train_step() for _ in range(2)]
+        winst = [dps[2].make_train_step() for _ in range(2)]
+        for st in single + winst:
+            st.capture_exchange = True
+        # twin: 2 warm-up steps per capture (single[0] then single[1]) = batches 0 0 1 1, then 0 1 0 1
+        for i in (0, 0, 1, 1):
+            eager[i](fresh[i]())
+        single[0].capture(fresh[0]); single[1].capture(fresh[1])
+        le, ls = [], []
+        for _ in range(2):
+            for i in range(2):
+                le.append(float(eager[i](fresh[i]())))
+                ls.append(float(single[i].replay()))
+        assert ls == le, (ls, le)
+        for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+            assert torch.equal(pa, pb)
+        # window: its warm-up runs batches 0 1 once; a fresh eager twin follows
+        models[0].load_state_dict(models[2].state_dict())
+        tw_dp = DataParallelGCN(H.make_network("GCN", H.default_options(), 64).cuda(), force_collective=True, combine=combine)
+        tw_dp.module.load_state_dict(models[2].state_dict())
+        tw = [tw_dp.make_train_step() for _ in range(2)]
+        win = StepWindow(winst, fresh)
+        for i in range(2):
+            tw[i](fresh[i]())
+        lw, lt = [], []
+        for _ in range(2):
+            lt += [float(tw[i](fresh[i]())) for i in range(2)]
+            lw += [float(v) for v in win.replay()]
+        assert lw == lt, (lw, lt)
+        for pa, pb in zip(tw_dp.module.parameters(), models[2].parameters()):
+            assert torch.equal(pa, pb)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("n", [1, 7, 4096, 100003])
 def test_fused_mse_loss(H, n):
     """hcatgnet_amd.networks.MSELoss == nn.MSELoss() (mean), value and both gradients."""

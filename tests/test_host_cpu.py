@@ -193,7 +193,7 @@ def test_base_network_dispatch_mirrors_the_reference():
 
 def test_exchange_probe_failure_in_the_child_is_a_verdict_not_an_exception(monkeypatch):
     """bench.py tries the one-shot xGMI exchange in a sacrificial child process per rank first.  Here (no GPU) the child
-    dies at its first device call: the caller gets False and carries on with the RCCL form."""
+    dies at its first device call: the caller gets both verdicts False and carries on with the plain RCCL form."""
     import importlib.util
     import socket
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
@@ -206,7 +206,7 @@ def test_exchange_probe_failure_in_the_child_is_a_verdict_not_an_exception(monke
         monkeypatch.setenv(k, v)
     if torch.cuda.is_available():
         pytest.skip("the point is a child that cannot reach a GPU")
-    assert bench.isolated_probe(1, False, "sse", timeout_s=240.0) is False
+    assert bench.isolated_probe(1, False, "sse", timeout_s=240.0) == {"oneshot": False, "captured": False}
 
 
 def test_trainer_parameter_cache_follows_the_model():
