@@ -196,7 +196,7 @@ def probe_main(argv=None) -> int:
     """What a caller runs in a child process per rank BEFORE its own process touches the GPU (`bench.py: isolated_probe`).
     Phase 1, the one-shot exchange: process group, set-up, self test and a free-running soak of real steps.  Phase 2, the
     RCCL form with the collective recorded into the step's hipGraph (`FusedTrainStep.capture_exchange`): capture, 32
-    replays, finite loss and bitwise-equal weights on every rank.  Verdicts go to the JSON file named by HCG_PROBE_OUT as
+    replays, then a two-step `StepWindow` replayed 8 times; finite loss and bitwise-equal weights on every rank.  Verdicts go to the JSON file named by HCG_PROBE_OUT as
     soon as a phase ends ({"oneshot": bool, "captured": bool}); exit code 0 = both passed.  What a `try` cannot catch in the
     caller's own process -- a GPU memory fault on a peer mapping aborts the process, a wedged collective never returns --
     ends this child instead, and the caller keeps the plain RCCL form.  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
@@ -274,6 +274,15 @@ def probe_main(argv=None) -> int:
                 last = st.replay()
             torch.cuda.synchronize()
             good = bool(torch.isfinite(last).item())
+            # ... and several steps with their collectives in ONE graph (what bench.py replays: train.StepWindow)
+            from .train import StepWindow
+            st2 = dp2.make_train_step()
+            st2.capture_exchange = True
+            win = StepWindow([st, st2], [fresh, fresh])
+            for _ in range(8):
+                last = win.replay()[-1]
+            torch.cuda.synchronize()
+            good = good and bool(torch.isfinite(last).item())
         except Exception as exc:                       # noqa: BLE001  (every rank still issues the collectives below)
             print(f"[xgmi probe] rank {rank}: captured form raised {type(exc).__name__}: {exc}", flush=True)
             good = False
