@@ -557,6 +557,8 @@ def main():
             raise SystemExit(f"bench.py: the process group reports world size {rccl_world}, expected {world}")
         dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place)
         exchange_mode = "rccl"
+        if not fused_ok and probe_ok is not None:             # (the autograd path uses neither graph form)
+            probe_ok = bool(probe_ok["oneshot"])
         if fused_ok:
             for tr in trainers + [fwdbwd]:
                 dp.attach(tr)
