@@ -747,7 +747,8 @@ class StepWindow:
         for i, st in enumerate(steps): st.capture(batch_fn[i], next_plan=plans[(i + 1) % n])
         window = StepWindow(steps, batch_fn);  losses = window.replay()      # one launch = n steps"""
 
-    def __init__(self, steps, batches):
+    def __init__(self, steps, batches, forward_only: bool = False):
+        """`forward_only`: the steps' `evaluate` form (plan, conv stack, head: loss only, nothing reduced or updated)."""
         steps, batches = list(steps), list(batches)
         if not steps or len(steps) != len(batches):
             raise ValueError("StepWindow needs as many batches as steps (at least one)")
@@ -760,7 +761,8 @@ class StepWindow:
                                     "(unless its `capture_exchange` is set: the collective is then recorded with the step)")
             if st.optimizer_step and not hasattr(model.optimizer, "enable_capturable"):
                 raise _lib.HcgError("StepWindow with optimizer_step needs hcatgnet_amd.optim.FusedAdam")
-        if steps[0].optimizer_step:
+        self.forward_only = bool(forward_only)
+        if steps[0].optimizer_step and not self.forward_only:
             model.optimizer.enable_capturable()
         self.steps, self.model = steps, model
         get = lambda b: b() if callable(b) else b
@@ -768,20 +770,20 @@ class StepWindow:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up: every buffer allocated, optimiser state re-based
             for st, b in zip(steps, batches):
-                st(get(b))
+                st(get(b), _forward_only=self.forward_only)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.losses = [st(get(b)) for st, b in zip(steps, batches)]
+            self.losses = [st(get(b), _forward_only=self.forward_only) for st, b in zip(steps, batches)]
         self._fp = [st._graph_fingerprint() for st in steps]
 
     def replay(self):
         """-> the steps' loss tensors (device scalars, overwritten by the next replay)."""
         if self._fp != [st._graph_fingerprint() for st in self.steps]:
             raise _lib.HcgError("StepWindow.replay(): parameter / optimiser / step buffers changed since the capture: build it again")
-        if self.steps[0].optimizer_step:
+        if self.steps[0].optimizer_step and not self.forward_only:
             self.model.optimizer.sync_lr()
         self.graph.replay()
         return self.losses
@@ -830,6 +832,41 @@ def train_network(model, train_loader, device):
     return float(total.item()) / len(train_loader.dataset)
 
 
+EVAL_WINDOW_MAX_BATCHES = 64
+
+
+def _eval_window(model, loader, fused):
+    """A `store.DeviceLoader` that does not shuffle yields the same batches every epoch (the reference's validation / test
+    loaders, call_methods.py:41-46): they are collated once, their `evaluate` steps captured as ONE hipGraph
+    (`StepWindow(forward_only=True)`) and an `eval_network` call is one graph launch + one reduction instead of
+    (collate + 3 launches) per batch.  -> the epoch's value, or None when this path does not apply (the caller loops)."""
+    from .store import DeviceLoader
+    if not (isinstance(loader, DeviceLoader) and not loader.shuffle and 0 < len(loader) <= EVAL_WINDOW_MAX_BATCHES):
+        return None
+    cache = getattr(loader, "_hcg_eval_window", None)
+    for attempt in range(2):
+        if cache is None or cache["model"] is not model:
+            batches = list(loader)
+            if not all(fused.reason(b) is None for b in batches):
+                return None
+            steps = [FusedTrainStep(model, optimizer_step=False) for _ in batches]
+            win = StepWindow(steps, batches, forward_only=True)
+            counts = torch.tensor([float(b.num_graphs) for b in batches], dtype=torch.float32, device=batches[0].x.device)
+            cache = {"model": model, "window": win, "batches": batches, "counts": counts}
+            try:
+                loader._hcg_eval_window = cache
+            except Exception:
+                pass
+        try:
+            losses = cache["window"].replay()
+        except _lib.HcgError:                 # parameters re-based since the capture (load_state_dict on new storages ...)
+            cache = None
+            continue
+        total = torch.dot(torch.stack(losses), cache["counts"])
+        return float(total.item()) / len(loader.dataset)
+    return None
+
+
 def eval_network(model, loader, device):
     """reference utils/utils_model.py:72-79 (forward + sqrt(MSE) per batch; no parameter update)."""
     model.eval()
@@ -840,6 +877,9 @@ def eval_network(model, loader, device):
             model._hcg_train_step = fused
         except Exception:
             pass
+    total = _eval_window(model, loader, fused)
+    if total is not None:
+        return total
     total = None
     with torch.no_grad():
         for batch in loader:

@@ -188,6 +188,35 @@ def test_step_window_equals_the_same_steps_one_by_one(H):
         StepWindow([FusedTrainStep(a, grad_sync=lambda flat: None)], [fresh[0]])
 
 
+def test_eval_network_window_equals_the_batch_loop(H):
+    """`eval_network` over a DeviceLoader that does not shuffle (the reference's validation / test loaders): the batches are
+    collated once and their evaluate steps replayed as ONE hipGraph.  Same value as the per-batch loop -- before training,
+    after the optimiser has re-based the parameters (the window is rebuilt), and after further epochs (the graph reads the
+    live weights); a shuffling loader keeps the loop."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep, eval_network, train_network
+    sb = synth.make_config("REAL", num_graphs=130)
+    store = H.DeviceGraphStore(sb.as_graph_list(), device="cuda")
+    val = H.DeviceLoader(store, batch_size=40)
+    trn = H.DeviceLoader(store, batch_size=40, shuffle=True, seed=3)
+    m = H.make_network("GCN", H.default_options(), 25).cuda()
+
+    def loop_value():
+        st = FusedTrainStep(m, optimizer_step=False)
+        tot = 0.0
+        for b in H.DeviceLoader(store, batch_size=40):
+            tot += float(st.evaluate(b)) * b.num_graphs
+        return tot / len(store)
+    for phase in range(3):
+        got, want = eval_network(m, val, "cuda"), loop_value()
+        assert abs(got - want) <= 1e-6 * abs(want), (phase, got, want)
+        assert getattr(val, "_hcg_eval_window", None) is not None
+        train_network(m, trn, "cuda")
+    assert getattr(trn, "_hcg_eval_window", None) is None
+    v = eval_network(m, trn, "cuda")                      # shuffling loader: the loop, no window
+    assert getattr(trn, "_hcg_eval_window", None) is None and v > 0
+
+
 def test_train_network_mirror_runs_an_epoch_and_learns(H):
     """hcatgnet_amd.train.train_network / eval_network / predict_network: the reference's loop signatures
     (utils/utils_model.py:55-111) over a DeviceLoader; fused step for 30-atom graphs, autograd fallback for graphs
