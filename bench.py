@@ -111,7 +111,7 @@ def self_launch(args) -> int:
     return rc
 
 
-def isolated_probe(world, rehearsal, combine, timeout_s=300.0):
+def isolated_probe(world, rehearsal, combine, timeout_s=420.0):
     """Both data-parallel graph forms tried once in a CHILD process per rank (`python -m hcatgnet_amd.xgmi`: its own process
     group on the next port; the one-shot exchange with set-up, self test and 64 free-running real steps; then the RCCL
     collective recorded into the step's hipGraph, 32 replays) before THIS process touches the GPU.  A failure no `try` can
