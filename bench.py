@@ -58,6 +58,8 @@ def parse():
                          "gradients into the peers' inboxes over the direct xGMI links inside the slab reduction + Adam launch; "
                          "'auto' = one-shot if it sets up and passes its self test on this machine, else RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="development only: skip the oracle check in front of the timings "
+                    "(the JSON line then says parity_gate: null)")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged-batch measurement")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--roofline-entry", default=None, help="C-ABI entry point timed for the roofline object")
@@ -279,6 +281,64 @@ def cpu_baseline(cfg_name, num_graphs, steps):
             "one_thread": {"value": sb.num_graphs / med_1t, "ms_per_step": med_1t * 1e3, "cores": 1, "steps": n_1t}}
 
 
+def parity_gate(model, r0, trainer, forward_only, dev):
+    """"parity gates -- run before any timing is accepted".  Step 0 on batch 0 of the rotation through the
+    product path (the same FusedTrainStep / C-ABI launches the timed loop issues, gradients only) against the fp64 CPU oracle:
+    loss, outputs, pooled embedding and EVERY gradient tensor.  Batch 0 is first made decidable (oracle/screen.py: the node
+    features of the few graphs that own an activation within 2e-6 of the LeakyReLU kink or a max-pool near-tie are re-drawn
+    -- one such element legitimately moves a weight gradient by ~1e-3); the timed rotation uses the screened batch.
+    The oracle is the CHECKER here, never the thing measured.  -> the `parity_gate` object of the JSON line."""
+    import torch
+    from oracle import gcn_oracle, screen
+    t0 = time.perf_counter()
+    sb = r0.sb
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x_cpu, redrawn = screen.make_decidable(params, sb.x, sb.edge_index, sb.batch, sb.num_graphs, seed=sb.num_graphs)
+    sb.x = x_cpu
+    r0.x.copy_(x_cpu.to(dev))
+
+    def rel(a, ref, floor=1e-30):
+        a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+        return float((a - ref).abs().max()) / max(float(ref.abs().max()), floor)
+    tol, tol_w = 1e-5, 1e-4
+    errs, limits = {}, {}
+    if forward_only:
+        with torch.no_grad():
+            out, emb = model(r0.fresh(), True)
+        o_out, o_emb = gcn_oracle.gcn_forward({k: v.double() for k, v in params.items()}, sb.x.double(), sb.edge_index, sb.batch,
+                                              sb.num_graphs)
+        errs.update(out=rel(out, o_out, 1.0), emb=rel(emb, o_emb))
+        limits.update(out=tol, emb=tol)
+    else:
+        if trainer is not None:                    # the no-autograd step the timed loop issues
+            loss = trainer(r0.fresh())
+            out, emb = trainer.last_out, trainer._bufs["cap"]["emb"][:sb.num_graphs]
+        else:                                      # models outside the fused step: the autograd path (same kernels per op)
+            model.optimizer.zero_grad(set_to_none=True)
+            out, emb = model(r0.fresh(), True)
+            loss = torch.sqrt(model.loss(out, r0.y2))
+            loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        o_loss, o_out, o_emb, o_grads = gcn_oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs,
+                                                                    dtype=torch.float64)
+        errs.update(loss=abs(float(loss) - float(o_loss)) / abs(float(o_loss)), out=rel(out, o_out, 1.0), emb=rel(emb, o_emb))
+        limits.update(loss=tol, out=tol, emb=tol)
+        for k, g in grads.items():
+            errs["d" + k] = rel(g, o_grads[k])
+            limits["d" + k] = tol_w if k.endswith("lin.weight") else tol     # conv weights sum > 1e5 terms (SURVEY 8d)
+    failed = [k for k in errs if not (errs[k] <= limits[k])]
+    return {"passed": not failed, "failed": failed, "errors": errs, "worst": max(errs.values()),
+            "tolerance": {"default": tol, "conv_weight_gradients": tol_w, "metric": "||d||_inf / ||ref||_inf per tensor (outputs: max(||ref||_inf, 1))"},
+            "oracle": "oracle/gcn_oracle.py in fp64 on the host (torch CPU restatement of the reference's PyG path, pinned bit-exact "
+                      "on the reference's embeddings.csv)",
+            "what": ("forward of batch 0" if forward_only else
+                     "step 0 of batch 0: loss, outputs, pooled embedding, every gradient tensor") +
+                    f" ({sb.num_graphs} graphs; {redrawn} graphs' features re-drawn by oracle/screen.py so that LeakyReLU / arg-max "
+                    f"branches are decidable at fp32)",
+            "seconds": time.perf_counter() - t0}
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -382,6 +442,25 @@ def main():
     trainers = [FusedTrainStep(model, optimizer_step=True) for _ in res] if fused_ok else []
     fwdbwd = FusedTrainStep(model, optimizer_step=False) if fused_ok else None
     dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
+
+    # ---- parity gate: no timing is accepted unless step 0 of batch 0 matches the oracle
+    gate = None
+    if not args.no_parity_gate:
+        gate = parity_gate(model, r0, fwdbwd, args.forward_only, dev)
+        log(f"parity gate: {'PASSED' if gate['passed'] else 'FAILED ' + str(gate['failed'])} (worst {gate['worst']:.2e}, {gate['seconds']:.1f} s)")
+
+    def refuse_timing(why):
+        """A failed parity gate: ONE JSON line without a `value` (no timing is accepted), exit code 1."""
+        if rank == 0:
+            rec = {"metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s", "value": None, "unit": "graphs/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": f"{args.config}: not timed -- {why}"}, "parity_gate": gate}
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(rec) + "\n").encode())
+        raise SystemExit(1)
+    if gate is not None and world == 1 and not gate["passed"]:
+        refuse_timing("the parity gate failed")
 
     def autograd_step(i=0, with_opt=True):
         model.optimizer.zero_grad(set_to_none=True)
@@ -555,6 +634,14 @@ def main():
         rccl_world = dist.get_world_size()
         if rccl_world != world:
             raise SystemExit(f"bench.py: the process group reports world size {rccl_world}, expected {world}")
+        if gate is not None:                                  # every rank gated its own batch 0: one failure refuses the run
+            gv = torch.tensor([1 if gate["passed"] else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(gv, op=dist.ReduceOp.MIN)
+            gate["passed_on_every_rank"] = bool(int(gv.item()))
+            if not gate["passed_on_every_rank"]:
+                dist.barrier()
+                dist.destroy_process_group()
+                refuse_timing("the parity gate failed on at least one rank")
         dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place)
         exchange_mode = "rccl"
         if not fused_ok and probe_ok is not None:             # (the autograd path uses neither graph form)
@@ -862,6 +949,7 @@ def main():
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
                                       f"of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
+            "parity_gate": gate,
             "rccl_world": rccl_world, "exchange": exchange_mode,
             # the child-process trials: of the one-shot exchange, and of the RCCL collective recorded into the step's graph
             "exchange_probe": (None if probe_ok is None else ("passed" if probe_ok else "failed")),

@@ -80,6 +80,8 @@ class FusedTrainStep:
         # data parallel: a `xgmi.OneShotExchange` (set by its `attach`): the gradient exchange then happens INSIDE the slab
         # reduction + Adam launch instead of as an RCCL collective between two launches
         self.exchange = None
+        self._last_carried = False              # the last step's update launch carried reduction + (exchange) + Adam
+        self.exchange_fallback_sync = None      # the collective hook `OneShotExchange.attach` took out of `grad_sync`
         # one-device rehearsals only (two ranks sharing a GPU): called right before the launch that carries the exchange.
         # A rank's polling launch fills every CU, and the OTHER process's conv kernels (488 of a SIMD's 512 VGPRs per
         # workgroup) cannot be placed beside it, so on one device the ranks must meet (synchronize + barrier) before that
@@ -305,6 +307,7 @@ class FusedTrainStep:
             _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
             njobs += 1
         join()
+        self._last_carried = step_word is not None
         if step_word is not None:
             if self.exchange is not None and self.pre_exchange_hook is not None:
                 self.pre_exchange_hook()
@@ -595,6 +598,7 @@ class FusedTrainStep:
             dh = dx
         # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
         #      are one launch (the update reads each gradient element as it is produced)
+        self._last_carried = step_word is not None
         if step_word is not None:
             if self.exchange is not None and self.pre_exchange_hook is not None:
                 self.pre_exchange_hook()
@@ -613,10 +617,18 @@ class FusedTrainStep:
     def _exchange_and_update(self, loss_buf):
         """Behind the slab reduction: gradient exchange (data parallel), the "sse" scale, the optimiser."""
         lib, opt, flat = _lib.load(), self.model.optimizer, self._flat
+        sync = self.grad_sync
+        if sync is None and self.exchange is not None:
+            # a one-shot exchange is attached but this step's update is not the fused launch that carries it (any-shape head,
+            # optimiser state not one flat group): the ranks exchange through the collective instead -- never not at all
+            sync = self.exchange_fallback_sync
+            if sync is None:
+                raise _lib.HcgError("a one-shot exchange is attached, this step cannot carry it and no collective fallback is "
+                                    "set: the replicas would diverge")
         if self.combine == "sse":
             ext = self._flat_ext
-            if self.grad_sync is not None:
-                self.grad_sync(ext)                          # SUM of [gradients | SSE | count] over the ranks
+            if sync is not None:
+                sync(ext)                                    # SUM of [gradients | SSE | count] over the ranks
             if self.optimizer_step and hasattr(opt, "step_sse"):
                 self._flat_grads(self._trainable(), flat.device)
                 opt.step_sse(ext, loss_buf)                  # scale + update, one launch
@@ -626,8 +638,8 @@ class FusedTrainStep:
                 if self.optimizer_step:
                     opt.step()
             return
-        if self.grad_sync is not None:
-            self.grad_sync(flat)
+        if sync is not None:
+            sync(flat)
         if self.optimizer_step:
             # the update reads the parameters' `.grad`: they must be views of THIS trainer's buffer (another trainer on
             # the same model may have re-pointed them since)
@@ -673,6 +685,9 @@ class FusedTrainStep:
                 self(get())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        orig_sync = sync
+        if sync is None and self.exchange is not None and not self._last_carried:
+            sync = self.exchange_fallback_sync         # (this step's update cannot carry the one-shot exchange: collective form)
         split = sync is not None and not self.capture_exchange
         try:
             if split or sync is None:
@@ -693,7 +708,7 @@ class FusedTrainStep:
                 if fork is not None:
                     main.wait_stream(fork)
         finally:
-            self.grad_sync, self._capturing_split = sync, False
+            self.grad_sync, self._capturing_split = orig_sync, False
         self._graph = (g_main, loss, split, self._graph_fingerprint())
         return self
 

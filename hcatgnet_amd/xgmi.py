@@ -93,7 +93,14 @@ class OneShotExchange:
             raise ValueError(f"exchange built for {self.n} gradients, the model has {n}")
         if not (step.optimizer_step and hasattr(step.model.optimizer, "step_with_reduction")):
             raise ValueError("the one-shot exchange rides in the fused update: it needs optimizer_step=True and FusedAdam")
+        if step.grad_sync is None:
+            raise ValueError("attach the trainer to a DataParallelGCN first (`dp.attach(step)` / `dp.make_train_step()`): its "
+                             "collective stays behind as the fallback of the steps the fused update cannot carry")
         step.exchange = self
+        # steps whose last launch cannot carry the exchange (a readout the one-launch head does not cover, an optimiser whose
+        # state is not one flat group) must still exchange: they take the collective this hook performs (such a
+        # step used to run with NO exchange at all and the replicas drifted apart silently)
+        step.exchange_fallback_sync = step.grad_sync
         step.grad_sync = None
         return step
 

@@ -434,3 +434,80 @@ def test_one_shot_exchange_two_ranks_equals_the_collective_path(H, oracle):
     assert np.array_equal(r0["w"], r1["w"])                                    # replicas bitwise in sync
     for k in r0["grads"]:
         assert np.array_equal(r0["grads"][k], r1["grads"][k]), k
+
+
+def _rank_main_xchg_generic_head(rank, world, port, q):
+    """Two ranks, a one-shot exchange attached, and a model whose readout the one-launch head does not cover (9 classes >
+    RCMAX): the update launch cannot carry the exchange, so the step must fall back to the collective."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hcatgnet_amd as H
+        from hcatgnet_amd import _lib, synth
+        from hcatgnet_amd.ddp import DataParallelGCN
+        from hcatgnet_amd.xgmi import OneShotExchange
+        C = 9
+        assert not _lib.load().hcg_head_supported(64, C)
+        sb = synth.make_config("C2", num_graphs=40 + 10 * rank, rank=rank)
+        mine = sb.as_batch("cuda")
+        mine.y = torch.randn(sb.num_graphs, C, generator=torch.Generator().manual_seed(5 + rank)).cuda()
+        m = H.make_network("GCN", H.default_options(n_classes=C), 64).cuda()
+        twin = H.make_network("GCN", H.default_options(n_classes=C), 64).cuda()
+        dp, dp_twin = DataParallelGCN(m, combine="sse"), DataParallelGCN(twin, combine="sse")
+        xchg = OneShotExchange(sum(p.numel() for p in m.parameters()))
+        res = {"rank": rank, "ok": bool(xchg.ok and xchg.self_test())}
+        if res["ok"]:
+            step = xchg.attach(dp.make_train_step())
+            ref = dp_twin.make_train_step()
+            losses = [(float(step(mine)), float(ref(mine))) for _ in range(3)]
+            res["carried"] = bool(step._last_carried)
+            res["losses"] = losses
+            res["w"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy().copy()
+            res["w_ref"] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu().numpy().copy()
+            try:                                     # without a collective to fall back on, the step refuses instead of drifting
+                lone = FusedTrainStepLone(m, xchg)
+                lone(mine)
+                res["lone_raised"] = False
+            except _lib.HcgError:
+                res["lone_raised"] = True
+        q.put(res)
+        xchg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def FusedTrainStepLone(model, xchg):
+    """A trainer with an exchange but no collective behind it (what `attach` now refuses to build)."""
+    from hcatgnet_amd.train import FusedTrainStep
+    st = FusedTrainStep(model, combine="sse")
+    st.exchange = xchg
+    return st
+
+
+def test_one_shot_exchange_falls_back_to_the_collective_when_the_update_cannot_carry_it(H):
+    """a trainer with a one-shot exchange attached whose step has no fused update launch (any-shape
+    head) used to run with NO gradient exchange.  Now it takes the collective: both ranks' weights stay bitwise equal and
+    equal the plain collective path; a trainer with neither raises."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_xchg_generic_head, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0["ok"] and r1["ok"], "one-shot exchange did not set up / pass its self test"
+    for r in (r0, r1):
+        assert r["carried"] is False and r["lone_raised"] is True
+        assert np.array_equal(r["w"], r["w_ref"])                 # the same collective + update as the plain data-parallel step
+        for a, b in r["losses"]:
+            assert a == b
+    assert np.array_equal(r0["w"], r1["w"])                       # replicas in sync
+    assert r0["losses"][0][0] == r1["losses"][0][0]               # "sse": every rank reports the global loss
