@@ -113,31 +113,62 @@ def self_launch(args) -> int:
     return rc
 
 
-def isolated_probe(world, rehearsal, combine, timeout_s=420.0):
+PROBE_BUDGET_S = 90.0     # the child-process trial of the two graph forms; + in-process self test and soak (bounded polls,
+                          # < 30 s): <= 120 s of a multi-GPU run go to deciding the exchange form
+
+
+def probe_port(world, rank):
+    """A port for the child process groups: rank 0 binds port 0 (a free one), the others read it from the launcher's store
+    (torchrun hosts a TCPStore at MASTER_ADDR:MASTER_PORT).  Without such a store: MASTER_PORT + 1."""
+    fallback = (int(os.environ.get("MASTER_PORT", "29500")) - 1024 + 1) % (65535 - 1024) + 1024
+    try:
+        import socket
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world, False,
+                         timedelta(seconds=20))
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            store.set("hcg_probe_port", str(port))
+            return port
+        return int(store.get("hcg_probe_port").decode())
+    except Exception as exc:      # noqa: BLE001  (no agent store: every rank derives the same fallback)
+        log(f"probe port: no launcher store ({type(exc).__name__}); using MASTER_PORT + 1")
+        return fallback
+
+
+def isolated_probe(world, rank, rehearsal, combine, timeout_s=PROBE_BUDGET_S):
     """Both data-parallel graph forms tried once in a CHILD process per rank (`python -m hcatgnet_amd.xgmi`: its own process
-    group on the next port; the one-shot exchange with set-up, self test and 64 free-running real steps; then the RCCL
-    collective recorded into the step's hipGraph, 32 replays) before THIS process touches the GPU.  A failure no `try` can
-    catch -- a GPU memory fault on a peer mapping aborts the process, a wedged launch or collective never returns -- then ends
-    the child, not the bench.  -> {"oneshot": bool, "captured": bool}: what the child had recorded when it ended (a phase it
-    never finished counts as failed); the plain RCCL form needs neither.  Stdlib only (nothing here may initialise HIP)."""
+    group; the one-shot exchange with set-up, self test and 64 free-running real steps; then the RCCL collective recorded
+    into the step's hipGraph, 32 replays) before THIS process touches the GPU.  A failure no `try` can catch -- a GPU memory
+    fault on a peer mapping aborts the process, a wedged launch or collective never returns -- then ends the child, not the
+    bench.  -> {"oneshot": bool, "captured": bool, "exit": code, "seconds": s, "note": last line of the child's log}: a
+    phase the child never finished counts as failed; the plain RCCL form needs neither.  No GPU call here."""
     import tempfile
     env = dict(os.environ)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child group's rank 0 hosts its own store ...
     env["MASTER_ADDR"] = "127.0.0.1"
-    env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) - 1024 + 1) % (65535 - 1024) + 1024)   # ... on the next port
+    env["MASTER_PORT"] = str(probe_port(world, rank))      # ... on a port rank 0 found free
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
     fd, out_path = tempfile.mkstemp(prefix="hcg_probe_", suffix=".json")
+    os.close(fd)
+    fd, log_path = tempfile.mkstemp(prefix="hcg_probe_", suffix=".log")
     os.close(fd)
     env["HCG_PROBE_OUT"] = out_path
     cmd = [sys.executable, "-m", "hcatgnet_amd.xgmi", "--combine", combine]
     if rehearsal:
         cmd += ["--one-device", "--soak-steps", "0"]      # (two ranks on one device starve each other in a free-running soak)
     t0 = time.perf_counter()
-    verdicts = {"oneshot": False, "captured": False}
+    verdicts = {"oneshot": False, "captured": False, "exit": None, "seconds": 0.0, "note": None}
+    log(f"data-parallel probe: child process group on port {env['MASTER_PORT']}, budget {timeout_s:.0f} s")
     try:
-        proc = subprocess.Popen(cmd, env=env, stdout=sys.stderr, stderr=sys.stderr, start_new_session=True)
+        logf = open(log_path, "w")
+        proc = subprocess.Popen(cmd, env=env, stdout=logf, stderr=subprocess.STDOUT, start_new_session=True)
     except OSError as exc:
+        verdicts["note"] = f"could not start: {exc}"
         log(f"data-parallel probe could not start ({exc}): plain RCCL form")
         return verdicts
     try:
@@ -149,16 +180,27 @@ def isolated_probe(world, rehearsal, combine, timeout_s=420.0):
             pass
         proc.wait()
         rc = -9
+    logf.close()
     try:
         got = json.load(open(out_path))
-        verdicts.update({k: bool(got.get(k, False)) for k in verdicts})
+        verdicts.update({k: bool(got.get(k, False)) for k in ("oneshot", "captured")})
     except (OSError, ValueError):
         pass
     try:
-        os.unlink(out_path)
+        lines = [ln.strip() for ln in open(log_path, errors="replace").read().splitlines() if ln.strip()]
+        for ln in lines[-12:]:
+            print("[probe child] " + ln, file=sys.stderr, flush=True)
+        verdicts["note"] = ("killed at the time limit; " if rc == -9 else "") + (lines[-1][:200] if lines else "no output")
     except OSError:
         pass
-    log(f"data-parallel probe (child process, world {world}): exit {rc} after {time.perf_counter() - t0:.1f} s -> {verdicts}")
+    for path in (out_path, log_path):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    verdicts["exit"], verdicts["seconds"] = rc, time.perf_counter() - t0
+    log(f"data-parallel probe (child process, world {world}): exit {rc} after {verdicts['seconds']:.1f} s -> "
+        f"oneshot {verdicts['oneshot']}, captured {verdicts['captured']}")
     return verdicts
 
 
@@ -166,10 +208,9 @@ class EntryTimer:
     """HIP-event timing of ONE C-ABI entry point on the stream it launches on (torch's current
     stream: the library only enqueues on the stream it is handed)."""
 
-    # entry points that launch the SAME kernel family as the named one (training forms of the pooled layer)
-    SAME_KERNEL = {"hcg_fused_layer_bwd": ("hcg_fused_layer_bwd_poolbits",),
-                   "hcg_fused_stack2_fwd": ("hcg_fused_stack2_fwd_train",),
-                   "hcg_fused_layer_fwd": ("hcg_fused_layer_fwd_train",)}
+    # entry points that launch the SAME kernel family as the named one (none since the forward / backward forms of the
+    # small-graph tiles are one entry point each)
+    SAME_KERNEL = {}
 
     def __init__(self, lib, name):
         import torch
@@ -355,18 +396,19 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    # N > 1, --exchange auto: the one-shot exchange has to survive a sacrificial child process group first (before anything
-    # here touches the GPU); the ranks combine their verdicts once the real process group is up
-    probe_ok, probe_captured = None, False
+    rehearsal = os.environ.get("HCG_BENCH_REHEARSAL") == "1"
+    # N > 1, --exchange auto: the two graph forms of the exchange have to survive a sacrificial child process group first
+    # (before anything here touches the GPU); the ranks combine their verdicts once the real process group is up
+    probe = None
     if (world > 1 and args.exchange == "auto" and not args.forward_only
-            and (os.environ.get("HCG_BENCH_REHEARSAL") != "1" or os.environ.get("HCG_PROBE_IN_REHEARSAL") == "1")):
-        probe_ok = isolated_probe(world, os.environ.get("HCG_BENCH_REHEARSAL") == "1", args.combine)
+            and (not rehearsal or os.environ.get("HCG_PROBE_IN_REHEARSAL") == "1")):
+        import torch  # noqa: F401  (no GPU call: pages the libraries in, so that the child's import does not eat its time limit)
+        probe = isolated_probe(world, rank, rehearsal, args.combine, timeout_s=PROBE_BUDGET_S)
 
     import torch
     import torch.distributed as dist
     # rehearsal of the N > 1 control flow on a ONE-GPU box (tools/rehearse_multi_rank.sh): every rank on device 0,
     # gloo instead of RCCL (RCCL refuses two ranks on one device).  Never set by the driver; the numbers mean nothing.
-    rehearsal = os.environ.get("HCG_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
     if not torch.cuda.is_available():
@@ -376,19 +418,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import hcatgnet_amd as H
-    from hcatgnet_amd import _lib, algbytes, synth
+    from hcatgnet_amd import _lib, algbytes, launch, synth
     from hcatgnet_amd.ddp import DataParallelGCN
     from hcatgnet_amd.train import FusedTrainStep
     if os.environ.get("HCG_LIB"):      # a library variant for A/B measurements (tools/build_variants.sh)
         _lib.LIB_PATH = os.path.abspath(os.environ["HCG_LIB"])
     lib = _lib.load()
     # development A/B switches (tools/ab_env.sh): measurement tooling only, the product has no environment switches
-    if os.environ.get("HCG_NO_POOLBITS") == "1":
-        FusedTrainStep.POOLBITS = False
-    if os.environ.get("HCG_NO_PREMASK") == "1":
-        FusedTrainStep.PREMASK = False
-    if os.environ.get("HCG_NO_OVERLAP") == "1":
-        FusedTrainStep.OVERLAP_GROUPS = False
+    for env, attr in (("HCG_NO_POOLBITS", "POOLBITS"), ("HCG_NO_PREMASK", "PREMASK"), ("HCG_NO_OVERLAP", "OVERLAP_GROUPS"),
+                      ("HCG_NO_HEAD_IN_FORWARD", "HEAD_IN_FORWARD")):
+        if os.environ.get(env) == "1":
+            setattr(FusedTrainStep, attr, False)
     log(f"rank {rank}/{world}: library loaded")
 
     cfg_name = args.config
@@ -441,7 +481,7 @@ def main():
     # step buffers) per resident batch; `fwdbwd` stops after the backward (gradients only: secondary figure, batch 0)
     trainers = [FusedTrainStep(model, optimizer_step=True) for _ in res] if fused_ok else []
     fwdbwd = FusedTrainStep(model, optimizer_step=False) if fused_ok else None
-    dp = None            # created after the hipGraph capture: no RCCL activity while a stream is capturing
+    dp = None
 
     # ---- parity gate: no timing is accepted unless step 0 of batch 0 matches the oracle
     gate = None
@@ -462,6 +502,56 @@ def main():
     if gate is not None and world == 1 and not gate["passed"]:
         refuse_timing("the parity gate failed")
 
+    def barrier():
+        if world > 1:
+            dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
+
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def timed(k, runner, start=0):
+        """runner(start, k) issues EXACTLY k steps; bracketed by barrier + synchronize on the way in and synchronize on the
+        way out (the closing barrier sits OUTSIDE the bracket: inside it cost ~2 % of a 20-step bracket at N = 8); MAX over
+        ranks.  The interpreter's cyclic garbage collector is off inside the bracket: a full collection of a process that
+        has imported torch takes ~80 ms -- four hundred steps' worth -- and lands wherever the allocation counters say (seen:
+        once in a 200-step burst loop, 0.106 -> 0.50 ms/step).  Nothing of the step is skipped by that."""
+        barrier()
+        torch.cuda.synchronize()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            runner(start, k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            if gc_was:
+                gc.enable()
+        barrier()
+        return max_over_ranks(dt)
+
+    def sustain(seconds, runner):
+        """The rotation for at least `seconds`: chunks of steps, one synchronize per chunk.  -> (steps, seconds, next index)"""
+        barrier()
+        torch.cuda.synchronize()
+        t0, n, chunk = time.perf_counter(), 0, 256
+        while True:
+            runner(n % NB, chunk)
+            n += chunk
+            torch.cuda.synchronize()
+            el = max_over_ranks(time.perf_counter() - t0)      # every rank must leave the loop after the same chunk
+            if el >= seconds:
+                return n, el, n % NB
+            if n % (chunk * 16) == 0:
+                log(f"sustained rotation: {n} steps, {el:.1f} s")
+
+    log(f"inputs resident: {NB} batches of N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
+
+    # ---- the autograd / forward-only paths (models or flags outside the fused step): eager or one graph per step
     def autograd_step(i=0, with_opt=True):
         model.optimizer.zero_grad(set_to_none=True)
         out = model(res[i].fresh())                      # plan build + forward
@@ -477,129 +567,79 @@ def main():
         with torch.no_grad():
             return model(res[i].fresh())
 
-    def eager_step(i=0, with_opt=True):
-        if args.forward_only:
-            return forward_step(i)
-        if not fused_ok:
-            return autograd_step(i, with_opt)
-        return (trainers[i] if with_opt else fwdbwd)(res[i].fresh())
+    class PlainRotation:
+        """The same interface as launch.Rotation for steps that are not a FusedTrainStep (forward only / autograd path)."""
+        def __init__(self):
+            self.graph_runs, self.errors, self.window, self.graphs, self.NB = None, {}, None, False, NB
 
-    replay = {}
+        def eager(self, i):
+            return forward_step(i) if args.forward_only else autograd_step(i)
 
-    def capture_all():
-        """Everything the step enqueues (plan build, forward, head with loss, backward, slab reduction, Adam) goes
-        into hipGraphs, one per resident batch; with N > 1 the RCCL all-reduce stays an eager call between the backward
-        graph and the (single-launch) update."""
-        if args.forward_only or not fused_ok:
+        def capture(self):
             runs = []
-            for i in range(NB):
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
+            try:
+                for i in range(NB):
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(3):
+                            forward_step(i) if args.forward_only else autograd_step(i, False)
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    if not args.forward_only:
+                        model.optimizer.zero_grad(set_to_none=True)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
                         forward_step(i) if args.forward_only else autograd_step(i, False)
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                if not args.forward_only:
-                    model.optimizer.zero_grad(set_to_none=True)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    forward_step(i) if args.forward_only else autograd_step(i, False)
-                grads = [] if args.forward_only else [p.grad for p in model.parameters()]
+                    grads = [] if args.forward_only else [p.grad for p in model.parameters()]
 
-                def run(with_opt=True, g=g, grads=grads):
-                    g.replay()
-                    if args.forward_only:
-                        return
-                    for p, gr in zip(model.parameters(), grads):
-                        p.grad = gr
-                    if dp is not None:
-                        dp.reduce_gradients(grads=grads)
-                    if with_opt:
+                    def run(g=g, grads=grads):
+                        g.replay()
+                        if args.forward_only:
+                            return
+                        for p, gr in zip(model.parameters(), grads):
+                            p.grad = gr
+                        if dp is not None:
+                            dp.reduce_gradients(grads=grads)
                         model.optimizer.step()
-                runs.append(run)
-            replay["full"] = runs
-            replay["fwdbwd"] = lambda: runs[0](False)
-            return
-        # every step derives ONE plan (graph_ptr / edge_ptr / validation from the int64 inputs): its own, in front of its forward;
-        # with --plan-overlap the NEXT batch's, on a forked branch of the graph beside this step's kernels
+                    runs.append(run)
+                err = None
+            except Exception as exc:      # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"
+            self.graphs = launch.all_ranks_agree(err is None, dev)
+            if self.graphs:
+                self.graph_runs = runs
+            else:
+                self.errors["graph"] = err or "capture failed on another rank"
+            return self.graphs
+
+        def build_windows(self, k):
+            return False
+
+        def forms(self):
+            return ["eager"] + (["graph"] if self.graphs else [])
+
+        def run(self, form, start, k):
+            for j in range(k):
+                i = (start + j) % NB
+                self.eager(i) if form == "eager" else self.graph_runs[i]()
+
+        pick = launch.Rotation.pick
+
+        def losses_finite(self):
+            return True
+
+    if fused_ok:
         for r in res:
             r.make_plan()
-        for i, tr in enumerate(trainers):
-            if args.plan_overlap == "none":
-                tr.capture(res[i].fresh)
-            elif args.plan_overlap == "fork":
-                tr.capture(res[i].planned, prefetch=res[(i + 1) % NB].plan.rebuild)
-            else:           # "fused": the step's last launch (slab reduction + Adam) also derives the next batch's plan
-                tr.capture(res[i].planned, next_plan=res[(i + 1) % NB].plan)
-        fwdbwd.capture(r0.fresh)
-        replay["full"] = [tr.replay for tr in trainers]
-        replay["fwdbwd"] = fwdbwd.replay
-
-    def barrier():
-        if world > 1:
-            dist.barrier(**({} if rehearsal else {"device_ids": [local_rank]}))
-
-    def max_over_ranks(dt):
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
-    def timed(k, fn, start=0, runner=None):
-        """K calls fn(i), i = start, start + 1, ... (mod NB) -- or runner(start, K), which issues exactly those K steps, several per
-        graph launch where it can -- bracketed by barrier + synchronize; MAX over ranks.
-        The interpreter's cyclic garbage collector is off inside the bracket: a full collection of a process that has
-        imported torch takes ~80 ms -- four hundred steps' worth -- and lands wherever the allocation counters say (seen:
-        once in the 200-step burst loop, 0.106 -> 0.50 ms/step).  Nothing of the step is skipped by that."""
-        barrier()
-        torch.cuda.synchronize()
-        gc_was = gc.isenabled()
-        gc.disable()
-        try:
-            t0 = time.perf_counter()
-            if runner is not None:
-                runner(start, k)
-            else:
-                for j in range(k):
-                    fn((start + j) % NB)
-            torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t0
-        finally:
-            if gc_was:
-                gc.enable()
-        return max_over_ranks(dt)
-
-    def sustain(seconds, fn, runner=None):
-        """The rotation for at least `seconds`: chunks of steps, one synchronize per chunk.  -> (steps, seconds, next index)"""
-        barrier()
-        torch.cuda.synchronize()
-        t0, n, chunk = time.perf_counter(), 0, 256
-        while True:
-            if runner is not None:
-                runner(n % NB, chunk)
-            else:
-                for j in range(chunk):
-                    fn((n + j) % NB)
-            n += chunk
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            if world > 1:    # every rank must leave the loop after the same chunk
-                t = torch.tensor([el], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            if el >= seconds:
-                return n, el, n % NB
-            if n % (chunk * 16) == 0:
-                log(f"sustained rotation: {n} steps, {el:.1f} s")
-
-    log(f"inputs resident: {NB} batches of N={N} E={E} B={B} F={F} D={D}; fused trainer: {fused_ok}")
+        rot = launch.Rotation(trainers, [r.fresh for r in res], [r.planned for r in res], [r.plan for r in res],
+                              plan_overlap=args.plan_overlap)
+    else:
+        rot = PlainRotation()
 
     def count_launching_calls():
         """Library entry points that enqueue kernels during ONE eager step (launches per step)."""
-        skip = ("_bytes", "_job", "_supported", "_per_tile", "hcg_version", "hcg_error_string")
+        skip = ("_bytes", "_job", "_supported", "_per_tile", "_blocks", "hcg_version", "hcg_error_string", "hcg_reduce_job_append")
         names = [n for n in _lib.SIGNATURES if not n.endswith(skip) and n not in skip]
         counts, origs = {}, {}
         for n in names:
@@ -610,21 +650,20 @@ def main():
                 return origs[_n](*a)
             setattr(lib, n, wrap)
         try:
-            eager_step()
+            rot.eager(0)
             torch.cuda.synchronize()
         finally:
             for n in names:
                 setattr(lib, n, origs[n])
         return counts
     for j in range(max(args.warmup, NB)):
-        eager_step(j % NB)
+        rot.eager(j % NB)
     torch.cuda.synchronize()
     log("warm-up done")
     launch_counts = count_launching_calls()
 
-    # ---- N > 1: process group, weights replicated, the gradient exchange chosen -- BEFORE the capture, so that a one-shot
-    #      exchange (inside the step's last launch) is captured with the step
-    rccl_world, exchange_mode, xchg = None, "none", None
+    # ---- N > 1: process group, weights replicated
+    rccl_world, xchg = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -635,206 +674,180 @@ def main():
         if rccl_world != world:
             raise SystemExit(f"bench.py: the process group reports world size {rccl_world}, expected {world}")
         if gate is not None:                                  # every rank gated its own batch 0: one failure refuses the run
-            gv = torch.tensor([1 if gate["passed"] else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(gv, op=dist.ReduceOp.MIN)
-            gate["passed_on_every_rank"] = bool(int(gv.item()))
+            gate["passed_on_every_rank"] = launch.all_ranks_agree(gate["passed"], dev)
             if not gate["passed_on_every_rank"]:
                 dist.barrier()
                 dist.destroy_process_group()
                 refuse_timing("the parity gate failed on at least one rank")
         dp = DataParallelGCN(model, combine=args.combine)    # broadcasts rank-0 weights (in place)
-        exchange_mode = "rccl"
-        if not fused_ok and probe_ok is not None:             # (the autograd path uses neither graph form)
-            probe_ok = bool(probe_ok["oneshot"])
-        if fused_ok:
-            for tr in trainers + [fwdbwd]:
-                dp.attach(tr)
-            probe_captured = False
-            if probe_ok is not None:       # every rank's child verdicts, combined: one failure anywhere = that form nowhere
-                pv = torch.tensor([1 if probe_ok["oneshot"] else 0, 1 if probe_ok["captured"] else 0], device=dev, dtype=torch.int32)
-                dist.all_reduce(pv, op=dist.ReduceOp.MIN)
-                probe_ok, probe_captured = bool(int(pv[0].item())), bool(int(pv[1].item()))
-            if probe_ok is False:
-                log("one-shot exchange: its probe in a child process group did not pass on every rank -- RCCL all-reduce stays")
-            elif rehearsal and args.exchange == "auto":
-                log("rehearsal (ranks share one device): a polling launch of one rank leaves no room for the other rank's conv "
-                    "kernels on the same GPU -- the one-shot exchange needs one GPU per rank; RCCL-form exchange (gloo) here")
-            elif args.exchange != "rccl":
-                # the one-shot xGMI exchange, if it sets up and passes its self test against the process group's own
-                # all-reduce on THIS machine (every rank gets the same verdict); else the RCCL collective stays
-                from hcatgnet_amd.xgmi import OneShotExchange
-                xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
-                ok = xchg.ok and xchg.self_test()
-                if ok:
-                    # ... and a free-running soak on a throw-away model: 64 real steps back to back, no host synchronisation
-                    # in between (what the timed loop does), every rank's verdict combined
-                    soak_model = H.make_network("GCN", opt, F).to(dev)
-                    soak_dp = DataParallelGCN(soak_model, combine=args.combine)
-                    soak = xchg.attach(soak_dp.make_train_step())
-                    last = None
-                    for j in range(64):
-                        last = soak(res[j % NB].fresh())
-                    torch.cuda.synchronize()
-                    good = int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item())
-                    verdict = torch.tensor([1 if good else 0], device=dev, dtype=torch.int32)
-                    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-                    ok = bool(int(verdict.item()))
-                    xchg.err.zero_()
-                    xchg.reset()                    # the soak's step stamps must not meet the real optimiser's
-                    del soak, soak_dp, soak_model
-                if ok:
-                    for tr in trainers:
-                        xchg.attach(tr)
-                    exchange_mode = "oneshot"
-                elif args.exchange == "oneshot":
-                    raise SystemExit("bench.py: --exchange oneshot, but the one-shot exchange failed its set-up / self test")
-                log(f"one-shot exchange: {'in use' if exchange_mode == 'oneshot' else 'not usable here, RCCL all-reduce stays'}")
-            if exchange_mode == "rccl" and probe_captured and not rehearsal and args.exchange == "auto":
-                # the RCCL form with the collective and the update recorded INTO the step's graph (passed in the child process
-                # group on every rank): the data-parallel step is one graph, and whole rotations one graph launch
-                for tr in trainers + [fwdbwd]:
-                    tr.capture_exchange = True
-                exchange_mode = "rccl-captured"
-                log("RCCL all-reduce recorded into the step's hipGraph (its probe in a child process group passed on every rank)")
-        for j in range(max(3, NB)):
-            eager_step(j % NB)
-        torch.cuda.synchronize()
-        log(f"{'gloo (rehearsal)' if rehearsal else 'RCCL'} process group up: world {rccl_world}, exchange {exchange_mode}")
+        log(f"{'gloo (rehearsal)' if rehearsal else 'RCCL'} process group up: world {rccl_world}")
 
-    launch_mode, graph_err = "eager", None
-    if not args.no_graph:
-        try:
-            capture_all()     # (RCCL form: the graph ends before the collective; one-shot form: the whole step is one graph)
-            launch_mode = "hipgraph"
-            log("step captured into hipGraphs")
-        except Exception as exc:  # report, never hide: the eager number stands
-            replay.clear()
-            graph_err = f"{type(exc).__name__}: {exc}"
-            log(f"graph capture failed, keeping eager launches: {graph_err}")
+    gc_frozen = [False]
 
-    # ---- a window: the NB steps of one rotation as ONE hipGraph (train.StepWindow) -- saves the bubble between two graph
-    #      launches.  Only where a whole step is one graph (one GPU, or the one-shot exchange inside the update launch) and every
-    #      step derives the next batch's plan itself (--plan-overlap fused).
-    window, window_err, tail_window, tail_n = None, None, None, 0
-    if ("full" in replay and fused_ok and not args.forward_only and args.plan_overlap == "fused" and not args.no_window
-            and exchange_mode in ("none", "oneshot", "rccl-captured") and NB > 1):
-        try:
-            from hcatgnet_amd.train import StepWindow
-            window = StepWindow(trainers, [r.planned for r in res])
-            # the timed K steps = ONE shorter window for K mod NB steps (the LAST batches of a rotation, issued first: a short graph
-            # reaches the GPU sooner after the bracket's synchronize, and the launch of the long one behind it is hidden) + whole rotations
-            tail_n = args.steps % NB
-            if tail_n >= 2:
-                tail_window = StepWindow(trainers[NB - tail_n:], [r.planned for r in res[NB - tail_n:]])
-            log(f"window captured: {NB} steps per graph launch" + (f" (+ one of {tail_n} for the remainder of {args.steps})" if tail_window else ""))
-        except Exception as exc:          # report, never hide: the per-step graphs stand
-            window, tail_window, window_err = None, None, f"{type(exc).__name__}: {exc}"
-            log(f"window capture failed, one graph per step stays: {window_err}")
+    def freeze_gc():
+        # set-up is over: collect once and move everything alive now (torch, the model, the trainers, the captured graphs) out
+        # of the collector's sight, so that a later collection -- the sustained run keeps the collector on -- walks little
+        if not gc_frozen[0]:
+            t_gc = time.perf_counter()
+            gc.collect()
+            gc.freeze()
+            gc_frozen[0] = True
+            log(f"gc.collect + gc.freeze after set-up: {(time.perf_counter() - t_gc) * 1e3:.0f} ms")
 
-    def window_runner(start, k):
-        """Exactly k consecutive steps of the rotation from index `start`: whole rotations as one window launch, the rest as
-        single-step graphs (the same captured launches either way)."""
-        j = 0
-        while j < k:
-            i = (start + j) % NB
-            if i == 0 and k - j >= NB:
-                window.replay()
-                j += NB
-            elif i == NB - tail_n and tail_window is not None and k - j >= tail_n:
-                tail_window.replay()
-                j += tail_n
-            else:
-                replay["full"][i]()
-                j += 1
+    def measure_form(sustain_s):
+        """Capture (graphs, windows) for the trainers as they are configured now, pick the fastest launch form, run the
+        rotation for `sustain_s` and time EXACTLY K steps right behind it.  -> dict (ms_per_step, ...)."""
+        if not args.no_graph:
+            if rot.capture() and not args.no_window:
+                rot.build_windows(args.steps)
+        freeze_gc()
+        form, per_form = rot.pick(timed, args.steps)
+        runner = lambda s, n: rot.run(form, s, n)
+        sus_steps, sus_s, nxt = sustain(sustain_s, runner) if sustain_s > 0 else (0, 0.0, 0)
+        tail_n = getattr(rot, "tail_n", 0)
+        if form == "window" and tail_n and nxt != NB - tail_n:
+            # (untimed) walk the rotation on to where the remainder window starts: the K timed steps are then that window + whole rotations
+            runner(nxt, (NB - tail_n - nxt) % NB)
+            nxt = NB - tail_n
+        dt = timed(args.steps, runner, start=nxt)
+        return {"launch": form, "ms_per_step": dt / args.steps * 1e3, "launch_forms_ms": per_form, "seconds": dt,
+                "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3},
+                "steps_per_graph_launch": NB if form == "window" else (1 if form == "graph" else None),
+                "errors": dict(rot.errors)}
 
-    # set-up is over: collect once and move everything alive now (torch, the model, 17 trainers, the captured graphs) out of
-    # the collector's sight, so that a later collection -- the sustained run keeps the collector on -- walks little
-    t_gc = time.perf_counter()
-    gc.collect()
-    gc.freeze()
-    log(f"gc.collect + gc.freeze after set-up: {(time.perf_counter() - t_gc) * 1e3:.0f} ms")
-
-    # kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop
+    # ---- kernel-level roofline: HIP events around the dominant entry point, inside a timed eager loop (before any graph)
     mid = r0.sb.max_nodes > 32
     # 128-wide layers over large graphs run through csrc/tall.hip (one entry point = up to three launches)
     from hcatgnet_amd import functional as _HF
     tall = mid and bool(lib.hcg_tall_supported(D, D, r0.sb.max_nodes, r0.sb.max_edges)) and (D != 64 or N >= _HF.TALL_MIN_NODES_D64)
     fam = "hcg_tall" if tall else "hcg_mid"
-    entry = args.roofline_entry or ((f"{fam}_layer_fwd" if mid else "hcg_fused_stack2_fwd") if args.forward_only
+    entry = args.roofline_entry or ((f"{fam}_layer_fwd" if mid else "hcg_fused_forward") if args.forward_only
                                     else (f"{fam}_layer_bwd" if mid else "hcg_fused_layer_bwd"))
+    if world > 1 and fused_ok:
+        launch.set_exchange_form(trainers + [fwdbwd], dp, "rccl")
+        for j in range(max(3, NB)):
+            rot.eager(j % NB)
+        torch.cuda.synchronize()
+    eager_runner = lambda s, n: rot.run("eager", s, n)
     timer = EntryTimer(lib, entry)
     timer.install()
     timer.enabled = True
-    dt = timed(args.steps, eager_step)
+    dt = timed(args.steps, eager_runner)
     timer.enabled = False
     k_ms, k_calls = timer.mean_ms()
     timer.uninstall()
     log(f"timed (with kernel events): {dt / args.steps * 1e3:.3f} ms/step")
-    dt_eager = timed(args.steps, eager_step)
+    dt_eager = timed(args.steps, eager_runner)
     log(f"timed eager (full step, rotating batches): {dt_eager / args.steps * 1e3:.3f} ms/step")
     # distribution of single steps (SURVEY 8d: median, p10 / p90): HIP events around every step of one more pass
     evs = []
     for j in range(args.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        eager_step(j % NB)
+        rot.eager(j % NB)
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
     per_step = sorted(a.elapsed_time(b) for a, b in evs)
     pct = {f"p{q}": per_step[min(len(per_step) - 1, int(len(per_step) * q / 100))] for q in (10, 50, 90)}
 
-    # ---- burst figure (round 1's headline): ONE batch replayed in place from an idle chip
-    dt_fb, dt_graph_burst = None, None
-    if "full" in replay:
-        for _ in range(max(3, args.warmup // 2)):
-            replay["full"][0]()
-        dt_graph_burst = timed(args.steps, lambda i: replay["full"][0]())
-        log(f"burst, hipGraph replay of ONE batch in place: {dt_graph_burst / args.steps * 1e3:.3f} ms/step")
-        if not args.forward_only:
-            for _ in range(3):
-                replay["fwdbwd"]()
-            dt_fb = timed(args.steps, lambda i: replay["fwdbwd"]())
-            log(f"burst, hipGraph replay (fwd+bwd only, no update): {dt_fb / args.steps * 1e3:.3f} ms/step")
-    elif not args.forward_only:
-        dt_fb = timed(args.steps, lambda i: eager_step(0, False))
-    dt_eager_burst = timed(args.steps, lambda i: eager_step(0))
+    # ---- the headline.  One GPU: one form.  N > 1: EVERY exchange form that is usable here is measured, the plain RCCL form
+    #      FIRST (so that whatever happens to a later form, a healthy number is banked), and `value` is the best healthy one
+    exchange_forms, fallback_reason, probe_note = {}, None, None
+    if world == 1 or not fused_ok:
+        best = measure_form(args.sustain)
+        exchange_mode = "none" if world == 1 else "rccl"
+    else:
+        verdicts = {"oneshot": False, "captured": False}
+        if probe is not None:       # every rank's child verdicts, combined: one failure anywhere = that form nowhere
+            verdicts = {k: launch.all_ranks_agree(bool(probe.get(k)), dev) for k in verdicts}
+            probe_note = probe.get("note")
+        candidates = ["rccl"]
+        if args.exchange == "auto" and not rehearsal:
+            candidates += [f for f, k in (("rccl-captured", "captured"), ("oneshot", "oneshot")) if verdicts[k]]
+        elif args.exchange == "oneshot":
+            candidates += ["oneshot"]
+        short = min(args.sustain, 1.5)
+        for form in candidates:
+            t_form = time.perf_counter()
+            try:
+                if form == "oneshot":
+                    from hcatgnet_amd.xgmi import OneShotExchange
+                    xchg = OneShotExchange(sum(p.numel() for p in model.parameters()))
+                    ok = launch.all_ranks_agree(bool(xchg.ok and xchg.self_test()), dev)
+                    if ok:      # a free-running soak on a throw-away model: 64 real steps back to back, no host synchronisation
+                        soak_model = H.make_network("GCN", opt, F).to(dev)
+                        soak_dp = DataParallelGCN(soak_model, combine=args.combine)
+                        soak = xchg.attach(soak_dp.make_train_step())
+                        last = None
+                        for j in range(64):
+                            last = soak(res[j % NB].fresh())
+                        torch.cuda.synchronize()
+                        ok = launch.all_ranks_agree(int(xchg.err[0].item()) == 0 and bool(torch.isfinite(last).item()), dev)
+                        xchg.err.zero_()
+                        xchg.reset()                    # the soak's step stamps must not meet the real optimiser's
+                        del soak, soak_dp, soak_model
+                    if not ok:
+                        exchange_forms[form] = {"healthy": False, "reason": "set-up / self test / soak failed on this machine"}
+                        continue
+                launch.set_exchange_form(trainers, dp, form, xchg)
+                for j in range(max(3, NB)):
+                    rot.eager(j % NB)
+                torch.cuda.synchronize()
+                m = measure_form(short)
+                healthy = rot.losses_finite() and (form != "oneshot" or int(xchg.err[0].item()) == 0)
+                m["healthy"] = launch.all_ranks_agree(healthy, dev)
+                if not m["healthy"]:
+                    m["reason"] = "non-finite loss or an exchange time-out after the timed loop"
+                    if xchg is not None:
+                        xchg.err.zero_()
+            except Exception as exc:      # noqa: BLE001  (a form that raises is a form that is not used; the banked one stands)
+                m = {"healthy": False, "reason": f"{type(exc).__name__}: {exc}"}
+                launch.all_ranks_agree(False, dev)
+            m["seconds_spent"] = time.perf_counter() - t_form
+            exchange_forms[form] = m
+            log(f"exchange form {form}: {m.get('ms_per_step')} ms/step, healthy {m['healthy']}" + (f" ({m.get('reason')})" if not m["healthy"] else ""))
+        good = {f: m for f, m in exchange_forms.items() if m.get("healthy") and m.get("ms_per_step")}
+        if not good:
+            # nothing healthy, not even the plain collective: report what happened, no value
+            gate = dict(gate or {}, exchange_forms=exchange_forms)
+            dist.barrier()
+            dist.destroy_process_group()
+            refuse_timing("no data-parallel exchange form ran healthy")
+        exchange_mode = min(good, key=lambda f: good[f]["ms_per_step"])
+        unhealthy = [f for f, m in exchange_forms.items() if not m.get("healthy")]
+        if unhealthy:
+            fallback_reason = "; ".join(f"{f}: {exchange_forms[f].get('reason')}" for f in unhealthy)
+        # the official figure: the chosen form again, full sustained run + EXACTLY K steps
+        launch.set_exchange_form(trainers, dp, exchange_mode, xchg)
+        for j in range(max(3, NB)):
+            rot.eager(j % NB)
+        torch.cuda.synchronize()
+        best = measure_form(args.sustain)
+        healthy = rot.losses_finite() and (exchange_mode != "oneshot" or int(xchg.err[0].item()) == 0)
+        if not launch.all_ranks_agree(healthy, dev):
+            # the chosen form went bad in the long run: the banked short measurement of the plain collective stands
+            fallback_reason = (fallback_reason + "; " if fallback_reason else "") + f"{exchange_mode}: unhealthy in the sustained run"
+            exchange_mode, best = "rccl", dict(good["rccl"]) if "rccl" in good else best
+    launch_mode, ms_step = best["launch"], best["ms_per_step"]
+    log(f"headline: {ms_step:.4f} ms/step ({launch_mode}; sustained {best['sustained']['ms_per_step']:.4f} over {best['sustained']['seconds']:.2f} s)")
 
-    # ---- the headline: sustained rotation over distinct batches, then EXACTLY K steps right behind it
-    use_graph = "full" in replay
-    if use_graph:      # the no-autograd step issues 6 launches from a host loop that can run ahead of the GPU: take the faster
-        tg = timed(max(args.steps, 4 * NB), lambda i: replay["full"][i]())
-        te = timed(max(args.steps, 4 * NB), eager_step)
-        use_graph = tg <= te
-        log(f"rotation probe: hipGraph {tg / max(args.steps, 4 * NB) * 1e3:.4f} vs eager {te / max(args.steps, 4 * NB) * 1e3:.4f} ms/step")
-    launch_mode = "hipgraph" if use_graph else "eager"
-    step_fn = (lambda i: replay["full"][i]()) if use_graph else eager_step
-    runner, steps_per_graph, per_step_graph_ms = None, (1 if use_graph else None), None
-    if window is not None:        # (also when the eager launches edged out the per-step graphs above)
-        kp = max(args.steps, 4 * NB) // NB * NB
-        timed(kp, None, runner=window_runner)
-        tw, tg1, te1 = (timed(kp, None, runner=window_runner), timed(kp, lambda i: replay["full"][i]()),
-                        timed(kp, eager_step))
-        log(f"rotation probe: {NB} steps per graph launch {tw / kp * 1e3:.4f} vs one graph per step {tg1 / kp * 1e3:.4f} "
-            f"vs eager {te1 / kp * 1e3:.4f} ms/step")
-        per_step_graph_ms = tg1 / kp * 1e3
-        if tw <= min(tg1, te1):
-            use_graph, launch_mode = True, "hipgraph"
-            step_fn = lambda i: replay["full"][i]()
-            runner, steps_per_graph = window_runner, NB
-    sus_steps, sus_s, nxt = sustain(args.sustain, step_fn, runner) if args.sustain > 0 else (0, 0.0, 0)
-    if runner is not None and tail_window is not None and nxt != NB - tail_n:
-        # (untimed) walk the rotation on to where the remainder window starts: the K timed steps are then that window + whole rotations
-        runner(nxt, (NB - tail_n - nxt) % NB)
-        nxt = NB - tail_n
-    dt_best = timed(args.steps, step_fn, start=nxt, runner=runner)
-    log(f"sustained {sus_s:.2f} s / {sus_steps} steps = {sus_s / max(sus_steps, 1) * 1e3:.4f} ms/step; "
-        f"timed {args.steps} steps right behind: {dt_best / args.steps * 1e3:.4f} ms/step ({launch_mode}"
-        f"{', ' + str(steps_per_graph) + ' steps per graph launch' if steps_per_graph and steps_per_graph > 1 else ''})")
-    for tr in trainers:
-        tr.check_health()
-    if xchg is not None and exchange_mode == "oneshot":
-        xchg.check()
+    # ---- secondary: burst figures (round 1's headline: ONE batch replayed in place from an idle chip), gradients-only step
+    dt_fb = dt_graph_burst = None
+    one = lambda fn: (lambda s, n: [fn() for _ in range(n)])
+    if fused_ok and world == 1:
+        try:
+            if rot.graphs:
+                for _ in range(3):
+                    trainers[0].replay()
+                dt_graph_burst = timed(args.steps, one(trainers[0].replay))
+            fwdbwd.capture(r0.fresh)
+            for _ in range(3):
+                fwdbwd.replay()
+            dt_fb = timed(args.steps, one(fwdbwd.replay))
+        except Exception as exc:      # noqa: BLE001
+            log(f"burst figures skipped: {type(exc).__name__}: {exc}")
+    dt_eager_burst = timed(args.steps, lambda s, n: [rot.eager(0) for _ in range(n)])
 
     bd = algbytes.breakdown(N, E, B, F, D, opt.n_convolutions)
     step_bytes = sum(v for k, v in bd.items() if not args.forward_only or k.endswith("_fwd") or k == "csr_build")
@@ -847,8 +860,9 @@ def main():
                    "hcg_mid_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
                    "hcg_tall_layer_bwd": (bd["conv1_bwd"] + bd["conv2_bwd"] + bd["pool_bwd"]) / 2.0,
                    "hcg_tall_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
-                   "hcg_fused_layer_fwd": (bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]) / 2.0,
-                   "hcg_fused_stack2_fwd": bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"]}.get(entry, float("nan"))
+                   # (training step: the launch also carries the readout head, forward and backward)
+                   "hcg_fused_forward": bd["conv1_fwd"] + bd["conv2_fwd"] + bd["pool_fwd"] +
+                                        (0 if args.forward_only else bd["readout_fwd"] + bd["readout_bwd"])}.get(entry, float("nan"))
     achieved = entry_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950
     # correction of MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only valid for the config they were taken on
@@ -862,7 +876,7 @@ def main():
             elif cfg_name in ("C5", "REAL"):
                 tj = {}
             prefix = {"hcg_fused_layer_bwd": "k_fused_layer_bwd", "hcg_mid_layer_bwd": "k_mid_layer_bwd",
-                      "hcg_fused_stack2_fwd": "k_fused_layer_fwd", "hcg_mid_layer_fwd": "k_mid_layer_fwd"}.get(entry)
+                      "hcg_fused_forward": "k_fused_layer_fwd", "hcg_mid_layer_fwd": "k_mid_layer_fwd"}.get(entry)
             vals = [v["hbm_bytes"] for k, v in tj.items() if prefix and k.startswith(prefix)]
             traffic = sum(vals) / len(vals) if vals else None
             if traffic is not None and entry.startswith("hcg_mid_") and D > 64:
@@ -888,76 +902,63 @@ def main():
             rtr = [FusedTrainStep(model, optimizer_step=True) for _ in rr]
             for r in rr:
                 r.make_plan()
-            for i, (tr, r) in enumerate(zip(rtr, rr)):
-                for _ in range(2):
-                    tr(r.fresh())
-                # the headline's pipeline: the step's last launch also derives the NEXT batch's plan (--plan-overlap fused)
-                if args.plan_overlap == "fused":
-                    tr.capture(r.planned, next_plan=rr[(i + 1) % NB].plan)
-                else:
-                    tr.capture(r.fresh)
-            rfn = lambda i: rtr[i].replay()
-            rrun = None
-            if runner is not None and args.plan_overlap == "fused":         # the headline's launch form
-                from hcatgnet_amd.train import StepWindow
-                rwin = StepWindow(rtr, [r.planned for r in rr])
-
-                def rrun(start, k):
-                    j = 0
-                    while j < k:
-                        i = (start + j) % NB
-                        if i == 0 and k - j >= NB:
-                            rwin.replay()
-                            j += NB
-                        else:
-                            rtr[i].replay()
-                            j += 1
-            timed(4 * NB, rfn, runner=rrun)
-            rdt = timed(max(args.steps, 200), rfn, runner=rrun)
+            rrot = launch.Rotation(rtr, [r.fresh for r in rr], [r.planned for r in rr], [r.plan for r in rr],
+                                   plan_overlap=args.plan_overlap)
+            for j in range(2 * NB):
+                rrot.eager(j % NB)
+            if rrot.capture() and best["launch"] == "window":
+                rrot.build_windows(0)
+            rform = "window" if rrot.window is not None else ("graph" if rrot.graphs else "eager")
+            rrun = lambda s, n: rrot.run(rform, s, n)
+            timed(4 * NB, rrun)
             k = max(args.steps, 200)
+            rdt = timed(k, rrun)
             gpt = lib.hcg_fused_graphs_per_tile(F, D, rr[0].sb.max_nodes)
             ragged = {"value": rr[0].B * k / rdt, "unit": "graphs/s", "ms_per_step": rdt / k * 1e3, "steps": k,
                       "graphs": rr[0].B, "nodes": rr[0].N, "edges": rr[0].E, "max_nodes": rr[0].sb.max_nodes,
                       "kernel_family": "small-graph tiles" if gpt > 0 else ("size-grouped batch: tiles for graphs <= 32 nodes + one graph per wave"
                                                                            if rr[0].sb.n_small else "one graph per wave / workgroup"),
-                      "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, hipGraph replay"
-                              f"{' (' + str(NB) + ' steps per graph launch)' if rrun is not None else ''}"}
+                      "note": f"n_g ~ U{{24..36}}, {NB} distinct batches round-robin, launch form {rform}"}
             log(f"ragged variant: {rdt / k * 1e3:.4f} ms/step")
-            del rr, rtr
+            del rr, rtr, rrot
         except Exception as exc:
             ragged = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
-        ms_step = dt_best / args.steps * 1e3
         touched = NB * (r0.bytes_touched() + (sum(t.nbytes for t in trainers[0]._bufs["cap"]["acts"] + trainers[0]._bufs["cap"]["dacts"])
                                               if fused_ok else 0))
+        xdesc = {"none": "", "rccl": "RCCL all-reduce (", "rccl-captured": "RCCL all-reduce recorded in the step graph (",
+                 "oneshot": "one-shot xGMI exchange inside the last launch ("}[exchange_mode]
         fwd_only_note = "plan/gcn_norm build + forward (conv stack, pool, readout) only" if args.forward_only else \
             (f"full training step: per-step plan/gcn_norm build, forward, sqrt(MSE) loss, backward, "
-             f"{('one-shot xGMI exchange inside the update launch (' if exchange_mode == 'oneshot' else ('RCCL all-reduce recorded in the step graph (' if exchange_mode == 'rccl-captured' else 'RCCL all-reduce (')) + args.combine + '), ' if world > 1 else ''}Adam update")
+             f"{xdesc + args.combine + '), ' if world > 1 else ''}Adam update")
+        spg = best.get("steps_per_graph_launch")
         rec = {
             "metric": "molecular graphs/sec fwd+bwd at 1/2/4/8 MI355X; achieved HBM GB/s" if not args.forward_only
                       else "molecular graphs/sec FORWARD ONLY (configs[1]; not the headline metric)",
-            "value": world * B * args.steps / dt_best, "unit": "graphs/s",
+            "value": world * B * args.steps / best["seconds"], "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'C2' if args.forward_only and cfg_name == 'C3' else args.config}: {B} synthetic graphs/GPU x "
                                    f"{N / B:.0f} atoms x {E / B:.0f} directed edges x "
                                    f"{F}-d features, {opt.n_convolutions}xGCNConv({D}) + [max,mean] pool + readout; "
                                    f"{fwd_only_note}; {NB} distinct batches round-robin; launch={launch_mode}"
-                                   f"{' (' + str(steps_per_graph) + ' consecutive steps per graph launch)' if steps_per_graph and steps_per_graph > 1 else ''}"
-                                   f"{'' if (launch_mode != 'hipgraph' or args.plan_overlap == 'none' or not fused_ok) else ', plan build of the NEXT batch ' + ('inside the last launch of the step' if args.plan_overlap == 'fused' else 'on a forked graph branch')}",
+                                   f"{' (' + str(spg) + ' consecutive steps per graph launch)' if spg and spg > 1 else ''}"
+                                   f"{'' if (launch_mode == 'eager' or args.plan_overlap == 'none' or not fused_ok) else ', plan build of the NEXT batch ' + ('inside the last launch of the step' if args.plan_overlap == 'fused' else 'on a forked graph branch')}",
                        "graphs_per_gpu": B, "nodes": N, "edges": E, "feat": F, "hidden": D,
                        "parallelism": f"dp{world} (batch-of-graphs, {'one-shot xGMI exchange' if exchange_mode == 'oneshot' else 'RCCL all-reduce'} "
                                       f"of {sum(p.numel() for p in model.parameters())} fp32 grads)"},
             "parity_gate": gate,
             "rccl_world": rccl_world, "exchange": exchange_mode,
-            # the child-process trials: of the one-shot exchange, and of the RCCL collective recorded into the step's graph
-            "exchange_probe": (None if probe_ok is None else ("passed" if probe_ok else "failed")),
-            "captured_collective_probe": (None if probe_ok is None or world == 1 else ("passed" if probe_captured else "failed")),
+            # N > 1: every exchange form measured on this machine (the plain collective first), and why a form was not used
+            "exchange_forms": exchange_forms or None, "exchange_fallback_reason": fallback_reason,
+            # the child-process trials of the two graph forms (budget: PROBE_BUDGET_S seconds)
+            "exchange_probe": None if probe is None else {k: probe.get(k) for k in ("oneshot", "captured", "exit", "seconds", "note")},
             "distinct_batches": NB, "bytes_touched_between_reuse": touched,
-            "sustained_s": sus_s, "sustained": {"steps": sus_steps, "seconds": sus_s, "ms_per_step": sus_s / max(sus_steps, 1) * 1e3,
-                                                "value": world * B * sus_steps / sus_s if sus_s > 0 else None,
-                                                "note": "the same rotation, run right before the timed steps (one synchronize per 256 steps)"},
+            "sustained_s": best["sustained"]["seconds"],
+            "sustained": dict(best["sustained"], value=(world * B * best["sustained"]["steps"] / best["sustained"]["seconds"]
+                                                        if best["sustained"]["seconds"] > 0 else None),
+                              note="the same rotation, run right before the timed steps (one synchronize per 256 steps)"),
             "burst": {"note": "ONE batch replayed in place from an idle chip (cache resident): round 1's headline figure",
                       "hipgraph_ms_per_step": dt_graph_burst / args.steps * 1e3 if dt_graph_burst else None,
                       "eager_ms_per_step": dt_eager_burst / args.steps * 1e3,
@@ -978,9 +979,8 @@ def main():
             "library_launching_calls_per_step": {"total": sum(launch_counts.values()), "by_entry_point": launch_counts},
             "ms_per_step_with_kernel_events": dt / args.steps * 1e3,
             "eager_step_ms_percentiles_hip_events": pct,
-            "launch": launch_mode, "steps_per_graph_launch": steps_per_graph, "one_graph_per_step_ms": per_step_graph_ms,
-            "window_error": window_err, "eager_ms_per_step": dt_eager / args.steps * 1e3,
-            "graph_capture_error": graph_err,
+            "launch": launch_mode, "steps_per_graph_launch": spg, "launch_forms_ms": best.get("launch_forms_ms"),
+            "launch_errors": best.get("errors") or None, "eager_ms_per_step": dt_eager / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg_name, args.num_graphs, args.cpu_steps)

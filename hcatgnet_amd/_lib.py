@@ -15,8 +15,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhcatgnet_hip.so")
 
 HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0, 1, 2, 4
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
-HCG_HEAD_MSE, HCG_HEAD_RMSE, HCG_HEAD_SSE = 0, 1, 2      # `rmse` argument of hcg_head_fwd_bwd_ex
-HCG_HEAD_SYNC_WORDS, HCG_HEAD_ERR_TIMEOUT = 520, 1
+HCG_LOSS_MSE, HCG_LOSS_RMSE, HCG_LOSS_SSE = 0, 1, 2      # loss modes of hcg_step_tail / hcg_loss_finalize / hcg_loss_fwd_bwd
+HCG_HEAD_FORWARD_ONLY = 1
+HCG_REDUCE_MAX_JOBS, HCG_REDUCE_MAX_SEGS = 8, 4
 HCG_XCHG_MEAN, HCG_XCHG_SSE, HCG_XCHG_ERR_TIMEOUT, HCG_XCHG_MAX_WORLD = 0, 1, 1, 8
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
                4: "batch id outside [0, num_graphs)", 8: "edges not grouped by graph / edge crosses graphs",
@@ -25,6 +26,36 @@ STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted
 STATUS_EDGE_UNGROUPED = 8
 
 P, I64, SZ, F32, INT = c_void_p, c_int64, c_size_t, c_float, c_int
+I32 = ctypes.c_int32
+
+
+# ---- host structs of the C ABI (include/hcatgnet_hip.h); tests/test_host_cpu.py checks their sizes against the library
+class ReduceSeg(ctypes.Structure):
+    _fields_ = [("begin", I32), ("count", I32), ("row_in", I32), ("row_out", I32), ("dst", P)]
+
+
+class ReduceJob(ctypes.Structure):
+    _fields_ = [("slabs", P), ("nslabs", I32), ("slab_floats", I32), ("nseg", I32), ("sse_index", I32),
+                ("seg", ReduceSeg * HCG_REDUCE_MAX_SEGS)]
+
+
+class TailArgs(ctypes.Structure):
+    """hcg_tail_args: the step's last launch (slab reductions, loss + deferred scale, exchange, Adam, next plan)."""
+    _fields_ = [("jobs_host", P), ("njobs", I32), ("loss_mode", I32), ("loss_count", F32), ("beta1", F32), ("beta2", F32),
+                ("eps", F32), ("loss", P), ("sse_tail", P), ("grad_flat", P), ("param", P), ("exp_avg", P), ("exp_avg_sq", P),
+                ("n", I64), ("lr_dev", P), ("step_dev", P), ("next_edge_index", P), ("next_batch", P), ("next_N", I64),
+                ("next_E", I64), ("next_B", I64), ("next_graph_ptr", P), ("next_edge_ptr", P), ("next_status", P), ("inbox", P),
+                ("peers_host", P), ("rank", I32), ("world", I32), ("xchg_mode", I32), ("reserved", I32), ("xchg_err", P)]
+
+
+class FusedFwdArgs(ctypes.Structure):
+    """hcg_fused_fwd_args: every forward form of the small-graph tiles."""
+    _fields_ = [("x", P), ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("edge_index", P), ("E", I64), ("graph_ptr", P),
+                ("edge_ptr", P), ("N", I64), ("B", I64), ("F", I64), ("D", I64), ("graphs_per_tile", I32), ("apply_act", I32),
+                ("slope", F32), ("head_flags", I32), ("out1", P), ("out2", P), ("emb", P), ("poolbits", P), ("status", P),
+                ("y", P), ("head_W0", P), ("head_b0", P), ("head_W1", P), ("head_b1", P), ("C", I64), ("z", P), ("out", P),
+                ("demb", P), ("head_workspace", P), ("head_workspace_bytes", SZ), ("step_counter", P)]
+
 
 # name -> (restype, argtypes); must list every symbol of include/hcatgnet_hip.h
 SIGNATURES = {
@@ -43,13 +74,12 @@ SIGNATURES = {
     "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
     "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
-    "hcg_fused_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
     "hcg_fused_poolbits_bytes": (SZ, [I64, INT]),
-    "hcg_fused_layer_fwd_train": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P]),
-    "hcg_fused_stack2_fwd_train": (INT, [P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P, P]),
-    "hcg_fused_layer_bwd_poolbits": (INT, [P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
-    "hcg_fused_stack2_fwd": (INT, [P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, P, P]),
-    "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
+    "hcg_fused_fwd_args_bytes": (SZ, []),
+    "hcg_fused_forward": (INT, [P, P]),
+    "hcg_fused_head_workspace_bytes": (SZ, [I64, INT]),
+    "hcg_fused_head_reduce_job": (INT, [P, SZ, I64, INT, I64, P, P, P, P, P]),
+    "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
     "hcg_mid_supported": (INT, [I64, I64, I64, I64]),
     "hcg_mid_workspace_bytes": (SZ, [I64, I64, I64, I64, I64]),
     "hcg_mid_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, P]),
@@ -65,7 +95,9 @@ SIGNATURES = {
     "hcg_readout2_bwd_partial": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, SZ, P]),
     "hcg_readout2_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
     "hcg_reduce_job_append": (INT, [P, P]),
-    "hcg_reduce_slabs": (INT, [P, INT, P]),
+    "hcg_tail_args_bytes": (SZ, []),
+    "hcg_step_tail": (INT, [P, P]),
+    "hcg_loss_finalize": (INT, [P, F32, INT, P, P, P]),
     "hcg_collate": (INT, [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P]),
     "hcg_adam_step": (INT, [P, P, P, P, I64, F32, F32, F32, F32, I64, P]),
     "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
@@ -76,27 +108,20 @@ SIGNATURES = {
     "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),
     "hcg_readout2_bwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P, SZ, P]),
     "hcg_head_supported": (INT, [I64, I64]),
-    "hcg_head_workspace_bytes": (SZ, [I64]),
-    "hcg_head_workspace_bytes_d": (SZ, [I64, I64]),
-    "hcg_head_fwd_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P]),
-    "hcg_head_fwd_bwd_ex": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, SZ, P, P, P, P]),
-    "hcg_head_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
-    "hcg_head_reduce_job_d": (INT, [P, SZ, I64, I64, I64, P, P, P, P, P]),
+    "hcg_head_workspace_bytes": (SZ, [I64, I64]),
+    "hcg_head_fwd_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, SZ, P, P]),
+    "hcg_head_reduce_job": (INT, [P, SZ, I64, I64, I64, P, P, P, P, P]),
     "hcg_sse_finalize": (INT, [P, I64, P, P]),
     "hcg_adam_step_dev_sse": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P, P]),
-    "hcg_reduce_slabs_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P]),
     "hcg_adam_step_dev": (INT, [P, P, P, P, I64, P, F32, F32, F32, P, P]),
-    "hcg_reduce_slabs_adam_plan": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P, P, I64, I64, I64, P, P, P, P]),
-    "hcg_fused_reduce_grads": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
     "hcg_xchg_inbox_bytes": (SZ, [I64, INT]),
+    "hcg_xchg_resident_blocks": (INT, []),
     "hcg_xchg_alloc": (INT, [SZ, P]),
     "hcg_xchg_free": (INT, [P]),
     "hcg_xchg_zero": (INT, [P, SZ]),
     "hcg_xchg_ipc_export": (INT, [P, P]),
     "hcg_xchg_ipc_open": (INT, [P, P]),
     "hcg_xchg_ipc_close": (INT, [P]),
-    "hcg_reduce_slabs_xchg_adam": (INT, [P, INT, P, P, P, P, I64, P, F32, F32, F32, P, P, P, INT, INT, INT, P, P,
-                                         P, P, I64, I64, I64, P, P, P, P]),
 }
 
 _lib = None
@@ -180,3 +205,42 @@ def require_gpu(*tensors):
 
 def describe_status(word: int) -> str:
     return "; ".join(msg for bit, msg in STATUS_BITS.items() if word & bit) or "ok"
+
+
+# ---- struct-argument entry points ------------------------------------------------------------------------------------
+def fused_forward(**kw):
+    """hcg_fused_forward: keyword = field of hcg_fused_fwd_args (tensors or None for pointers, numbers otherwise)."""
+    a = FusedFwdArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    check(load().hcg_fused_forward(ctypes.addressof(a), stream_ptr()), "hcg_fused_forward")
+
+
+def step_tail(jobs_addr: int, njobs: int, *, loss=None, loss_mode: int = HCG_LOSS_RMSE, loss_count: float = 0.0, sse_tail=None,
+              adam=None, next_plan=None, xchg=None):
+    """hcg_step_tail.  `jobs_addr`: host address of `njobs` hcg_reduce_job; `loss` [2] / `sse_tail` [2] device tensors;
+    `adam`: dict(grad_flat, param, exp_avg, exp_avg_sq (tensors), n, lr_dev, step_dev (tensors), beta1, beta2, eps);
+    `next_plan`: a pointers-only blocked BatchPlan; `xchg`: dict(inbox (address), peers_host (address of the host pointer
+    array), rank, world, mode, err (tensor))."""
+    a = TailArgs()
+    a.jobs_host, a.njobs, a.loss_mode, a.loss_count = jobs_addr, njobs, loss_mode, float(loss_count)
+    a.loss, a.sse_tail = ptr(loss), ptr(sse_tail)
+    if adam is not None:
+        a.grad_flat, a.param, a.exp_avg, a.exp_avg_sq = (adam["grad_flat"].data_ptr(), adam["param"].data_ptr(),
+                                                         adam["exp_avg"].data_ptr(), adam["exp_avg_sq"].data_ptr())
+        a.n, a.lr_dev, a.step_dev = adam["n"], adam["lr_dev"].data_ptr(), adam["step_dev"].data_ptr()
+        a.beta1, a.beta2, a.eps = adam["beta1"], adam["beta2"], adam["eps"]
+    if next_plan is not None:
+        np_ = next_plan
+        a.next_edge_index, a.next_batch = np_.edge_index.data_ptr(), np_.batch.data_ptr()
+        a.next_N, a.next_E, a.next_B = np_.N, np_.E, np_.B
+        a.next_graph_ptr, a.next_edge_ptr, a.next_status = np_.graph_ptr.data_ptr(), np_.edge_ptr.data_ptr(), np_.status.data_ptr()
+    if xchg is not None:
+        a.inbox, a.peers_host, a.rank, a.world, a.xchg_mode = xchg["inbox"], xchg["peers_host"], xchg["rank"], xchg["world"], xchg["mode"]
+        a.xchg_err = xchg["err"].data_ptr()
+    check(load().hcg_step_tail(ctypes.addressof(a), stream_ptr()), "hcg_step_tail")
+
+
+def reduce_jobs(jobs_addr: int, njobs: int):
+    """The slab reductions alone (no loss scale, no update)."""
+    step_tail(jobs_addr, njobs)

@@ -36,6 +36,7 @@
 //     kernel -> bitwise reproducible gradients.
 #include "common.h"
 #include "split_mfma.h"
+#include "head_tile.h"
 
 // Diagnostic builds only (tools/probe_fused.hip defines HCG_STAMP): s_memtime stamps of a few waves go to
 // a buffer of their own; the product build compiles STAMP() to nothing and executes no stamp.
@@ -300,16 +301,62 @@ struct Stager {
 // BITS (training, needs POOL): the pooled layer's activations do NOT go to HBM; what the pooled backward needs of
 // them leaves as two bits per element, in the accumulator layout: poolbits[tile][0][lane] bit 16 b + i <-> value at
 // (row krow(i, h), column 32 b + r) is > 0, poolbits[tile][1][lane] the same positions: value == its graph's column max.
-template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false>
+// HEAD (needs POOL): the regression head rides in the TAIL of this launch (head_tile.h).  A workgroup's tiles are
+// {8 b + w + k * 8 grid}: runs of 8 gpt consecutive graphs per round k; once its waves have left the tile loop their LDS is
+// free, the pooled rows they wrote are visible to the whole workgroup (workgroup-scope barrier), and the workgroup runs
+// readout forward, squared error and -- HEAD == 2 -- the UNSCALED readout backward over its own graphs: z, out, demb and
+// one gradient slab + SSE partial per workgroup.  Round 2 spent a launch of its own (15 us at C3: a grid-wide exchange of
+// one scalar on 128 of 256 CUs) on this; the scalar is applied by the step's last launch now (reduce.hip).
+struct FwdHead {
+  const float* y;
+  const float* W0;
+  const float* b0;
+  const float* W1;
+  const float* b1;
+  int C;
+  float* z;
+  float* out;
+  float* demb;
+  float* slabs;
+  int* step_counter;
+};
+
+template <int RC, bool BACKWARD>
+__device__ __forceinline__ void fwd_head_tail(void* lds_base, const FwdHead& H, const float* __restrict__ emb, int gpt, int B,
+                                              int num_tiles, float slope) {
+  using namespace hcg_head;
+  HeadLds<DD>& HL = *reinterpret_cast<HeadLds<DD>*>(lds_base);
+  HeadState<DD, RC> S;
+  head_begin<DD, RC>(HL, S, H.W0, H.b0, H.W1, H.b1, H.C);
+  const int R = WAVES * gpt;                               // graphs of this workgroup per round of its waves
+  const int stride = gridDim.x * WAVES;                    // tiles between two rounds
+  int rows_total = 0;
+  for (int tb = blockIdx.x * WAVES; tb < num_tiles; tb += stride) {
+    const int left = B - tb * gpt;
+    rows_total += left < R ? left : R;
+  }
+  const int base = blockIdx.x * WAVES * gpt, step_g = stride * gpt;
+  for (int j0 = 0; j0 < rows_total; j0 += RT) {
+    const int n = rows_total - j0 < RT ? rows_total - j0 : RT;
+    head_tile<DD, RC, BACKWARD>(HL, S, [=](int row) { const int j = j0 + row, k = j / R; return base + k * step_g + (j - k * R); },
+                                n, H.C, slope, emb, H.y, H.W0, H.z, H.out, H.demb);
+  }
+  head_end<DD, RC, BACKWARD>(HL, S, H.C, H.slabs + (size_t)blockIdx.x * HC<DD>::SLAB);
+}
+
+template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false, int HEAD = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ W2, const float* __restrict__ bias2,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ edge_ptr, int64_t N, int gpt, int B, int num_tiles, float slope, int apply_act,
     float* __restrict__ out, float* __restrict__ out2, float* __restrict__ emb, uint32_t* __restrict__ poolbits,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, FwdHead HA = FwdHead{}) {
   static_assert(!BITS || POOL, "the bit form belongs to the pooled layer");
+  static_assert(HEAD == 0 || POOL, "the head reads the pooled embedding");
   __shared__ WaveLdsF lds[WAVES];
+  static_assert(HEAD == 0 || sizeof(hcg_head::HeadLds<DD>) <= sizeof(WaveLdsF) * WAVES, "the head's LDS aliases the tile buffers");
+  if (HEAD != 0 && HA.step_counter && blockIdx.x == 0 && threadIdx.x == 0) HA.step_counter[0] += 1;   // this step's number
   __shared__ __attribute__((aligned(16))) short w1l[3 * DD * (KPAD + WPAD)];
   __shared__ __attribute__((aligned(16))) short w2l[STACK2 ? 3 * DD * (DD + WPAD) : 8];
   STAMP_DECL
@@ -524,6 +571,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   }
   STAMP(63);
   STAMP_FLUSH();
+  if constexpr (HEAD != 0) {
+    __syncthreads();           // every wave has left its tiles: LDS free, this workgroup's pooled rows visible to all of it
+    if (HA.C == 1) fwd_head_tail<1, HEAD == 2>(&lds[0], HA, emb, gpt, B, num_tiles, slope);
+    else fwd_head_tail<hcg_head::RCMAX, HEAD == 2>(&lds[0], HA, emb, gpt, B, num_tiles, slope);
+  }
 }
 
 // =====================================================================================================
@@ -966,34 +1018,79 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
   return (size_t)pick_grid(tiles) * (DD * kpad + DD) * sizeof(float) + 256;
 }
 
-static int launch_fused_fwd(const float* x, const float* W, const float* b, const float* W2, const float* b2,
-                            const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
-                            int64_t N, int64_t B, int64_t F, int64_t D, int graphs_per_tile, float slope, int apply_act,
-                            float* out, float* out2, float* emb, uint32_t* poolbits, int32_t* status, hipStream_t stream) {
+// workspace of the head in the forward's tail: one slab (gradient partial sums + SSE partial) per workgroup of the launch
+extern "C" size_t hcg_fused_head_workspace_bytes(int64_t B, int graphs_per_tile) {
+  if (graphs_per_tile <= 0 || B <= 0) return 0;
+  const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
+  return hcg_align_up((size_t)pick_grid(tiles) * hcg_head::HC<DD>::SLAB * sizeof(float), 256) + 256;
+}
+
+extern "C" int hcg_fused_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int graphs_per_tile, int64_t C,
+                                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
+  if (B <= 0 || graphs_per_tile < 1 || C < 1 || C > hcg_head::RCMAX || !job || !workspace) return HCG_ERR_INVALID_ARG;
+  if (dW0 && (!db0 || !dW1 || !db1)) return HCG_ERR_INVALID_ARG;
+  if (workspace_bytes < hcg_fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
+  const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
+  hcg_head::head_fill_job<DD>((const float*)workspace, pick_grid(tiles), (int)C, dW0, db0, dW1, db1, job);
+  return HCG_OK;
+}
+
+// Every forward form of the small-graph tiles: one or two stacked conv layers, optional [max, mean] pooling of the last one,
+// optional training form (the pooled layer's activations stay on chip, 2 bits per element leave), optional readout head in
+// the tail of the launch.
+extern "C" size_t hcg_fused_fwd_args_bytes(void) { return sizeof(hcg_fused_fwd_args); }
+
+extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t stream_) {
+  if (!a) return HCG_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const float *x = a->x, *W = a->W1, *b = a->b1, *W2 = a->W2, *b2 = a->b2;
+  const int64_t* edge_index = a->edge_index;
+  int64_t E = a->E;
+  const int64_t N = a->N, B = a->B, F = a->F, D = a->D;
+  const int graphs_per_tile = a->graphs_per_tile;
+  float *out = a->out1, *out2 = a->out2, *emb = a->emb;
+  uint32_t* poolbits = a->poolbits;
   const bool stack2 = W2 != nullptr;
   const bool bits = poolbits != nullptr;   // the pooled layer's activations stay on chip (training form)
+  const bool head = a->head_W0 != nullptr;
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1) return HCG_ERR_UNSUPPORTED;
-  if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;  // LeakyReLU is evaluated as max(v, slope*v)
+  if (a->apply_act && !(a->slope >= 0.f && a->slope <= 1.f)) return HCG_ERR_UNSUPPORTED;  // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
-  if (B == 0 || N == 0) return HCG_OK;
-  if (!x || !W || !b || !graph_ptr || !edge_ptr || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (B == 0 || N == 0) return head ? HCG_ERR_INVALID_ARG : HCG_OK;
+  if (!x || !W || !b || !a->graph_ptr || !a->edge_ptr || !a->status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
   if (bits && !emb) return HCG_ERR_INVALID_ARG;
-  if (!out && !(bits && !stack2)) return HCG_ERR_INVALID_ARG;
-  if (stack2 && (!b2 || (!out2 && !bits))) return HCG_ERR_INVALID_ARG;
+  if (stack2) {
+    if (!b2 || !out || (!out2 && !bits)) return HCG_ERR_INVALID_ARG;
+  } else {
+    if (out2 || (!out && !bits)) return HCG_ERR_INVALID_ARG;
+  }
+  const bool head_bwd = head && !(a->head_flags & HCG_HEAD_FORWARD_ONLY);
+  FwdHead H{};
+  if (head) {
+    // the head needs the training form of a stacked pair (the one form the training step of a two-layer model issues)
+    if (!stack2 || !bits || (a->head_flags & ~HCG_HEAD_FORWARD_ONLY)) return HCG_ERR_UNSUPPORTED;
+    if (a->C < 1 || a->C > hcg_head::RCMAX) return HCG_ERR_UNSUPPORTED;
+    if (!a->y || !a->head_b0 || !a->head_W1 || !a->head_b1 || !a->z || !a->out || (head_bwd && !a->demb) || !a->head_workspace)
+      return HCG_ERR_INVALID_ARG;
+    if (a->head_workspace_bytes < hcg_fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
+    H = FwdHead{a->y, a->head_W0, a->head_b0, a->head_W1, a->head_b1, (int)a->C, a->z, a->out, a->demb, (float*)a->head_workspace,
+                (int*)a->step_counter};
+  }
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   const int grid = pick_grid(tiles);
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
-  if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no tile has edges
-#define LAUNCH_FWD(KP, VC, PL, ST, BT)                                                                                \
-  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST, BT>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, \
-                     E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, out, out2, emb,      \
-                     poolbits, status)
+  if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(a->graph_ptr); E = 1; }  // readable dummy; no tile has edges
+#define LAUNCH_FWD(KP, VC, PL, ST, BT, HD)                                                                               \
+  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST, BT, HD>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, \
+                     E, a->graph_ptr, a->edge_ptr, N, graphs_per_tile, (int)B, tiles, a->slope, a->apply_act, out, out2, \
+                     emb, poolbits, a->status, H)
 #define DISPATCH_FWD(KP, VC)                                                                                     \
   do {                                                                                                           \
-    if (bits)        { if (stack2) LAUNCH_FWD(KP, VC, true, true, true); else LAUNCH_FWD(KP, VC, true, false, true); } \
-    else if (stack2) { if (emb) LAUNCH_FWD(KP, VC, true, true, false); else LAUNCH_FWD(KP, VC, false, true, false); }  \
-    else             { if (emb) LAUNCH_FWD(KP, VC, true, false, false); else LAUNCH_FWD(KP, VC, false, false, false); } \
+    if (head)        { if (head_bwd) LAUNCH_FWD(KP, VC, true, true, true, 2); else LAUNCH_FWD(KP, VC, true, true, true, 1); } \
+    else if (bits)   { if (stack2) LAUNCH_FWD(KP, VC, true, true, true, 0); else LAUNCH_FWD(KP, VC, true, false, true, 0); } \
+    else if (stack2) { if (emb) LAUNCH_FWD(KP, VC, true, true, false, 0); else LAUNCH_FWD(KP, VC, false, true, false, 0); }  \
+    else             { if (emb) LAUNCH_FWD(KP, VC, true, false, false, 0); else LAUNCH_FWD(KP, VC, false, false, false, 0); } \
   } while (0)
   if (F <= 32) { if (vec) DISPATCH_FWD(32, true); else DISPATCH_FWD(32, false); }
   else         { if (vec) DISPATCH_FWD(64, true); else DISPATCH_FWD(64, false); }
@@ -1003,51 +1100,10 @@ static int launch_fused_fwd(const float* x, const float* W, const float* b, cons
   return HCG_OK;
 }
 
-extern "C" int hcg_fused_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
-                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
-                                   int64_t D, int graphs_per_tile, float slope, int apply_act, float* out, float* emb,
-                                   int32_t* status, hcg_stream_t stream) {
-  return launch_fused_fwd(x, W, b, nullptr, nullptr, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, out, nullptr, emb, nullptr, status, (hipStream_t)stream);
-}
-
-// ---- training forms: the pooled (last) conv layer's activations never reach HBM.  The pooled backward needs two facts
-// per element -- its sign (LeakyReLU') and whether it is its graph's column maximum -- and they leave as 2 bits per
-// element (`poolbits`, hcg_fused_poolbits_bytes) for hcg_fused_layer_bwd_poolbits over the same plan / graphs_per_tile.
+// 2 bits per element of the pooled layer (training forms): see k_fused_layer_fwd<BITS>
 extern "C" size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile) {
   if (graphs_per_tile <= 0 || B <= 0) return 0;
   return (size_t)((B + graphs_per_tile - 1) / graphs_per_tile) * 128 * sizeof(uint32_t);
-}
-
-extern "C" int hcg_fused_layer_fwd_train(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
-                                         const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
-                                         int64_t D, int graphs_per_tile, float slope, int apply_act, float* emb,
-                                         uint32_t* poolbits, int32_t* status, hcg_stream_t stream) {
-  if (!poolbits) return HCG_ERR_INVALID_ARG;
-  return launch_fused_fwd(x, W, b, nullptr, nullptr, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, nullptr, nullptr, emb, poolbits, status, (hipStream_t)stream);
-}
-
-extern "C" int hcg_fused_stack2_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                                          const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
-                                          const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
-                                          int graphs_per_tile, float slope, int apply_act, float* out1, float* emb,
-                                          uint32_t* poolbits, int32_t* status, hcg_stream_t stream) {
-  if (!W2 || !b2 || !poolbits) return HCG_ERR_INVALID_ARG;
-  return launch_fused_fwd(x, W1, b1, W2, b2, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, out1, nullptr, emb, poolbits, status, (hipStream_t)stream);
-}
-
-// two stacked conv layers (F -> 64 -> 64) in ONE launch: out1 = layer-1 node embeddings, out2 = layer-2
-// node embeddings (both are needed by the backward), emb (nullable) = [max, mean] pooling of out2
-extern "C" int hcg_fused_stack2_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                                    const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
-                                    const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
-                                    int graphs_per_tile, float slope, int apply_act, float* out1, float* out2, float* emb,
-                                    int32_t* status, hcg_stream_t stream) {
-  if (!W2 || !b2 || !out2) return HCG_ERR_INVALID_ARG;
-  return launch_fused_fwd(x, W1, b1, W2, b2, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, graphs_per_tile, slope,
-                          apply_act, out1, out2, emb, nullptr, status, (hipStream_t)stream);
 }
 
 static int launch_fused_bwd(const float* dout, const float* demb, const float* emb, const float* out,
@@ -1101,39 +1157,19 @@ static int launch_fused_bwd(const float* dout, const float* demb, const float* e
   return HCG_OK;
 }
 
+// `poolbits` != NULL: pooled backward of a layer whose forward ran in the training form (poolbits stand in for out / emb;
+// dout, emb, out must then be NULL)
 extern "C" int hcg_fused_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
-                                   const float* x, const float* W, const int64_t* edge_index, int64_t E,
+                                   const uint32_t* poolbits, const float* x, const float* W, const int64_t* edge_index, int64_t E,
                                    const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F,
                                    int64_t D, int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
                                    void* workspace, size_t workspace_bytes, hcg_stream_t stream) {
-  return launch_fused_bwd(dout, demb, emb, out, nullptr, x, W, edge_index, E, graph_ptr, edge_ptr, N, B, F, D,
+  if (poolbits && (dout || emb || out || !demb)) return HCG_ERR_INVALID_ARG;
+  return launch_fused_bwd(dout, demb, emb, out, poolbits, x, W, edge_index, E, graph_ptr, edge_ptr, N, B, F, D,
                           graphs_per_tile, slope, apply_act, dx, status, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// pooled backward of a layer whose forward ran in the training form (poolbits instead of out / emb)
-extern "C" int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* poolbits, const float* x, const float* W,
-                                            const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
-                                            const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
-                                            int graphs_per_tile, float slope, int apply_act, float* dx, int32_t* status,
-                                            void* workspace, size_t workspace_bytes, hcg_stream_t stream) {
-  if (!poolbits || !demb) return HCG_ERR_INVALID_ARG;
-  return launch_fused_bwd(nullptr, demb, nullptr, nullptr, poolbits, x, W, edge_index, E, graph_ptr, edge_ptr, N, B, F, D,
-                          graphs_per_tile, slope, apply_act, dx, status, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-// second stage of the backward: dW[D, F], db[D] <- the per-workgroup slabs left in `workspace` by
-// hcg_fused_layer_bwd (same B, F, D, graphs_per_tile), summed in a fixed order.
-extern "C" int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F,
-                                      int64_t D, int graphs_per_tile, float* dW, float* db, hcg_stream_t stream) {
-  // one job for the shared slab-reduction kernel: the same summation order as the batched reduction of a whole step, so
-  // the per-layer and the whole-model paths stay bitwise equal
-  hcg_reduce_job job;
-  const int rc = hcg_fused_reduce_job(workspace, workspace_bytes, N, B, F, D, graphs_per_tile, dW, db, &job);
-  if (rc != HCG_OK) return rc;
-  return hcg_reduce_slabs(&job, 1, stream);
-}
-
-// host-side description of this layer's slab set for hcg_reduce_slabs (no launch)
+// host-side description of this layer's slab set for hcg_step_tail (no launch)
 extern "C" int hcg_fused_reduce_job(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
                                     int graphs_per_tile, float* dW, float* db, hcg_reduce_job* job) {
   if (D != DD || F < 1 || F > 64 || graphs_per_tile < 1 || !dW || !db || !job || !workspace) return HCG_ERR_INVALID_ARG;
@@ -1146,7 +1182,7 @@ extern "C" int hcg_fused_reduce_job(const void* workspace, size_t workspace_byte
   job->nslabs = grid;
   job->slab_floats = slab_floats;
   job->nseg = 2;
-  job->reserved = 0;
+  job->sse_index = 0;
   job->seg[0] = hcg_reduce_seg{0, DD * kpad, kpad, (int32_t)F, dW};
   job->seg[1] = hcg_reduce_seg{DD * kpad, DD, 1, 1, db};
   return HCG_OK;

@@ -1,0 +1,434 @@
+// The regression head on a tile of <= 32 graphs (SURVEY rows a10, a12 and their part of a11; f2), shared by the stand-alone
+// head kernel (head.hip) and by the tail phase of the small-graph forward (fused.hip: the head rides in the conv stack's
+// launch):
+//     z    = LeakyReLU(emb W0^T + b0)            [B, 2D] -> [B, D]        reference model/gcn.py:36-45, 70-71
+//     out  = z W1^T + b1                         [B, D]  -> [B, C]
+//     diff = out - y ; sse += diff^2             reference utils/utils_model.py:64 (`torch.sqrt(model.loss(out, y))`)
+//     backward of SSE / 2 (dloss/dout = diff, UNSCALED): dz, demb, dW0, db0, dW1, db1     (utils/utils_model.py:65)
+// The batch-dependent factor of the real loss gradient -- 1 / (B C sqrt(MSE)) -- is ONE scalar and the backward is linear
+// in it, so nothing here waits for the other workgroups: each leaves its partial sum of squared errors in its slab and the
+// step's last launch (reduce.hip: k_step_tail) applies the scale while it reduces.  Round 2 exchanged that scalar across
+// the grid inside the head kernel (8-byte stamped slots, bounded polls, co-residency): all of it is gone.
+// Contractions on v_mfma_f32_32x32x2_f32 (exact f32): the head is latency-bound, not MFMA-bound.
+#pragma once
+#include "common.h"
+
+namespace hcg_head {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// see split_mfma.h (mfma_results_fence): keep VALU reads of an accumulator a whole foreign MFMA away from the chain's
+// last MFMA when several waves share the SIMD's matrix pipe (f32 32x32x2: 16 passes = 64 cycles)
+__device__ __forceinline__ void results_fence(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a)); }
+
+constexpr int RT = 32;            // graphs per tile
+constexpr int RCMAX = 8;
+
+// Shapes of the head for hidden width RD (= embedding_dim: 64, the reference's default, options/base_options.py:199-204;
+// 128 = BASELINE configs[4]).  Wave roles: forward = RD/32 output column blocks x 2 K halves -> HW = RD/16 waves (4 / 8);
+// backward = one 32-column block of the 2RD-wide embedding per wave (2RD/32 = HW blocks).
+template <int RD_>
+struct HC {
+  static constexpr int RD = RD_;          // hidden width
+  static constexpr int RK = 2 * RD;       // pooled embedding width
+  static constexpr int NB = RD / 32;      // output column blocks of the forward GEMM
+  static constexpr int HW = 2 * NB;       // working waves
+  static constexpr int NT = HW * 64;      // working threads
+  static constexpr int ES = RK + 4;       // LDS stride of the emb tile
+  static constexpr int ZS = RD + 4;       // LDS stride of the z / dz tile
+  static constexpr int WS0 = RK + 1;      // LDS stride of the W0 image [RD][RK]
+  static constexpr bool W0_LDS = RD <= 64;   // RD = 128: the image would be 131 KB -- the W0 fragments come from global memory / L2
+  static constexpr int OJ = RD / 8;       // out projection: threads per graph row (8 hidden units each)
+  static constexpr int QN = RD / 4;       // backward step 1: float4 column groups of a dz row
+  // slab layout per WORKGROUP: dW0 [RD][RK] | db0 [RD] | dW1 [RCMAX][RD] | db1 [RCMAX] | SSE partial | pad
+  static constexpr int SMALL = RD + RCMAX * RD + RCMAX;       // db0 | dW1 | db1
+  static constexpr int SSE_INDEX = RD * RK + SMALL;
+  static constexpr int SLAB = SSE_INDEX + 8;                  // (slab rows stay 32-byte aligned)
+  static constexpr int ESZ = RT * ES > HW * (SMALL + 8) ? RT * ES : HW * (SMALL + 8);    // emb tile, later the combine scratch
+};
+
+__device__ __forceinline__ constexpr int krow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+template <int RD>
+struct HeadLds {
+  using C_ = HC<RD>;
+  float w0[C_::W0_LDS ? RD * C_::WS0 : 4];   // W0 [d][k]
+  float e[C_::ESZ];              // emb tile
+  float z[RT * C_::ZS];          // z tile, later dz
+  float part[C_::NB][RT * 33];   // K-half partial sums of the forward GEMM (per column block)
+  float diff[RT][RCMAX];         // out - y
+  float w1[RCMAX * RD];
+  float red[16];
+};
+
+// per-thread state that lives across the tiles of a workgroup
+// RC = compile-time bound of the class count handled in registers: 1 (the reference's regression, n_classes = 1,
+// options/base_options.py:178-183) or RCMAX -- with eight classes' accumulators live across the tile loop the 128-wide
+// head spilled 82 registers
+template <int RD, int RC>
+struct HeadState {
+  using K = HC<RD>;
+  float bz;                      // b0 of this wave's forward column
+  float b1v[RC];
+  float sse;                     // thread-private partial of the squared error, fixed tile order
+  f32x16 dw0[K::NB];             // dW0[:, cb] row blocks, accumulated over the tiles
+  float4 db0;
+  float4 dw1[RC];
+  float db1[RC];
+};
+
+// weights -> LDS once per workgroup; biases -> registers.  Every global load is issued before the first LDS write (a
+// load-store loop would serialise 32 HBM round trips per thread).  All threads of the block call it; threads >= NT idle.
+// Ends WITHOUT a barrier: the first tile's leading __syncthreads orders the staging.
+template <int RD, int RC>
+__device__ __forceinline__ void head_begin(HeadLds<RD>& L, HeadState<RD, RC>& S, const float* __restrict__ W0,
+                                           const float* __restrict__ b0, const float* __restrict__ W1,
+                                           const float* __restrict__ b1, int C) {
+  using K = HC<RD>;
+  constexpr int RK = K::RK, NT = K::NT, WS0 = K::WS0, NB = K::NB;
+  constexpr bool W0_LDS = K::W0_LDS;
+  const bool active = threadIdx.x < NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31;
+  S.sse = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.dw0[mb][i] = 0.f;
+  S.db0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < RC; ++c) { S.dw1[c] = make_float4(0.f, 0.f, 0.f, 0.f); S.db1[c] = 0.f; S.b1v[c] = 0.f; }
+  S.bz = 0.f;
+  if (!active) return;
+  constexpr int W4 = W0_LDS ? RD * RK / 4 / NT : 1;          // 8 float4 of W0 per thread
+  constexpr int W1N = RCMAX * RD / NT;
+  float4 wv[W4];
+  if (W0_LDS) {
+#pragma unroll
+    for (int it = 0; it < W4; ++it) wv[it] = *reinterpret_cast<const float4*>(W0 + 4 * (threadIdx.x + it * NT));
+  }
+  float w1v[W1N];
+#pragma unroll
+  for (int it = 0; it < W1N; ++it) {
+    const int idx = threadIdx.x + it * NT;
+    w1v[it] = W1[idx < C * RD ? idx : 0];
+  }
+  S.bz = b0[(wave % NB) * 32 + r];
+#pragma unroll
+  for (int c = 0; c < RC; ++c) S.b1v[c] = b1[c < C ? c : 0];
+  if (W0_LDS) {
+#pragma unroll
+    for (int it = 0; it < W4; ++it) {
+      const int f4 = threadIdx.x + it * NT, row = f4 / (RK / 4), c4 = f4 - row * (RK / 4);
+      float* dst = L.w0 + row * WS0 + 4 * c4;
+      dst[0] = wv[it].x; dst[1] = wv[it].y; dst[2] = wv[it].z; dst[3] = wv[it].w;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < W1N; ++it) {
+    const int idx = threadIdx.x + it * NT;
+    L.w1[idx] = idx < C * RD ? w1v[it] : 0.f;
+  }
+}
+
+// One tile: rows [0, n) are graphs gmap(row) (ascending), rows >= n are padding.  `BACKWARD` false: forward + squared
+// error only.  Every thread of the block must call it (workgroup barriers inside); threads >= NT only take the barriers.
+template <int RD, int RC, bool BACKWARD, class GMap>
+__device__ __forceinline__ void head_tile(HeadLds<RD>& L, HeadState<RD, RC>& S, GMap gmap, int n, int C, float slope,
+                                          const float* __restrict__ emb, const float* __restrict__ y,
+                                          const float* __restrict__ W0, float* __restrict__ z, float* __restrict__ out,
+                                          float* __restrict__ demb) {
+  using K = HC<RD>;
+  constexpr int RK = K::RK, NB = K::NB, NT = K::NT, ES = K::ES, ZS = K::ZS, WS0 = K::WS0, OJ = K::OJ, QN = K::QN;
+  constexpr bool W0_LDS = K::W0_LDS;
+  const bool active = threadIdx.x < NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nb = wave % NB, kh = (wave / NB) & 1;              // forward: output column block / K half of this wave
+  const int orow = (threadIdx.x / OJ) & (RT - 1), oj = threadIdx.x % OJ;   // out projection: OJ threads per graph row
+  const int last = n > 0 ? n - 1 : 0;
+  // ---- targets + emb rows: every load issued before the first LDS write
+  float yv[RC];
+  constexpr int PER_ROW = RK / 4, ITER = RT * PER_ROW / NT;
+  static_assert(RT * PER_ROW % NT == 0, "rows per thread");
+  float4 ev[ITER];
+  if (active) {
+    const int gy = gmap(orow < n ? orow : last);
+#pragma unroll
+    for (int c = 0; c < RC; ++c) yv[c] = y[(size_t)gy * C + (c < C ? c : C - 1)];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + it * NT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+      ev[it] = *reinterpret_cast<const float4*>(emb + (size_t)gmap(row < n ? row : last) * RK + 4 * c4);
+    }
+  }
+  __syncthreads();                                      // previous tile's readers are done (also orders the weight staging)
+  if (active) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + it * NT, row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+      if (row >= n) ev[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(L.e + row * ES + 4 * c4) = ev[it];
+    }
+  }
+  __syncthreads();
+  // ---- z = LeakyReLU(emb W0^T + b0): wave (nb, kh) = output column block x K half
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (active) {
+    if (W0_LDS) {
+#pragma unroll
+      for (int t8 = 0; t8 < RK / 16; ++t8) {              // this wave's K half: k = RD kh + 8 t8 + 4h + u
+        const int k0 = RD * kh + 8 * t8 + 4 * h;
+        const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + k0);
+        const float* wrow = L.w0 + (nb * 32 + r) * WS0 + k0;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wrow[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wrow[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wrow[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wrow[3], acc, 0, 0, 0);
+      }
+    } else {
+      // W0 fragments straight from global memory / L2 (every workgroup reads the same 131 KB): four float4 in flight
+      // (eight, beside the backward's accumulators that live across the tile loop, spilled 82 registers)
+      constexpr int WB = 4;
+      const float* wg = W0 + (size_t)(nb * 32 + r) * RK + RD * kh + 4 * h;
+#pragma unroll 1
+      for (int t0 = 0; t0 < RK / 16; t0 += WB) {
+        float4 wv[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) wv[u] = *reinterpret_cast<const float4*>(wg + 8 * (t0 + u));
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(L.e + r * ES + RD * kh + 8 * (t0 + u) + 4 * h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
+        }
+      }
+    }
+    results_fence(acc);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L.part[nb][krow(i, h) * 33 + r] = acc[i];
+    }
+  }
+  __syncthreads();
+  if (active && kh == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = krow(i, h);
+      const float v = hcg_leaky((acc[i] + L.part[nb][row * 33 + r]) + S.bz, slope);
+      L.z[row * ZS + nb * 32 + r] = v;
+      if (row < n) z[(size_t)gmap(row) * RD + nb * 32 + r] = v;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    // out[row][c] = z[row] . W1[c] + b1[c] ; diff = out - y.  Thread (row, j): hidden units 8j..8j+7 of every class,
+    // the OJ partial sums of a row meet by xor-shuffles (fixed order)
+    const float4 za = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj);
+    const float4 zb = *reinterpret_cast<const float4*>(L.z + orow * ZS + 8 * oj + 4);
+    const int go = gmap(orow < n ? orow : last);
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      if (c < C) {                                     // block-uniform
+        const float4 wa = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj);
+        const float4 wb = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj + 4);
+        float s = ((za.x * wa.x + za.y * wa.y) + (za.z * wa.z + za.w * wa.w)) + ((zb.x * wb.x + zb.y * wb.y) + (zb.z * wb.z + zb.w * wb.w));
+#pragma unroll
+        for (int off = 1; off < OJ; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (oj == 0) {
+          float d = 0.f;
+          if (orow < n) {
+            s += S.b1v[c];
+            out[(size_t)go * C + c] = s;
+            d = s - yv[c];
+            S.sse += d * d;
+          }
+          L.diff[orow][c] = d;
+        }
+      } else if (oj == 0) {
+        L.diff[orow][c] = 0.f;
+      }
+    }
+  }
+  if (!BACKWARD) return;
+  __syncthreads();
+  // ---- backward of SSE / 2 on the unscaled diff
+  const int q = threadIdx.x % QN, rgrp = (threadIdx.x / QN) & 15;     // step 1: float4 column group / row (16 rows per pass)
+  const int cb = wave & (K::HW - 1);                   // this wave's 32-column block of the 2RD-wide embedding
+  // 1. dz = (dout W1) * leaky'(z) -> L.z ; db0, dW1, db1 partial sums.  Two (row, 4-column) slots per thread.
+  float4 dzv[2];
+  if (active) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + rgrp;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n) {
+        const float4 zz = *reinterpret_cast<const float4*>(L.z + row * ZS + 4 * q);
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+          if (c < C) {
+            const float go = L.diff[row][c];
+            const float4 w = *reinterpret_cast<const float4*>(L.w1 + c * RD + 4 * q);
+            d.x += go * w.x; d.y += go * w.y; d.z += go * w.z; d.w += go * w.w;
+            S.dw1[c].x += go * zz.x; S.dw1[c].y += go * zz.y; S.dw1[c].z += go * zz.z; S.dw1[c].w += go * zz.w;
+            if (q == 0) S.db1[c] += go;
+          }
+        }
+        d.x *= hcg_leaky_grad(zz.x, slope); d.y *= hcg_leaky_grad(zz.y, slope);
+        d.z *= hcg_leaky_grad(zz.z, slope); d.w *= hcg_leaky_grad(zz.w, slope);
+        S.db0.x += d.x; S.db0.y += d.y; S.db0.z += d.z; S.db0.w += d.w;
+      }
+      dzv[it] = d;
+    }
+  }
+  __syncthreads();                                   // every read of z is done
+  if (active) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + rgrp;
+      *reinterpret_cast<float4*>(L.z + row * ZS + 4 * q) = dzv[it];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    // 2. dW0[:, cb] += dz^T emb[:, cb]   (K = graph rows)
+#pragma unroll
+    for (int s = 0; s < RT / 2; ++s) {
+      const int row = 2 * s + h;
+      const float bv = L.e[row * ES + cb * 32 + r];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+        S.dw0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.z[row * ZS + mb * 32 + r], bv, S.dw0[mb], 0, 0, 0);
+    }
+    // 3. demb[:, cb] = dz W0[:, cb]
+    f32x16 de;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) de[i] = 0.f;
+    if (W0_LDS) {
+#pragma unroll
+      for (int t8 = 0; t8 < RD / 8; ++t8) {
+        const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * t8 + 4 * h);
+        const int d0 = 8 * t8 + 4 * h;
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, L.w0[(d0 + 0) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, L.w0[(d0 + 1) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, L.w0[(d0 + 2) * WS0 + cb * 32 + r], de, 0, 0, 0);
+        de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, L.w0[(d0 + 3) * WS0 + cb * 32 + r], de, 0, 0, 0);
+      }
+    } else {
+      constexpr int WB = 4;                            // 16 dword loads of W0 in flight (coalesced across r)
+#pragma unroll 1
+      for (int t0 = 0; t0 < RD / 8; t0 += WB) {
+        float wv[WB][4];
+#pragma unroll
+        for (int u = 0; u < WB; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wv[u][j] = W0[(size_t)(8 * (t0 + u) + 4 * h + j) * RK + cb * 32 + r];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(L.z + r * ZS + 8 * (t0 + u) + 4 * h);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u][0], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u][1], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u][2], de, 0, 0, 0);
+          de = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u][3], de, 0, 0, 0);
+        }
+      }
+    }
+    results_fence(de);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = krow(i, h);
+      if (row < n) demb[(size_t)gmap(row) * RK + cb * 32 + r] = de[i];
+    }
+  }
+}
+
+// One slab per workgroup: gradient partial sums (BACKWARD) and the partial sum of squared errors.  Every thread of the
+// block calls it.
+template <int RD, int RC, bool BACKWARD>
+__device__ __forceinline__ void head_end(HeadLds<RD>& L, HeadState<RD, RC>& S, int C, float* __restrict__ slab) {
+  using K = HC<RD>;
+  constexpr int RK = K::RK, NB = K::NB, HW = K::HW, NT = K::NT, QN = K::QN, SMALL = K::SMALL;
+  const bool active = threadIdx.x < NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5, q = threadIdx.x % QN, cb = wave & (HW - 1);
+  // block partial of the squared error: lanes -> wave (fixed xor tree) -> block (fixed order)
+  float sse = S.sse;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sse += __shfl_xor(sse, off, 64);
+  __syncthreads();                                     // the last tile's readers of e / z are done
+  if (active && lane == 0) L.red[wave] = sse;
+  float* scratch = L.e;                                // [HW][SMALL + 8]: the emb tile is dead
+  if (BACKWARD && active) {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) results_fence(S.dw0[mb]);
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) slab[(mb * 32 + krow(i, h)) * RK + cb * 32 + r] = S.dw0[mb][i];
+    // db0 / dW1 / db1: thread (row group, q) holds partial sums for columns 4q..4q+3; combine the row groups of a wave
+    // (64 / QN of them) by shuffles, the waves through LDS -- all in a fixed order
+    auto fold = [](float4 v) {
+#pragma unroll
+      for (int off = QN; off < 64; off <<= 1) {
+        v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+      }
+      return v;
+    };
+    float* mine = scratch + wave * (SMALL + 8);
+    const float4 db0 = fold(S.db0);
+    if (lane < QN) *reinterpret_cast<float4*>(mine + 4 * q) = db0;
+#pragma unroll
+    for (int c = 0; c < RCMAX; ++c) {
+      if (c < RC && c < C) {                           // block-uniform: classes the model does not have cost no shuffles
+        const float4 v = fold(S.dw1[c < RC ? c : 0]);
+        if (lane < QN) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = v;
+        float sc = S.db1[c < RC ? c : 0];              // lanes with q == 0 hold the partial sums
+#pragma unroll
+        for (int off = QN; off < 64; off <<= 1) sc += __shfl_xor(sc, off, 64);
+        if (lane == 0) mine[RD + RCMAX * RD + c] = sc;
+      } else {
+        if (lane < QN) *reinterpret_cast<float4*>(mine + RD + c * RD + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) mine[RD + RCMAX * RD + c] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float block_sse = L.red[0];
+#pragma unroll
+    for (int w = 1; w < HW; ++w) block_sse += L.red[w];
+    slab[K::SSE_INDEX] = block_sse;
+  }
+  if (BACKWARD && active) {
+    for (int idx = threadIdx.x; idx < SMALL; idx += NT) {
+      float sm = scratch[idx];
+#pragma unroll
+      for (int w = 1; w < HW; ++w) sm += scratch[w * (SMALL + 8) + idx];
+      slab[RD * RK + idx] = sm;
+    }
+  }
+}
+
+// host side: the reduce job of `nslabs` head slabs (dW0 == nullptr: partials only)
+template <int RD>
+inline void head_fill_job(const float* slabs, int nslabs, int C, float* dW0, float* db0, float* dW1, float* db1,
+                          hcg_reduce_job* job) {
+  using K = HC<RD>;
+  constexpr int RK = K::RK;
+  job->slabs = slabs;
+  job->nslabs = nslabs;
+  job->slab_floats = K::SLAB;
+  job->nseg = dW0 ? 4 : 0;
+  job->sse_index = K::SSE_INDEX;
+  for (int g = 0; g < HCG_REDUCE_MAX_SEGS; ++g) job->seg[g] = hcg_reduce_seg{0, 0, 1, 1, nullptr};
+  if (dW0) {
+    job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
+    job->seg[1] = hcg_reduce_seg{RD * RK, RD, 1, 1, db0};
+    job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};
+    job->seg[3] = hcg_reduce_seg{RD * RK + RD + RCMAX * RD, (int32_t)C, 1, 1, db1};
+  }
+}
+
+}  // namespace hcg_head

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_mse_bwd(const float* __restrict__ a, co
 }
 
 // loss AND its gradient in one launch (one workgroup: n = B * C is a few thousand): mode 0 = MSE, 1 = sqrt(MSE),
-// HCG_HEAD_SSE = the data-parallel form of hcg_head_fwd_bwd_ex (dout = a - b unscaled, [SSE, n] -> sse_tail).
+// HCG_LOSS_SSE = the data-parallel form with a collective (dout = a - b unscaled, [SSE, n] -> sse_tail).
 __global__ __launch_bounds__(LT) void k_loss_fwd_bwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int mode,
                                                      float* __restrict__ loss, float* __restrict__ da,
                                                      float* __restrict__ sse_tail) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(LT) void k_loss_fwd_bwd(const float* __restrict__ a
     loss[0] = lv;
     loss[1] = mse;
     if (sse_tail) { sse_tail[0] = tot; sse_tail[1] = (float)n; }
-    bc = mode == HCG_HEAD_SSE ? 1.0f : mode ? 1.0f / ((float)n * lv) : 2.0f / (float)n;
+    bc = mode == HCG_LOSS_SSE ? 1.0f : mode ? 1.0f / ((float)n * lv) : 2.0f / (float)n;
   }
   __syncthreads();
   const float scale = bc;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(LT) void k_loss_fwd_bwd(const float* __restrict__ a
 
 extern "C" int hcg_loss_fwd_bwd(const float* a, const float* b, int64_t n, int mode, float* loss, float* da, float* sse_tail,
                                 hcg_stream_t stream) {
-  if (n <= 0 || !a || !b || !loss || !da || mode < 0 || mode > HCG_HEAD_SSE || (mode == HCG_HEAD_SSE && !sse_tail))
+  if (n <= 0 || !a || !b || !loss || !da || mode < 0 || mode > HCG_LOSS_SSE || (mode == HCG_LOSS_SSE && !sse_tail))
     return HCG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(k_loss_fwd_bwd, dim3(1), dim3(LT), 0, (hipStream_t)stream, a, b, n, mode, loss, da, sse_tail);
   HCG_CHECK_LAUNCH();

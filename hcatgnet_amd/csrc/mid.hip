@@ -12,7 +12,7 @@
 //     four rows per pass) -- the neighbour gather never touches HBM;
 //   * out = LeakyReLU(dinv . Y + b) stored once (row-contiguous 256 B), optional [max, mean] pooling epilogue.
 // backward mirrors it (dY' tile -> transpose segmented sum -> dH tile -> dW on the matrix cores with K = nodes,
-// dX = dH W), per-workgroup gradient slabs reduced in a fixed order by hcg_reduce_slabs.
+// dX = dH W), per-workgroup gradient slabs reduced in a fixed order by hcg_step_tail.
 // LDS is sized at launch from the batch's largest graph (dynamic shared memory): 2 workgroups per CU up to 96 nodes.
 #include "common.h"
 #include "split_mfma.h"
@@ -762,7 +762,7 @@ extern "C" size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64
 
 // backward, stage 1 (one launch per 64-column half).  dout == NULL selects the pooled form (upstream gradient = demb
 // [B, 2D], expanded on chip with `emb`).  dx nullable (first layer).  Leaves one slab per workgroup and half in
-// `workspace`; describe them with hcg_mid_reduce_job (one job per half) and sum with hcg_reduce_slabs.
+// `workspace`; describe them with hcg_mid_reduce_job (one job per half) and sum with hcg_step_tail.
 extern "C" int hcg_mid_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
                                  const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                  const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
@@ -826,7 +826,7 @@ extern "C" int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes,
   job->nslabs = gsz;
   job->slab_floats = DD * fpad + DD;
   job->nseg = 2;
-  job->reserved = 0;
+  job->sse_index = 0;
   job->seg[0] = hcg_reduce_seg{0, DD * fpad, fpad, (int32_t)F, dW + (size_t)half * DD * F};
   job->seg[1] = hcg_reduce_seg{DD * fpad, DD, 1, 1, db + half * DD};
   return HCG_OK;

@@ -54,7 +54,7 @@ namespace {
 
 // step count and learning rate read from device memory (hipGraph-capturable).  Bias corrections in double
 // like torch's host computation.  The last workgroup to take a ticket publishes step + 1.
-// SSE: `g` = [n summed SSE/2-gradients | SSE | count] (data-parallel form of the head, hcg_head_fwd_bwd_ex): the
+// SSE: `g` = [n summed SSE/2-gradients | SSE | count] (data-parallel form HCG_LOSS_SSE): the
 // gradient of sqrt(MSE) over all ranks' graphs is g * 1 / (count * sqrt(SSE / count)); written back in place.
 template <bool SSE>
 __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,

@@ -315,10 +315,13 @@ extern "C" int hcg_readout2_bwd(const float* dout, const float* emb, const float
   hcg_reduce_job job;
   const int rc = hcg_readout2_reduce_job(workspace, workspace_bytes, B, C, dW0, db0, dW1, db1, &job);
   if (rc != HCG_OK) return rc;
-  return hcg_reduce_slabs(&job, 1, stream_);
+  hcg_tail_args ta{};
+  ta.jobs_host = &job;
+  ta.njobs = 1;
+  return hcg_step_tail(&ta, stream_);
 }
 
-// backward without the slab reduction (pair with hcg_readout2_reduce_job + hcg_reduce_slabs)
+// backward without the slab reduction (pair with hcg_readout2_reduce_job + hcg_step_tail)
 extern "C" int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z, const float* W0,
                                         const float* W1, int64_t B, int64_t D, int64_t C, float slope, float* demb,
                                         void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
@@ -342,7 +345,7 @@ extern "C" int hcg_readout2_reduce_job(const void* workspace, size_t workspace_b
   job->nslabs = grid;
   job->slab_floats = SLAB;
   job->nseg = 4;
-  job->reserved = 0;
+  job->sse_index = 0;
   job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
   job->seg[1] = hcg_reduce_seg{RD * RK, RD, 1, 1, db0};
   job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};

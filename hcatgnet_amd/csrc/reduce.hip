@@ -70,7 +70,7 @@ struct XchgArgs {
   int rank, world;
   int64_t n_ext;                                 // n + 2: gradients | SSE | count
   int mode;                                      // HCG_XCHG_MEAN: (sum over ranks) / world; HCG_XCHG_SSE: the SSE form's scale
-  float* flat_ext;                               // [n + 2] local: gradients are written back here, [n], [n + 1] = this rank's SSE, count
+  const float* flat_ext;                         // [n + 2] local; without SSE partials in a job, [n], [n + 1] = this rank's SSE, count
   float* loss;                                   // [2]: SSE mode: global sqrt(MSE), MSE
   int32_t* err;
 };
@@ -110,9 +110,33 @@ __device__ __forceinline__ float xchg_gather(const XchgArgs& X, int parity, int6
   return sum;
 }
 
-template <bool ADAM, bool PLAN = false, bool XCHG = false>
-__global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, PlanArgs P = PlanArgs{}, XchgArgs X = XchgArgs{}) {
-  if (PLAN && (int)blockIdx.y == jobs.njobs) {        // block-uniform
+// LOSS: the deferred loss scale.  Every backward launch of the step ran on the UNSCALED error (out - y): the whole
+// backward is linear in dloss/dout = scale * (out - y), scale being the one number that depends on the whole batch
+// (1 / (count * sqrt(MSE)) for the reference's sqrt(MSE), utils/utils_model.py:64).  The readout head leaves one partial sum
+// of squared errors per workgroup in its slabs (hcg_reduce_job.sse_index); every block of THIS launch adds them in the same
+// fixed order (bitwise the same scale everywhere), and the scale multiplies each gradient element as it is reduced --
+// no grid-wide exchange, no launch of its own (round 2's head kernel spent a grid barrier on this scalar).
+struct LossArgs {
+  const float* sse_part;    // first partial; nullptr = the slabs hold final gradients (scale 1)
+  int nparts, stride;       // partial b at sse_part[b * stride]
+  float count;              // elements of the squared-error sum on this rank (B * C)
+  int mode;                 // HCG_LOSS_MSE / HCG_LOSS_RMSE / HCG_LOSS_SSE
+  float* loss;              // [2] nullable: the loss, the MSE
+  float* sse_tail;          // [2] nullable: this rank's SSE and count (data-parallel "sse" form with a collective)
+};
+
+// sum of the SSE partials: lanes take partials l, l + 64, ... in ascending order, then a fixed xor tree
+__device__ __forceinline__ float loss_sse_sum(const LossArgs& L, int lane) {
+  float s = 0.f;
+  for (int b = lane; b < L.nparts; b += 64) s += L.sse_part[(size_t)b * L.stride];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+
+template <bool ADAM, bool XCHG = false>
+__global__ __launch_bounds__(256) void k_step_tail(Jobs jobs, AdamArgs A, PlanArgs P, LossArgs L, XchgArgs X = XchgArgs{}) {
+  if (P.batch != nullptr && (int)blockIdx.y == jobs.njobs) {        // block-uniform: the NEXT batch's plan
     const int64_t total = P.N + P.E + 2, stride = (int64_t)gridDim.x * 256;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride)
       hcg_ptrs_thread(t, P.ei, P.batch, P.N, P.E, P.B, P.graph_ptr, P.edge_ptr, P.status);
@@ -123,29 +147,52 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
   const int o = threadIdx.x % RO, sl = threadIdx.x / RO;
   const int idx = blockIdx.x * RO + o;
   if (blockIdx.x * RO >= J.slab_floats) return;   // block-uniform
-  __shared__ float adam_c[3];                        // lr / bias-correction-1, sqrt(bias-correction-2), [XCHG] gradient scale
+  // [0] lr / bias-correction-1, [1] sqrt(bias-correction-2), [2] scale applied to this rank's sum (before an exchange),
+  // [3] scale applied to the exchanged total
+  __shared__ float adam_c[4];
   const unsigned xstep = XCHG ? (unsigned)A.step_dev[0] : 0u;
   const int parity = (int)(xstep & 1u);
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation
     const int t = A.step_dev[0];                     // number of THIS update (advanced earlier in the step)
     adam_c[0] = A.lr_dev[0] / (float)(1.0 - hcg_powi((double)A.b1, t));
     adam_c[1] = (float)sqrt(1.0 - hcg_powi((double)A.b2, t));
   }
-  if (XCHG && threadIdx.x == 255) {                  // the two tail elements [SSE, count]: published once per rank, gathered by every block
-    const int64_t n = X.n_ext - 2;
-    const float sse = X.flat_ext[n], cnt = X.flat_ext[n + 1];
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-      xchg_publish(X, parity, n, sse, xstep);
-      xchg_publish(X, parity, n + 1, cnt, xstep);
+  if (threadIdx.x >= 192) {                          // wave 3: the loss, its scale, the exchange of [SSE, count]
+    const int lane = threadIdx.x - 192;
+    float sse = 0.f, cnt = 1.f, pre = 1.f, post = 1.f;
+    const bool deferred = L.sse_part != nullptr;
+    if (deferred) {
+      sse = loss_sse_sum(L, lane);
+      cnt = L.count;
+      const float mse = sse / cnt, lv = sqrtf(mse);
+      if (L.mode == HCG_LOSS_RMSE) pre = 1.0f / (cnt * lv);
+      else if (L.mode == HCG_LOSS_MSE) pre = 2.0f / cnt;
+      if (first && lane == 0) {
+        if (L.loss && !(XCHG && X.mode == HCG_XCHG_SSE)) { L.loss[0] = L.mode == HCG_LOSS_MSE ? mse : lv; L.loss[1] = mse; }
+        if (L.sse_tail) { L.sse_tail[0] = sse; L.sse_tail[1] = cnt; }
+      }
+    } else if (XCHG) {
+      const int64_t n = X.n_ext - 2;
+      sse = X.flat_ext[n];
+      cnt = X.flat_ext[n + 1];
     }
-    float scale = 1.0f / (float)X.world;
-    if (X.mode == HCG_XCHG_SSE) {
-      const float sse_t = xchg_gather(X, parity, n, sse, xstep), cnt_t = xchg_gather(X, parity, n + 1, cnt, xstep);
-      const float mse = sse_t / cnt_t, lv = sqrtf(mse);
-      scale = 1.0f / (cnt_t * lv);
-      if (blockIdx.x == 0 && blockIdx.y == 0) { X.loss[0] = lv; X.loss[1] = mse; }
+    if (XCHG && lane == 63) {                        // the two tail elements: published once per rank, gathered by every block
+      const int64_t n = X.n_ext - 2;
+      if (first) {
+        xchg_publish(X, parity, n, sse, xstep);
+        xchg_publish(X, parity, n + 1, cnt, xstep);
+      }
+      post = 1.0f / (float)X.world;
+      if (X.mode == HCG_XCHG_SSE) {
+        const float sse_t = xchg_gather(X, parity, n, sse, xstep), cnt_t = xchg_gather(X, parity, n + 1, cnt, xstep);
+        const float mse = sse_t / cnt_t, lv = sqrtf(mse);
+        pre = 1.0f;
+        post = 1.0f / (cnt_t * lv);
+        if (first) { X.loss[0] = lv; X.loss[1] = mse; }
+      }
     }
-    adam_c[2] = scale;
+    if (lane == 63) { adam_c[2] = pre; adam_c[3] = post; }
   }
   // where this output element goes (threads of slice 0 only), and -- fused update -- its parameter and moments,
   // requested BEFORE the slab loop: the update then waits on nothing but the sum
@@ -179,9 +226,10 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < RS; ++k) tot += part[k][o];
+    tot *= adam_c[2];
     if (XCHG) {                                        // this rank's partial -> every peer; all ranks' partials -> the gradient
       xchg_publish(X, parity, (int64_t)off, tot, xstep);
-      tot = xchg_gather(X, parity, (int64_t)off, tot, xstep) * adam_c[2];
+      tot = xchg_gather(X, parity, (int64_t)off, tot, xstep) * adam_c[3];
     }
     *gdst = tot;
     if (ADAM) {
@@ -194,12 +242,93 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(Jobs jobs, AdamArgs A, Plan
   }
 }
 
+// the loss alone from a head's SSE partials (forward-only steps: the reference's eval_network body, utils/utils_model.py:75-78)
+__global__ __launch_bounds__(64) void k_loss_finalize(LossArgs L) {
+  const float sse = loss_sse_sum(L, threadIdx.x);
+  if (threadIdx.x == 0) {
+    const float mse = sse / L.count;
+    L.loss[0] = L.mode == HCG_LOSS_MSE ? mse : sqrtf(mse);
+    L.loss[1] = mse;
+    if (L.sse_tail) { L.sse_tail[0] = sse; L.sse_tail[1] = L.count; }
+  }
+}
+
 }  // namespace
 
-static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamArgs* adam, int64_t n_flat, hipStream_t stream,
-                         const PlanArgs* plan = nullptr, const XchgArgs* xchg = nullptr) {
+// the job that carries the head's SSE partials -> LossArgs (at most one per step)
+static int loss_args_from_jobs(const hcg_reduce_job* jobs_host, int njobs, float count, int mode, float* loss, float* sse_tail,
+                               LossArgs* out) {
+  LossArgs L{};
+  for (int j = 0; j < njobs; ++j) {
+    const hcg_reduce_job& J = jobs_host[j];
+    if (J.sse_index <= 0) continue;
+    if (L.sse_part || J.sse_index >= J.slab_floats || J.nslabs < 1) return HCG_ERR_INVALID_ARG;
+    L.sse_part = J.slabs + J.sse_index;
+    L.nparts = J.nslabs;
+    L.stride = J.slab_floats;
+  }
+  if (L.sse_part) {
+    if (!(count > 0.f) || (mode != HCG_LOSS_MSE && mode != HCG_LOSS_RMSE && mode != HCG_LOSS_SSE)) return HCG_ERR_INVALID_ARG;
+    L.count = count; L.mode = mode; L.loss = loss; L.sse_tail = sse_tail;
+  }
+  *out = L;
+  return HCG_OK;
+}
+
+// Workgroups of the exchanging tail that can be resident at once (occupancy query x CUs, cached).  A polling workgroup waits
+// for granules that the peer publishes from ITS workgroups; if more workgroups poll than fit on the chip, a rank's resident
+// ones could wait for elements whose publishers are still queued behind the peer's resident pollers -- a circular wait that
+// only the bounded polls would end.  hcg_step_tail refuses such a launch instead (HCG_ERR_UNSUPPORTED); blocks without an
+// output element return at once and do not count.
+extern "C" int hcg_xchg_resident_blocks(void) {
+  static int cap = -1;      // queried once per process (also keeps the query out of a stream capture)
+  if (cap >= 0) return cap;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_step_tail<true, true>, 256, 0) != hipSuccess) per_cu = 0;
+  cap = cus * per_cu;
+  return cap;
+}
+
+extern "C" size_t hcg_tail_args_bytes(void) { return sizeof(hcg_tail_args); }
+extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }
+
+extern "C" int hcg_step_tail(const hcg_tail_args* a, hcg_stream_t stream_) {
+  if (!a) return HCG_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int njobs = a->njobs;
+  const hcg_reduce_job* jobs_host = a->jobs_host;
+  const bool adam = a->param != nullptr, plan = a->next_batch != nullptr, xchg = a->inbox != nullptr;
   if (njobs < 0 || njobs > HCG_REDUCE_MAX_JOBS || (njobs > 0 && !jobs_host)) return HCG_ERR_INVALID_ARG;
-  if (njobs == 0) return adam ? HCG_ERR_INVALID_ARG : HCG_OK;
+  if (njobs == 0) return (adam || plan || xchg) ? HCG_ERR_INVALID_ARG : HCG_OK;
+  AdamArgs A{};
+  if (adam) {
+    if (a->n <= 0 || !a->grad_flat || !a->exp_avg || !a->exp_avg_sq || !a->lr_dev || !a->step_dev) return HCG_ERR_INVALID_ARG;
+    A = AdamArgs{a->grad_flat, a->param, a->exp_avg, a->exp_avg_sq, a->lr_dev, (const int*)a->step_dev, a->beta1, a->beta2, a->eps};
+  }
+  PlanArgs P{};
+  if (plan) {
+    if (a->next_N < 0 || a->next_E < 0 || a->next_B < 0 || !a->next_graph_ptr || !a->next_edge_ptr || !a->next_status ||
+        (a->next_E > 0 && !a->next_edge_index))
+      return HCG_ERR_INVALID_ARG;
+    P = PlanArgs{a->next_edge_index, a->next_batch, a->next_N, a->next_E, a->next_B, a->next_graph_ptr, a->next_edge_ptr, a->next_status};
+  }
+  XchgArgs X{};
+  if (xchg) {
+    if (!adam || !a->peers_host || !a->loss || !a->xchg_err) return HCG_ERR_INVALID_ARG;
+    if (a->world < 1 || a->world > HCG_XCHG_MAX_WORLD || a->rank < 0 || a->rank >= a->world ||
+        (a->xchg_mode != HCG_XCHG_MEAN && a->xchg_mode != HCG_XCHG_SSE))
+      return HCG_ERR_INVALID_ARG;
+    X.inbox = (unsigned long long*)a->inbox;
+    for (int p = 0; p < a->world; ++p) {
+      if (!a->peers_host[p]) return HCG_ERR_INVALID_ARG;
+      X.peer[p] = (unsigned long long*)a->peers_host[p];
+    }
+    X.rank = a->rank; X.world = a->world; X.n_ext = a->n + 2; X.mode = a->xchg_mode; X.flat_ext = a->grad_flat; X.loss = a->loss;
+    X.err = a->xchg_err;
+  }
+  LossArgs L{};
+  HCG_TRY(loss_args_from_jobs(jobs_host, njobs, a->loss_count, a->loss_mode, a->loss, a->sse_tail, &L));
   Jobs jobs;
   jobs.njobs = njobs;
   int max_floats = 0;
@@ -211,7 +340,7 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
       if (!S.dst || S.row_in <= 0 || S.row_out <= 0 || S.row_out > S.row_in || S.count < 0) return HCG_ERR_INVALID_ARG;
       if (adam) {   // the update addresses param / moments by the gradient's offset: every dst must lie in the flat buffer
         const int64_t rows = (S.count + S.row_in - 1) / S.row_in;
-        if (S.dst < adam->grad_flat || S.dst + rows * S.row_out > adam->grad_flat + n_flat) return HCG_ERR_INVALID_ARG;
+        if (S.dst < a->grad_flat || S.dst + rows * S.row_out > a->grad_flat + a->n) return HCG_ERR_INVALID_ARG;
       }
     }
     jobs.job[j] = J;
@@ -220,42 +349,29 @@ static int launch_reduce(const hcg_reduce_job* jobs_host, int njobs, const AdamA
   for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
   // (plan row: one thread per node / edge as k_ptrs runs it -- fewer, looping blocks serialise its dependent loads: +3 us)
   unsigned gx = (max_floats + RO - 1) / RO;
-  if (plan) { const unsigned px = (unsigned)hcg_cdiv(plan->N + plan->E + 2, 256); if (px > gx) gx = px; }
+  if (plan) { const unsigned px = (unsigned)hcg_cdiv(P.N + P.E + 2, 256); if (px > gx) gx = px; }
   const dim3 grid(gx, njobs + (plan ? 1 : 0));
-  if (xchg && adam && plan) hipLaunchKernelGGL((k_reduce_jobs<true, true, true>), grid, dim3(256), 0, stream, jobs, *adam, *plan, *xchg);
-  else if (xchg && adam) hipLaunchKernelGGL((k_reduce_jobs<true, false, true>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{}, *xchg);
-  else if (plan && adam) hipLaunchKernelGGL((k_reduce_jobs<true, true, false>), grid, dim3(256), 0, stream, jobs, *adam, *plan, XchgArgs{});
-  else if (adam) hipLaunchKernelGGL((k_reduce_jobs<true, false, false>), grid, dim3(256), 0, stream, jobs, *adam, PlanArgs{}, XchgArgs{});
-  else hipLaunchKernelGGL((k_reduce_jobs<false, false, false>), grid, dim3(256), 0, stream, jobs, AdamArgs{}, PlanArgs{}, XchgArgs{});
+  if (xchg) {
+    int polling = 0;
+    for (int j = 0; j < njobs; ++j) polling += (jobs.job[j].slab_floats + RO - 1) / RO;
+    if (polling > hcg_xchg_resident_blocks()) return HCG_ERR_UNSUPPORTED;
+  }
+  if (xchg) hipLaunchKernelGGL((k_step_tail<true, true>), grid, dim3(256), 0, stream, jobs, A, P, L, X);
+  else if (adam) hipLaunchKernelGGL((k_step_tail<true, false>), grid, dim3(256), 0, stream, jobs, A, P, L, XchgArgs{});
+  else hipLaunchKernelGGL((k_step_tail<false, false>), grid, dim3(256), 0, stream, jobs, A, P, L, XchgArgs{});
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
 
-extern "C" int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream) {
-  return launch_reduce(jobs_host, njobs, nullptr, 0, (hipStream_t)stream);
-}
-
-extern "C" int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
-                                     float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
-                                     float beta2, float eps, const int32_t* step_dev, hcg_stream_t stream) {
-  if (n <= 0 || !grad_flat || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
-  AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
-  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream);
-}
-
-// hcg_reduce_slabs_adam + the pointers-only plan (HCG_PLAN_BLOCKED | HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS) of the NEXT
-// batch in the same launch
-extern "C" int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
-                                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
-                                          float beta2, float eps, const int32_t* step_dev, const int64_t* next_edge_index,
-                                          const int64_t* next_batch, int64_t N, int64_t E, int64_t B, int32_t* next_graph_ptr,
-                                          int32_t* next_edge_ptr, int32_t* next_status, hcg_stream_t stream) {
-  if (n <= 0 || !grad_flat || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return HCG_ERR_INVALID_ARG;
-  if (N < 0 || E < 0 || B < 0 || !next_batch || !next_graph_ptr || !next_edge_ptr || !next_status || (E > 0 && !next_edge_index))
-    return HCG_ERR_INVALID_ARG;
-  AdamArgs a{grad_flat, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
-  PlanArgs pl{next_edge_index, next_batch, N, E, B, next_graph_ptr, next_edge_ptr, next_status};
-  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, &pl);
+extern "C" int hcg_loss_finalize(const hcg_reduce_job* head_job_host, float count, int mode, float* loss, float* sse_tail,
+                                 hcg_stream_t stream) {
+  if (!head_job_host || !loss) return HCG_ERR_INVALID_ARG;
+  LossArgs L{};
+  HCG_TRY(loss_args_from_jobs(head_job_host, 1, count, mode, loss, sse_tail, &L));
+  if (!L.sse_part) return HCG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, L);
+  HCG_CHECK_LAUNCH();
+  return HCG_OK;
 }
 
 // ---- one-shot gradient exchange over xGMI (data parallel): buffers + the fused launch ------------------------------
@@ -294,35 +410,6 @@ extern "C" int hcg_xchg_ipc_open(const void* handle64, void** ptr) {
   return hcg_hip_err(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
 }
 extern "C" int hcg_xchg_ipc_close(void* ptr) { return ptr ? hcg_hip_err(hipIpcCloseMemHandle(ptr)) : HCG_OK; }
-
-extern "C" int hcg_reduce_slabs_xchg_adam(const hcg_reduce_job* jobs_host, int njobs, float* flat_ext, float* param_flat,
-                                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1,
-                                          float beta2, float eps, const int32_t* step_dev, void* inbox, void* const* peers,
-                                          int rank, int world, int mode, float* loss, int32_t* err,
-                                          const int64_t* next_edge_index, const int64_t* next_batch, int64_t N, int64_t E,
-                                          int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr, int32_t* next_status,
-                                          hcg_stream_t stream) {
-  if (n <= 0 || !flat_ext || !param_flat || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || !inbox || !peers || !loss || !err)
-    return HCG_ERR_INVALID_ARG;
-  if (world < 1 || world > HCG_XCHG_MAX_WORLD || rank < 0 || rank >= world || (mode != HCG_XCHG_MEAN && mode != HCG_XCHG_SSE))
-    return HCG_ERR_INVALID_ARG;
-  AdamArgs a{flat_ext, param_flat, exp_avg, exp_avg_sq, lr_dev, (const int*)step_dev, beta1, beta2, eps};
-  XchgArgs x{};
-  x.inbox = (unsigned long long*)inbox;
-  for (int p = 0; p < world; ++p) {
-    if (!peers[p]) return HCG_ERR_INVALID_ARG;
-    x.peer[p] = (unsigned long long*)peers[p];
-  }
-  x.rank = rank; x.world = world; x.n_ext = n + 2; x.mode = mode; x.flat_ext = flat_ext; x.loss = loss; x.err = err;
-  if (next_batch) {
-    if (N < 0 || E < 0 || B < 0 || !next_graph_ptr || !next_edge_ptr || !next_status || (E > 0 && !next_edge_index)) return HCG_ERR_INVALID_ARG;
-    PlanArgs pl{next_edge_index, next_batch, N, E, B, next_graph_ptr, next_edge_ptr, next_status};
-    return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, &pl, &x);
-  }
-  return launch_reduce(jobs_host, njobs, &a, n, (hipStream_t)stream, nullptr, &x);
-}
-
-extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }
 
 // Two backward launches of ONE layer over two groups of graphs (size-grouped batches: small-graph tiles + one graph per
 // wave) leave their slabs back to back in one workspace: `more` is appended to `job` -- same slab geometry, same

@@ -1115,7 +1115,7 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
 
 // dout == NULL selects the pooled form (upstream gradient = demb [B, 2D], expanded on chip with `emb` and `out`).
 // apply_act: bit 0 = multiply the upstream gradient by leaky'(out); bit 1 = hand dx down already multiplied by leaky'(x).
-// Leaves dW / db slabs in `workspace`: describe them with hcg_tall_reduce_jobs (two jobs) and sum with hcg_reduce_slabs.
+// Leaves dW / db slabs in `workspace`: describe them with hcg_tall_reduce_jobs (two jobs) and sum with hcg_step_tail.
 extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
                                   const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                   const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
@@ -1240,14 +1240,14 @@ extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_byte
   j->nslabs = dw_grid(N, D);
   j->slab_floats = (int32_t)(D * fp);
   j->nseg = 1;
-  j->reserved = 0;
+  j->sse_index = 0;
   j->seg[0] = hcg_reduce_seg{0, (int32_t)(D * fp), fp, (int32_t)F, dW};
   j = job_host + 1;
   j->slabs = ws.db_slabs;
   j->nslabs = seg_grid64(B);
   j->slab_floats = (int32_t)D;
   j->nseg = 1;
-  j->reserved = 0;
+  j->sse_index = 0;
   j->seg[0] = hcg_reduce_seg{0, (int32_t)D, 1, 1, db};
   return HCG_OK;
 }

@@ -8,6 +8,8 @@ readout Linear(+LeakyReLU) stack (model/gcn.py:70-71) and `loss.backward()` thro
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -198,10 +200,9 @@ class _FusedLayerFn(torch.autograd.Function):
         dev = x.device
         out = torch.empty(N, D, dtype=torch.float32, device=dev)
         emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
-        rc = lib.hcg_fused_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
-                                     _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, gpt, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), _lib.ptr(plan.status),
-                                     _lib.stream_ptr())
-        _lib.check(rc, "hcg_fused_layer_fwd")
+        _lib.fused_forward(x=x, W1=weight, b1=bias, edge_index=plan.edge_index, E=plan.E, graph_ptr=plan.graph_ptr,
+                           edge_ptr=plan.edge_ptr, N=N, B=plan.B, F=F, D=D, graphs_per_tile=gpt, apply_act=int(apply_act),
+                           slope=slope, out1=out, emb=emb, status=plan.status)
         ctx.plan, ctx.gpt, ctx.apply_act, ctx.slope, ctx.pool = plan, gpt, apply_act, slope, pool
         if pool:
             ctx.save_for_backward(x, weight, out, emb)
@@ -227,14 +228,15 @@ class _FusedLayerFn(torch.autograd.Function):
         db = torch.empty(D, dtype=torch.float32, device=dev)
         wsb = lib.hcg_fused_workspace_bytes(plan.B, F, D, ctx.gpt)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        rc = lib.hcg_fused_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), _lib.ptr(x),
+        rc = lib.hcg_fused_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), None, _lib.ptr(x),
                                      _lib.ptr(weight), _lib.ptr(plan.edge_index), plan.E,
                                      _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, ctx.gpt, ctx.slope,
                                      int(ctx.apply_act), _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "hcg_fused_layer_bwd")
-        rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, plan.B, F, D, ctx.gpt, _lib.ptr(dW), _lib.ptr(db),
-                                        _lib.stream_ptr())
-        _lib.check(rc, "hcg_fused_reduce_grads")
+        job = _lib.ReduceJob()
+        _lib.check(lib.hcg_fused_reduce_job(_lib.ptr(ws), wsb, N, plan.B, F, D, ctx.gpt, _lib.ptr(dW), _lib.ptr(db),
+                                            ctypes.addressof(job)), "hcg_fused_reduce_job")
+        _lib.reduce_jobs(ctypes.addressof(job), 1)
         return dx, dW, db, None, None, None, None, None
 
 
@@ -296,7 +298,7 @@ class _MidLayerFn(torch.autograd.Function):
         for half in range(halves):
             _lib.check(lib.hcg_mid_reduce_job(_lib.ptr(ws), wsb, plan.B, F, D, plan.max_nodes, plan.max_edges, half,
                                               _lib.ptr(dW), _lib.ptr(db), ctypes.addressof(jobs) + half * jb), "hcg_mid_reduce_job")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), halves, stream), "hcg_reduce_slabs")
+        _lib.reduce_jobs(ctypes.addressof(jobs), halves)
         return dx, dW, db, None, None, None, None
 
 
@@ -372,7 +374,7 @@ class _TallLayerFn(torch.autograd.Function):
         jobs = ctypes.create_string_buffer(jb * 2)
         _lib.check(lib.hcg_tall_reduce_jobs(_lib.ptr(ws), wsb, N, plan.B, F, D, _lib.ptr(dW), _lib.ptr(db),
                                             ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), 2, stream), "hcg_reduce_slabs")
+        _lib.reduce_jobs(ctypes.addressof(jobs), 2)
         return dx, dW, db, None, None, None, None
 
 
@@ -501,21 +503,17 @@ class _FusedModelFn(torch.autograd.Function):
             # the reference's default depth: both conv layers in ONE launch (csrc/fused.hip, STACK2)
             a1 = torch.empty(N, D, dtype=torch.float32, device=dev)
             a2 = torch.empty(N, D, dtype=torch.float32, device=dev)
-            rc = lib.hcg_fused_stack2_fwd(_lib.ptr(x), _lib.ptr(convs[0]), _lib.ptr(convs[1]), _lib.ptr(convs[2]),
-                                          _lib.ptr(convs[3]), _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr),
-                                          _lib.ptr(plan.edge_ptr), N, plan.B, x.shape[1], D, gpts[0], slope, 1, _lib.ptr(a1),
-                                          _lib.ptr(a2), _lib.ptr(emb), _lib.ptr(plan.status), stream)
-            _lib.check(rc, "hcg_fused_stack2_fwd")
+            _lib.fused_forward(x=x, W1=convs[0], b1=convs[1], W2=convs[2], b2=convs[3], edge_index=plan.edge_index, E=plan.E,
+                               graph_ptr=plan.graph_ptr, edge_ptr=plan.edge_ptr, N=N, B=plan.B, F=x.shape[1], D=D,
+                               graphs_per_tile=gpts[0], apply_act=1, slope=slope, out1=a1, out2=a2, emb=emb, status=plan.status)
             acts = [a1, a2]
         else:
             for l in range(n_conv):
                 W, b = convs[2 * l], convs[2 * l + 1]
                 out = torch.empty(N, D, dtype=torch.float32, device=dev)
-                rc = lib.hcg_fused_layer_fwd(_lib.ptr(h), _lib.ptr(W), _lib.ptr(b), _lib.ptr(plan.edge_index), plan.E,
-                                             _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, h.shape[1], D,
-                                             gpts[l], slope, 1, _lib.ptr(out), _lib.ptr(emb) if l == n_conv - 1 else None,
-                                             _lib.ptr(plan.status), stream)
-                _lib.check(rc, "hcg_fused_layer_fwd")
+                _lib.fused_forward(x=h, W1=W, b1=b, edge_index=plan.edge_index, E=plan.E, graph_ptr=plan.graph_ptr,
+                                   edge_ptr=plan.edge_ptr, N=N, B=plan.B, F=h.shape[1], D=D, graphs_per_tile=gpts[l], apply_act=1,
+                                   slope=slope, out1=out, emb=emb if l == n_conv - 1 else None, status=plan.status)
                 acts.append(out)
                 h = out
         C = R1w.shape[0]
@@ -598,7 +596,7 @@ class _FusedModelFn(torch.autograd.Function):
             keep.append(ws)
             last = l == n_conv - 1
             rc = lib.hcg_fused_layer_bwd(None if last else _lib.ptr(dh), _lib.ptr(demb) if last else None,
-                                         _lib.ptr(emb) if last else None, _lib.ptr(acts[l]), _lib.ptr(inp), _lib.ptr(W),
+                                         _lib.ptr(emb) if last else None, _lib.ptr(acts[l]), None, _lib.ptr(inp), _lib.ptr(W),
                                          _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr),
                                          N, B, F, D, gpts[l], slope, 1, _lib.ptr(dx), _lib.ptr(plan.status), _lib.ptr(ws), wsb,
                                          stream)
@@ -608,12 +606,14 @@ class _FusedModelFn(torch.autograd.Function):
                                                     jaddr + njobs * jb), "hcg_fused_reduce_job")
                 njobs += 1
             else:
-                rc = lib.hcg_fused_reduce_grads(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db), stream)
-                _lib.check(rc, "hcg_fused_reduce_grads")
+                job = _lib.ReduceJob()
+                _lib.check(lib.hcg_fused_reduce_job(_lib.ptr(ws), wsb, N, B, F, D, gpts[l], _lib.ptr(dW), _lib.ptr(db),
+                                                    ctypes.addressof(job)), "hcg_fused_reduce_job")
+                _lib.reduce_jobs(ctypes.addressof(job), 1)
             grads[2 * l], grads[2 * l + 1] = dW, db
             dh = dx
         if batched:
-            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
+            _lib.reduce_jobs(jaddr, njobs)
         return (None, None, None, dh if ctx.needs_input_grad[3] else None, *grads, dR0w, dR0b, dR1w, dR1b)
 
 

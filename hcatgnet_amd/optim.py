@@ -109,8 +109,8 @@ class FusedAdam(torch.optim.Optimizer):
         return self._flat[gi]
 
     def fused_update_ready(self, flat_grad: torch.Tensor):
-        """Device word the head kernel must advance (hcg_head_fwd_bwd `step_counter`) if the NEXT update can be fused
-        into the slab reduction (`step_with_reduction`), else None -- nothing is launched or changed here."""
+        """Device word the head must advance (`step_counter` of hcg_head_fwd_bwd / hcg_fused_forward) if the NEXT update can be
+        fused into the step's last launch (`step_with_reduction`), else None -- nothing is launched or changed here."""
         if not self.capturable or len(self.param_groups) != 1:
             return None
         group = self.param_groups[0]
@@ -131,13 +131,15 @@ class FusedAdam(torch.optim.Optimizer):
         return fl["step_dev"]
 
     def step_with_reduction(self, jobs_addr: int, njobs: int, flat_grad: torch.Tensor, next_plan=None, exchange=None,
-                            flat_ext=None, mode: str = "mean", loss_buf=None) -> bool:
-        """The backward's slab reduction and this optimiser's update as ONE launch (hcg_reduce_slabs_adam): `jobs_addr`
-        = host address of the hcg_reduce_job array whose segments write `flat_grad` (the buffer the parameters'
-        `.grad` are views of, in parameter order).  The step word returned by `fused_update_ready` must have been
-        advanced earlier in this step (the head kernel does).  Returns False -- nothing launched -- when the
-        preconditions do not hold; the caller then issues the two launches.  `next_plan` (a pointers-only blocked
-        `BatchPlan` of the NEXT batch): its graph_ptr / edge_ptr are re-derived by the same launch."""
+                            flat_ext=None, mode: str = "mean", loss_buf=None, loss_mode: int = _lib.HCG_LOSS_RMSE,
+                            loss_count: float = 0.0) -> bool:
+        """The step's last launch (hcg_step_tail): the backward's slab reductions, the loss with its deferred scale
+        (`loss_mode`, `loss_count` = B * C; used when a job carries the head's SSE partials), this optimiser's update, and
+        optionally the data-parallel exchange and the NEXT batch's plan.  `jobs_addr` = host address of the hcg_reduce_job
+        array whose segments write `flat_grad` (the buffer the parameters' `.grad` are views of, in parameter order).  The
+        step word returned by `fused_update_ready` must have been advanced earlier in this step (the head does).  Returns
+        False -- nothing launched -- when the preconditions do not hold; the caller then issues reduction and update
+        separately.  `next_plan`: a pointers-only blocked `BatchPlan`."""
         ready, self._ready = getattr(self, "_ready", None), None
         if (ready is not None and ready[0] == flat_grad.data_ptr() and self._flat.get(0) is ready[1]
                 and self.capturable and len(self.param_groups) == 1):
@@ -165,7 +167,6 @@ class FusedAdam(torch.optim.Optimizer):
         if fl["lr_host"] != lr:
             fl["lr_host"] = lr
             fl["lr_dev"].fill_(lr)
-        lib = _lib.load()
         if next_plan is not None:
             np_ = next_plan
             if np_.mode != "blocked" or np_.has_csr or not np_.shared_status:
@@ -173,18 +174,13 @@ class FusedAdam(torch.optim.Optimizer):
         if exchange is not None:      # data parallel: the one-shot xGMI exchange sits between the reduction and the update
             if flat_ext is None or flat_ext.data_ptr() != flat_grad.data_ptr() or flat_ext.numel() != fl["n"] + 2 or loss_buf is None:
                 raise _lib.HcgError("one-shot exchange: needs the extended flat buffer [gradients | SSE | count] and the loss buffer")
-            exchange.launch(jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan)
+            exchange.launch(jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan, loss_count=loss_count,
+                            loss_mode=loss_mode)
             return True
-        if next_plan is not None:
-            _lib.check(lib.hcg_reduce_slabs_adam_plan(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
-                                                      fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
-                                                      fl["step_dev"].data_ptr(), np_.edge_index.data_ptr(), np_.batch.data_ptr(),
-                                                      np_.N, np_.E, np_.B, np_.graph_ptr.data_ptr(), np_.edge_ptr.data_ptr(),
-                                                      np_.status.data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam_plan")
-            return True
-        _lib.check(lib.hcg_reduce_slabs_adam(jobs_addr, njobs, flat_grad.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(),
-                                             fl["v"].data_ptr(), fl["n"], fl["lr_dev"].data_ptr(), b1, b2, eps,
-                                             fl["step_dev"].data_ptr(), _lib.stream_ptr()), "hcg_reduce_slabs_adam")
+        _lib.step_tail(jobs_addr, njobs, loss=loss_buf, loss_mode=loss_mode, loss_count=loss_count,
+                       adam=dict(grad_flat=flat_grad, param=fl["p"], exp_avg=fl["m"], exp_avg_sq=fl["v"], n=fl["n"],
+                                 lr_dev=fl["lr_dev"], step_dev=fl["step_dev"], beta1=b1, beta2=b2, eps=eps),
+                       next_plan=next_plan)
         return True
 
     def step_sse(self, flat_ext: torch.Tensor, loss_buf: torch.Tensor):

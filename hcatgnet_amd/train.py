@@ -6,14 +6,14 @@ values; what changes is how a step is issued:
   reference step (utils/utils_model.py:60-68)          here (`FusedTrainStep`)
   -------------------------------------------          ---------------------------------------------------
   optimizer.zero_grad()                                 -- (every gradient is overwritten, never accumulated)
-  out = model(batch)                                    hcg_fused_stack2_fwd / hcg_mid_layer_fwd x n_conv   (+ plan: 1)
-  loss = sqrt(MSELoss(out, y.unsqueeze(1)))             hcg_head_fwd_bwd                1 launch: readout fwd,
-  loss.backward()                                           loss, readout bwd (grid barrier inside)
-                                                        hcg_fused_layer_bwd / hcg_mid_layer_bwd x n_conv
-                                                        hcg_reduce_slabs                1 launch -> ONE flat gradient
-  [data parallel]                                       RCCL all-reduce of that buffer, in place
-  optimizer.step()                                      hcg_adam_step(_dev)             1 launch
-  loss.item()                                           -- (the loss stays on the device; ONE sync per epoch)
+  out = model(batch)                                    hcg_fused_forward               1 launch: both conv layers, pooling AND
+  loss = sqrt(MSELoss(out, y.unsqueeze(1)))                 the readout head (forward, squared error, unscaled backward)
+  loss.backward()                                       hcg_fused_layer_bwd x n_conv    (other graph sizes: hcg_mid_* / hcg_tall_*
+                                                            per layer + hcg_head_fwd_bwd)
+  [data parallel]                                       [one-shot xGMI exchange inside the last launch, or an RCCL all-reduce]
+  optimizer.step()                                      hcg_step_tail                   1 launch: slab reductions -> ONE flat
+  loss.item()                                               gradient, loss + its deferred scale, Adam, the next batch's plan
+                                                        -- (the loss stays on the device; ONE sync per epoch)
 
 No autograd graph is built: the step is a fixed sequence of C-ABI calls, which is also what makes it capturable
 into a hipGraph (`FusedTrainStep.capture`).  Graphs up to 32 nodes run through the small-graph tiles (csrc/fused.hip),
@@ -32,8 +32,16 @@ import torch.distributed
 from . import _lib
 from . import functional as HF
 
+class _Ctx:
+    """Everything one step needs, resolved once: shapes, weights, buffers, the kernel family of every layer."""
+    __slots__ = ("batch", "plan", "x", "y2", "convs", "l0", "l1", "N", "F", "B", "D", "C", "n_conv", "dev", "W", "bs",
+                 "gpts", "tall", "bufs", "n_small", "head_fused", "forward_only", "flat", "gaddr", "step_word",
+                 "jobs", "jaddr", "jb", "njobs", "loss_mode", "sse_split", "poolbits")
+
+
 class FusedTrainStep:
-    """One training step of the reference's loop as 6 enqueued launches (small-graph tiles; n_conv + 4 in general), no autograd, no host sync.
+    """One training step of the reference's loop as FOUR enqueued launches on small-graph tiles (conv stack + pooling +
+    readout head, two conv backward launches, the step tail), n_conv + 4 in general -- no autograd, no host sync.
 
         step = FusedTrainStep(model)            # model: hcatgnet_amd.GCN on the GPU
         loss = step(batch)                      # 0-d device tensor: sqrt(MSE) of this batch, weights already updated
@@ -42,21 +50,24 @@ class FusedTrainStep:
     (gradients in `model.parameters()[i].grad`, views of one flat buffer); `grad_sync` is called with the flat gradient
     between backward and optimiser (data parallel: `DataParallelGCN.attach(step)` sets it).
 
-    `combine` (data parallel, needs rmse): "mean" = every rank's own sqrt(MSE), gradients averaged (DDP convention);
-    "sse" = the head leaves the gradients of SSE / 2 plus [SSE, count] behind the flat buffer, `grad_sync` SUMS all of it
-    over the ranks and ONE scale 1 / (count * sqrt(SSE / count)) gives the gradient of sqrt(MSE) over the concatenated
-    batch of all ranks -- what the reference's step computes on one device (utils/utils_model.py:64-65); the loss returned
-    is then that global loss.
+    The loss scale is DEFERRED: the backward is linear in dloss/dout = scale * (out - y), so the head and every conv
+    backward launch run on the unscaled error, the head leaves one partial sum of squared errors per workgroup, and the
+    step's last launch (`hcg_step_tail`) derives loss and scale and applies the scale while it reduces the gradient slabs
+    -- there is no grid-wide exchange anywhere in the step (csrc/head_tile.h, csrc/reduce.hip).
 
-    Every instance owns its exchange words for the head kernel's grid-wide sum (`check_health()` reports a timed-out
-    exchange): two trainers may run on two streams at once.
+    `combine` (data parallel, needs rmse): "mean" = every rank's own sqrt(MSE), gradients averaged (DDP convention);
+    "sse" = gradients stay those of SSE / 2, [SSE, count] sit behind the flat buffer, `grad_sync` SUMS all of it over the
+    ranks and ONE scale 1 / (count * sqrt(SSE / count)) gives the gradient of sqrt(MSE) over the concatenated batch of all
+    ranks -- what the reference's step computes on one device (utils/utils_model.py:64-65); the loss returned is then that
+    global loss.
     """
 
     # development switches for A/B measurements (tools/ab_env.sh sets them from the environment; never set in product
     # code): POOLBITS = False stores the pooled layer's activations as the plain forms do, PREMASK = False leaves every
-    # activation derivative to the layer that owns it
+    # activation derivative to the layer that owns it, HEAD_IN_FORWARD = False keeps the head a launch of its own
     POOLBITS = True
     PREMASK = True
+    HEAD_IN_FORWARD = True
     OVERLAP_GROUPS = True          # captured size-grouped steps: the two kernel families as two branches of the hipGraph
 
     def __init__(self, model, rmse: bool = True, optimizer_step: bool = True, grad_sync=None, combine: str = "mean"):
@@ -70,17 +81,16 @@ class FusedTrainStep:
             model.optimizer.enable_capturable()     # step count / lr in device memory: same launches eager and captured
         self._bufs = {}
         self._graph = None
-        self._sync = {}
         self._capturing_split = False
         self._side_streams = {}
         # pipelined loaders: a pointers-only `BatchPlan` of the NEXT batch (built once with validate=False); the step's last
-        # launch (slab reduction + Adam) re-derives its graph_ptr / edge_ptr from the tensors' current contents, so the next
-        # step -- on a batch object that carries that plan (`batch._hcg_plan = plan`) -- starts without a plan launch
+        # launch re-derives its graph_ptr / edge_ptr from the tensors' current contents, so the next step -- on a batch object
+        # that carries that plan (`batch._hcg_plan = plan`) -- starts without a plan launch
         self.next_plan = None
-        # data parallel: a `xgmi.OneShotExchange` (set by its `attach`): the gradient exchange then happens INSIDE the slab
-        # reduction + Adam launch instead of as an RCCL collective between two launches
+        # data parallel: a `xgmi.OneShotExchange` (set by its `attach`): the gradient exchange then happens INSIDE the step's
+        # last launch instead of as an RCCL collective between two launches
         self.exchange = None
-        self._last_carried = False              # the last step's update launch carried reduction + (exchange) + Adam
+        self._last_carried = False              # the last step's tail launch carried reduction + (exchange) + Adam
         self.exchange_fallback_sync = None      # the collective hook `OneShotExchange.attach` took out of `grad_sync`
         # one-device rehearsals only (two ranks sharing a GPU): called right before the launch that carries the exchange.
         # A rank's polling launch fills every CU, and the OTHER process's conv kernels (488 of a SIMD's 512 VGPRs per
@@ -113,24 +123,6 @@ class FusedTrainStep:
     def reason(self, batch=None) -> Optional[str]:
         """`unsupported_reason(self.model, batch)` with the cached parameter list."""
         return self.unsupported_reason(self.model, batch, self._trainable())
-
-    def _sync_words(self, dev: torch.device) -> torch.Tensor:
-        """The HCG_HEAD_SYNC_WORDS exchange words of hcg_head_fwd_bwd: once-zeroed, owned by THIS trainer (launches that
-        share a set must be stream-ordered; a trainer issues its launches on one stream at a time)."""
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        t = self._sync.get(key)
-        if t is None:
-            t = self._sync[key] = torch.zeros(_lib.HCG_HEAD_SYNC_WORDS, dtype=torch.int32, device=dev)
-        return t
-
-    def check_health(self):
-        """Synchronising read of the head kernel's error word: raises if a grid-wide exchange timed out (the losses of
-        that step are NaN).  The words are re-zeroed so the trainer can be used again."""
-        for t in self._sync.values():
-            if int(t[1].item()) & _lib.HCG_HEAD_ERR_TIMEOUT:
-                t.zero_()
-                raise _lib.HcgError("hcg_head_fwd_bwd: the grid-wide exchange timed out (workgroups not co-resident, or "
-                                    "launches of two streams sharing one set of sync words); losses of that step are NaN")
 
     # ------------------------------------------------------------------ support check (host only)
     @staticmethod
@@ -168,161 +160,7 @@ class FusedTrainStep:
             st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
         return st
 
-    # ------------------------------------------------------------------ size-grouped batches: two kernel families per layer
-    def _size_groups(self, batch, plan, convs, D, C, n_conv):
-        """-> n_small when the batch is size-grouped (`collate(..., group_by_size=True)`: the first n_small graphs have <= 32
-        nodes, the others 33 .. 64) and both groups are non-empty: the small graphs then run in the small-graph tiles, the
-        larger ones one graph per wave, instead of everything on the slower family."""
-        ns = getattr(batch, "n_small", None)
-        lib = _lib.load()
-        if (ns is None or not (0 < ns < plan.B) or n_conv != 2 or D != 64 or not lib.hcg_head_supported(D, C)
-                or plan.max_nodes is None or plan.max_nodes <= 32 or plan.max_edges is None):
-            return None
-        for c in convs:
-            if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, 32) <= 0:
-                return None
-            if not HF.mid_supported(plan, c.in_channels, c.out_channels):
-                return None
-        return int(ns)
-
-    def _routed_step(self, batch, plan, bufs, x, y2, convs, l0, l1, n_small, _forward_only):
-        """The step of `__call__` for a size-grouped batch: graphs [0, n_small) through csrc/fused.hip (one graph per
-        32-row tile), graphs [n_small, B) through the hcg_mid_* entry points (one graph per wave, csrc/wave.hip) -- every
-        launch gets the sub-range of graph_ptr / edge_ptr / emb / demb it owns; node rows are absolute, so x, the
-        activations and dx need no offsets.  Both groups' slabs of a layer sit back to back and are ONE reduction job."""
-        lib, model = _lib.load(), self.model
-        p = _lib.ptr
-        N, F, B, D, C = x.shape[0], x.shape[1], plan.B, model.embedding_dim, model._n_classes
-        dev, stream, slope = x.device, _lib.stream_ptr(), HF.LEAKY_SLOPE
-        mxn, mxe = plan.max_nodes, plan.max_edges
-        Bs, Bb = n_small, B - n_small
-        # The two groups' launches touch disjoint rows, graphs and slabs.  While the step is being CAPTURED the larger graphs'
-        # launches go to a second stream, forked before each conv phase and joined behind it = two branches of the hipGraph:
-        # each family's last workgroups fill the CUs the other has already left (neither fills the chip: ~1.4 tiles per wave /
-        # ~0.6 graphs per wave slot at 4096 graphs).  Measured on the ragged bench: replay 0.1975 -> 0.188 ms/step; the eager
-        # step is host-bound and the four extra event calls cost it 0.196 -> 0.215, so eager steps stay on one stream.
-        main_s = torch.cuda.current_stream(dev)
-        side_s = self._side_stream(dev) if (self.OVERLAP_GROUPS and torch.cuda.is_current_stream_capturing()) else None
-        stream_b = ctypes.c_void_p(side_s.cuda_stream) if side_s is not None else stream
-
-        def fork():
-            if side_s is not None:
-                side_s.wait_stream(main_s)
-
-        def join():
-            if side_s is not None:
-                main_s.wait_stream(side_s)
-        gp, ep = plan.graph_ptr, plan.edge_ptr
-        gp_b, ep_b = gp.data_ptr() + 4 * Bs, ep.data_ptr() + 4 * Bs
-        acts, emb, demb = bufs["acts"], bufs["emb"], bufs["demb"]
-        emb_b, demb_b = emb.data_ptr() + 4 * 2 * D * Bs, demb.data_ptr() + 4 * 2 * D * Bs
-        W = [HF._f32c(c.lin.weight) for c in convs]
-        bs = [HF._f32c(c.bias) for c in convs]
-        gpt = int(lib.hcg_fused_graphs_per_tile(F, D, 32))
-        # ---- forward: tiles (both layers + pooling in one launch, pooled layer kept on chip as 2 bits / element), then waves
-        nb = lib.hcg_fused_poolbits_bytes(Bs, gpt)
-        poolbits = bufs["ws"].get("poolbits_r")
-        if poolbits is None or poolbits.numel() < nb:
-            poolbits = bufs["ws"]["poolbits_r"] = torch.empty(int(nb * 1.25), dtype=torch.uint8, device=dev)
-        fork()
-        _lib.check(lib.hcg_fused_stack2_fwd_train(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, p(gp), p(ep),
-                                                  N, Bs, F, D, gpt, slope, 1, p(acts[0]), p(emb), p(poolbits), p(plan.status), stream),
-                   "hcg_fused_stack2_fwd_train")
-        _lib.check(lib.hcg_mid_layer_fwd(p(x), p(W[0]), p(bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, F, D, mxn, mxe,
-                                         slope, 1, p(acts[0]), None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
-        _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, D, D, mxn, mxe,
-                                         slope, 1, p(acts[1]), emb_b, p(plan.status), stream_b), "hcg_mid_layer_fwd")
-        join()
-        # ---- head over all graphs
-        opt = model.optimizer
-        step_word, flat, g = None, None, None
-        if not _forward_only:
-            params = self._trainable()
-            flat = self._flat_grads(params, dev)
-            # address of every parameter's slice of the flat gradient buffer (cached per buffer: eight tensor slices per
-            # step otherwise)
-            ga = getattr(self, "_gaddr", None)
-            if ga is None or ga[0] != flat.data_ptr() or ga[1] is not params:
-                addr, off = {}, 0
-                for q in params:
-                    addr[id(q)] = flat.data_ptr() + 4 * off
-                    off += q.numel()
-                ga = self._gaddr = (flat.data_ptr(), params, addr)
-            g = (lambda prm, _a=ga[2]: _a[id(prm)])
-            if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
-                    and (self.combine == "mean" or self.exchange is not None) and hasattr(opt, "fused_update_ready")):
-                step_word = opt.fused_update_ready(flat)
-        sse = self.combine == "sse" and not _forward_only
-        mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
-        tail = self._flat_ext[flat.numel():] if sse else None
-        _lib.check(lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(HF._f32c(l0.weight)), p(HF._f32c(l0.bias)), p(HF._f32c(l1.weight)),
-                                           p(HF._f32c(l1.bias)), B, D, C, slope, mode, p(bufs["z"]), p(bufs["out"]), p(bufs["loss"]),
-                                           p(demb), p(bufs["ws_head"]), bufs["ws_head_bytes"], p(self._sync_words(dev)),
-                                           p(step_word), p(tail), stream), "hcg_head_fwd_bwd_ex")
-        self.last_out = bufs["out"]
-        if _forward_only:
-            return bufs["loss"][0]
-        jb = lib.hcg_reduce_job_bytes()
-        jobs = ctypes.create_string_buffer(jb * 8)
-        tmp = ctypes.create_string_buffer(jb)
-        jaddr, taddr = ctypes.addressof(jobs), ctypes.addressof(tmp)
-        _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, C, g(l0.weight), g(l0.bias),
-                                           g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job")
-        njobs = 1
-        # ---- conv stack backward, last layer first; each layer: tiles on the small graphs, waves on the others
-        premask = bool(self.PREMASK)
-        dx = bufs["dacts"][0]
-        fork()
-        for l in (1, 0):
-            inp = x if l == 0 else acts[0]
-            Fl = inp.shape[1]
-            ws_a = lib.hcg_fused_workspace_bytes(Bs, Fl, D, gpt)
-            ws_b = lib.hcg_mid_workspace_bytes(Bb, Fl, D, mxn, mxe)
-            off_b = ws_a - 256                                  # = the tile launch's slabs, exactly (the query pads by 256)
-            ws = bufs["ws"].get(("r", l))
-            if ws is None or ws.numel() < off_b + ws_b:
-                ws = bufs["ws"][("r", l)] = torch.empty(int((off_b + ws_b) * 1.25), dtype=torch.uint8, device=dev)
-            wsb_ptr = ws.data_ptr() + off_b
-            if l == 1:
-                flags = 1 | (2 if premask else 0)
-                _lib.check(lib.hcg_fused_layer_bwd_poolbits(p(demb), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E, p(gp),
-                                                            p(ep), N, Bs, Fl, D, gpt, slope, flags, p(dx), p(plan.status), p(ws),
-                                                            off_b, stream), "hcg_fused_layer_bwd_poolbits")
-                _lib.check(lib.hcg_mid_layer_bwd(None, demb_b, emb_b, p(acts[1]), p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b,
-                                                 ep_b, N, Bb, Fl, D, mxn, mxe, slope, flags, p(dx), p(plan.status), wsb_ptr, ws_b,
-                                                 stream_b), "hcg_mid_layer_bwd")
-            else:
-                act = 0 if premask else 1
-                a_out = p(acts[0]) if act else None
-                _lib.check(lib.hcg_fused_layer_bwd(p(dx), None, None, a_out, p(inp), p(W[l]), p(plan.edge_index), plan.E, p(gp), p(ep),
-                                                   N, Bs, Fl, D, gpt, slope, act, None, p(plan.status), p(ws), off_b, stream),
-                           "hcg_fused_layer_bwd")
-                _lib.check(lib.hcg_mid_layer_bwd(p(dx), None, None, a_out, p(inp), p(W[l]), p(plan.edge_index), plan.E, gp_b, ep_b, N,
-                                                 Bb, Fl, D, mxn, mxe, slope, act, None, p(plan.status), wsb_ptr, ws_b, stream_b),
-                           "hcg_mid_layer_bwd")
-            _lib.check(lib.hcg_fused_reduce_job(p(ws), off_b, N, Bs, Fl, D, gpt, g(convs[l].lin.weight), g(convs[l].bias),
-                                                jaddr + njobs * jb), "hcg_fused_reduce_job")
-            _lib.check(lib.hcg_mid_reduce_job(wsb_ptr, ws_b, Bb, Fl, D, mxn, mxe, 0, g(convs[l].lin.weight), g(convs[l].bias), taddr),
-                       "hcg_mid_reduce_job")
-            _lib.check(lib.hcg_reduce_job_append(jaddr + njobs * jb, taddr), "hcg_reduce_job_append")
-            njobs += 1
-        join()
-        self._last_carried = step_word is not None
-        if step_word is not None:
-            if self.exchange is not None and self.pre_exchange_hook is not None:
-                self.pre_exchange_hook()
-            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
-                                           flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):
-                raise _lib.HcgError("optimizer state changed between head launch and update")
-        else:
-            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
-            if self.next_plan is not None:
-                self.next_plan.rebuild()                   # (no fused update to ride in: its own launch)
-            if not self._capturing_split:
-                self._exchange_and_update(bufs["loss"])
-        return bufs["loss"][0]
-
-    # ------------------------------------------------------------------ the step
+    # ------------------------------------------------------------------ buffers
     def _buffers(self, key, N, B, F, D, C, n_conv, dev):
         """Step buffers: allocated for the largest (N, B) seen so far and handed out as views -- the variable-size
         batches of a shuffled epoch then reuse one allocation instead of ~12 `torch.empty` per step."""
@@ -333,12 +171,15 @@ class FusedTrainStep:
             capN = max(N, int(cap["N"] * 1.25) if cap and cap["sig"] == sig else 0)
             capB = max(B, cap["B"] if cap and cap["sig"] == sig else 0)
             f32 = dict(dtype=torch.float32, device=dev)
-            hb = lib.hcg_head_workspace_bytes_d(capB, D if lib.hcg_head_supported(D, C) else 64)
+            # head slabs: the stand-alone head's (<= one per CU) or the forward tail's (one per workgroup of the tile launch:
+            # graphs_per_tile 1 bounds it)
+            hb = max(lib.hcg_head_workspace_bytes(capB, D if lib.hcg_head_supported(D, C) else 64),
+                     lib.hcg_fused_head_workspace_bytes(capB, 1))
             cap = {"sig": sig, "N": capN, "B": capB,
                    "acts": [torch.empty(capN, D, **f32) for _ in range(n_conv)],
                    "dacts": [torch.empty(capN, D, **f32) for _ in range(n_conv - 1)],
                    "emb": torch.empty(capB, 2 * D, **f32), "demb": torch.empty(capB, 2 * D, **f32),
-                   "z": torch.empty(capB, D, **f32), "out": torch.empty(capB, C, **f32), "loss": torch.empty(2, **f32),
+                   "z": torch.empty(capB, D, **f32), "out": torch.empty(capB, C, **f32), "loss": torch.zeros(2, **f32),
                    "ws_head": torch.empty(hb, dtype=torch.uint8, device=dev), "ws": {}}
             self._bufs = {"cap": cap}
             self._graph = None                          # a captured graph holds the old buffers' addresses
@@ -346,7 +187,7 @@ class FusedTrainStep:
         if b is None:
             b = {"acts": [t[:N] for t in cap["acts"]], "dacts": [t[:N] for t in cap["dacts"]], "emb": cap["emb"][:B],
                  "demb": cap["demb"][:B], "z": cap["z"][:B], "out": cap["out"][:B], "loss": cap["loss"],
-                 "ws_head": cap["ws_head"], "ws_head_bytes": lib.hcg_head_workspace_bytes_d(B, D if lib.hcg_head_supported(D, C) else 64), "ws": cap["ws"]}
+                 "ws_head": cap["ws_head"], "ws_head_bytes": cap["ws_head"].numel(), "ws": cap["ws"]}
             self._bufs = {"cap": cap, key: b}          # views of the current shape (one live shape at a time)
         return b
 
@@ -357,6 +198,12 @@ class FusedTrainStep:
         if ws is None or ws.numel() < wsb:
             ws = bufs["ws"][("tall", l)] = torch.empty(int(wsb * 1.25), dtype=torch.uint8, device=dev)
         return ws, wsb
+
+    def _ws(self, bufs, key, nbytes, dev):
+        ws = bufs["ws"].get(key)
+        if (ws is None or ws.numel() < nbytes) and nbytes > 0:
+            ws = bufs["ws"][key] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+        return ws
 
     def _head_buffers(self, bufs, B, D, C, dev):
         """Scratch of the any-shape head (five launches): allocated once per capacity."""
@@ -395,227 +242,407 @@ class FusedTrainStep:
                 off += p.numel()
         return flat
 
-    def evaluate(self, batch, _checked: bool = False):
-        """Forward + loss only (the reference's `eval_network` body, utils/utils_model.py:75-78): plan, conv stack, head
-        -- 3 launches; the head kernel's backward half runs too (a few us) but nothing is reduced or updated."""
-        return self(batch, _forward_only=True, _checked=_checked)
-
-    def __call__(self, batch, _forward_only: bool = False, _checked: bool = False):
-        model = self.model
-        if not _checked:                 # (the epoch loops below have just asked `reason(batch)` themselves)
-            why = self.reason(batch)
-            if why is not None:
-                raise _lib.HcgError(f"FusedTrainStep does not cover this model/batch: {why}")
-        lib = _lib.load()
+    # ------------------------------------------------------------------ the step, piece by piece
+    def _prepare(self, batch, forward_only: bool) -> _Ctx:
+        model, lib = self.model, _lib.load()
+        c = _Ctx()
+        c.batch, c.forward_only = batch, forward_only
         x, y = batch.x, batch.y
         _lib.require_gpu(x, y, batch.edge_index)
-        x = HF._f32c(x)
-        plan = model._plan_for(batch, x, batch.edge_index, batch.batch, None)
-        convs = [model.conv1] + list(model.conv_layers)
-        l0, l1 = model.readout[0][0], model.readout[1]
-        N, F, B, D, C = x.shape[0], x.shape[1], plan.B, model.embedding_dim, model._n_classes
-        n_conv, dev, stream, slope = len(convs), x.device, _lib.stream_ptr(), HF.LEAKY_SLOPE
-        y2 = HF._f32c(y).reshape(B, -1)
-        if y2.shape[1] != C:
-            raise ValueError(f"targets have {y2.shape[1]} columns, the model predicts {C}")
+        c.x = x = HF._f32c(x)
+        c.plan = plan = model._plan_for(batch, x, batch.edge_index, batch.batch, None)
+        c.convs = convs = [model.conv1] + list(model.conv_layers)
+        c.l0, c.l1 = model.readout[0][0], model.readout[1]
+        c.N, c.F, c.B, c.D, c.C = x.shape[0], x.shape[1], plan.B, model.embedding_dim, model._n_classes
+        c.n_conv, c.dev = len(convs), x.device
+        c.y2 = HF._f32c(y).reshape(c.B, -1)
+        if c.y2.shape[1] != c.C:
+            raise ValueError(f"targets have {c.y2.shape[1]} columns, the model predicts {c.C}")
         # kernel family per layer: gpt > 0 = small-graph tiles (csrc/fused.hip), 0 = one graph per workgroup (csrc/mid.hip)
-        gpts = [HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) for c in convs]
-        for c, gpt in zip(convs, gpts):
-            if gpt <= 0 and not HF.mid_supported(plan, c.in_channels, c.out_channels):
+        c.gpts = [HF.fused_graphs_per_tile(plan, cv.in_channels, cv.out_channels) for cv in convs]
+        for cv, gpt in zip(convs, c.gpts):
+            if gpt <= 0 and not HF.mid_supported(plan, cv.in_channels, cv.out_channels):
                 raise _lib.HcgError("FusedTrainStep: graph / layer shape outside the fused kernels")
         # 128-wide layers over large graphs: dense row-streaming transform + per-graph segmented sum (csrc/tall.hip)
-        tall = [gpt <= 0 and getattr(c, "family", "auto") != "mid" and HF.tall_supported(plan, c.in_channels, c.out_channels)
-                for c, gpt in zip(convs, gpts)]
-        mxn, mxe = plan.max_nodes, plan.max_edges
-        bufs = self._buffers((N, B, F, plan.E), N, B, F, D, C, n_conv, dev)
-        n_small = self._size_groups(batch, plan, convs, D, C, n_conv)
-        if n_small is not None:
-            return self._routed_step(batch, plan, bufs, x, y2, convs, l0, l1, n_small, _forward_only)
-        acts, emb = bufs["acts"], bufs["emb"]
-        p = _lib.ptr
-        W = [HF._f32c(c.lin.weight) for c in convs]
-        bs = [HF._f32c(c.bias) for c in convs]
-        # ---- forward (conv stack + pooling).  Small-graph tiles: the pooled layer's activations stay on chip, two bits
-        #      per element (sign, is-the-column-max) are all its backward needs of them
-        poolbits = None
-        if gpts[-1] > 0 and self.POOLBITS:
-            nb = lib.hcg_fused_poolbits_bytes(B, gpts[-1])
-            poolbits = bufs["ws"].get("poolbits")
-            if poolbits is None or poolbits.numel() < nb:
-                poolbits = bufs["ws"]["poolbits"] = torch.empty(int(nb * 1.25), dtype=torch.uint8, device=dev)
-        if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0 and poolbits is None:
-            rc = lib.hcg_fused_stack2_fwd(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
-                                          p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1, p(acts[0]),
-                                          p(acts[1]), p(emb), p(plan.status), stream)
-            _lib.check(rc, "hcg_fused_stack2_fwd")
-        elif n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
-            rc = lib.hcg_fused_stack2_fwd_train(p(x), p(W[0]), p(bs[0]), p(W[1]), p(bs[1]), p(plan.edge_index), plan.E,
-                                                p(plan.graph_ptr), p(plan.edge_ptr), N, B, F, D, gpts[0], slope, 1,
-                                                p(acts[0]), p(emb), p(poolbits), p(plan.status), stream)
-            _lib.check(rc, "hcg_fused_stack2_fwd_train")
-        else:
-            h = x
-            for l in range(n_conv):
-                pe = p(emb) if l == n_conv - 1 else None
-                if gpts[l] > 0 and pe is not None and poolbits is not None:
-                    rc = lib.hcg_fused_layer_fwd_train(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                                       p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, pe,
-                                                       p(poolbits), p(plan.status), stream)
-                    _lib.check(rc, "hcg_fused_layer_fwd_train")
-                elif gpts[l] > 0:
-                    rc = lib.hcg_fused_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                                 p(plan.edge_ptr), N, B, h.shape[1], D, gpts[l], slope, 1, p(acts[l]), pe,
-                                                 p(plan.status), stream)
-                    _lib.check(rc, "hcg_fused_layer_fwd")
-                elif tall[l]:
-                    ws, wsb = self._tall_ws(bufs, l, N, B, h.shape[1], D, dev)
-                    rc = lib.hcg_tall_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                                p(plan.edge_ptr), N, B, h.shape[1], D, mxn, mxe, slope, 1, p(acts[l]), pe,
-                                                p(plan.status), p(ws), wsb, stream)
-                    _lib.check(rc, "hcg_tall_layer_fwd")
-                else:
-                    rc = lib.hcg_mid_layer_fwd(p(h), p(W[l]), p(bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                               p(plan.edge_ptr), N, B, h.shape[1], D, mxn, mxe, slope, 1, p(acts[l]), pe,
-                                               p(plan.status), stream)
-                    _lib.check(rc, "hcg_mid_layer_fwd")
-                h = acts[l]
-        # ---- head: readout forward, loss, readout backward
-        opt = model.optimizer
-        step_word, flat, g = None, None, None
-        if not _forward_only:
+        c.tall = [gpt <= 0 and getattr(cv, "family", "auto") != "mid" and HF.tall_supported(plan, cv.in_channels, cv.out_channels)
+                  for cv, gpt in zip(convs, c.gpts)]
+        c.bufs = self._buffers((c.N, c.B, c.F, plan.E), c.N, c.B, c.F, c.D, c.C, c.n_conv, c.dev)
+        c.W = [HF._f32c(cv.lin.weight) for cv in convs]
+        c.bs = [HF._f32c(cv.bias) for cv in convs]
+        c.head_fused = bool(lib.hcg_head_supported(c.D, c.C))
+        c.n_small = self._size_groups(batch, plan, convs, c.D, c.C, c.n_conv)
+        c.jb = lib.hcg_reduce_job_bytes()
+        c.jobs = ctypes.create_string_buffer(c.jb * _lib.HCG_REDUCE_MAX_JOBS)
+        c.jaddr, c.njobs = ctypes.addressof(c.jobs), 0
+        c.flat = c.gaddr = c.step_word = None
+        c.poolbits = None
+        # how the loss scale reaches the gradients (see the class docstring).  "sse" with a collective between backward and
+        # update: the tail leaves the gradients unscaled and [SSE, count] behind the flat buffer; everything else: the tail
+        # applies this rank's own scale ("sse" without any exchange IS sqrt(MSE) of the own batch)
+        dp_sync = self.grad_sync is not None or self.exchange is not None or self._capturing_split
+        c.sse_split = self.combine == "sse" and dp_sync and not forward_only
+        c.loss_mode = _lib.HCG_LOSS_SSE if c.sse_split else (_lib.HCG_LOSS_RMSE if self.rmse else _lib.HCG_LOSS_MSE)
+        if not forward_only:
             params = self._trainable()
-            flat = self._flat_grads(params, dev)
-            ga = getattr(self, "_gaddr", None)         # (see _routed_step)
-            if ga is None or ga[0] != flat.data_ptr() or ga[1] is not params:
+            c.flat = self._flat_grads(params, c.dev)
+            # address of every parameter's slice of the flat gradient buffer (cached per buffer: eight tensor slices per
+            # step otherwise)
+            ga = getattr(self, "_gaddr", None)
+            if ga is None or ga[0] != c.flat.data_ptr() or ga[1] is not params:
                 addr, off = {}, 0
                 for q in params:
-                    addr[id(q)] = flat.data_ptr() + 4 * off
+                    addr[id(q)] = c.flat.data_ptr() + 4 * off
                     off += q.numel()
-                ga = self._gaddr = (flat.data_ptr(), params, addr)
-            g = (lambda prm, _a=ga[2]: _a[id(prm)])
-            # without an exchange between backward and update, the slab reduction applies Adam itself; the head kernel
+                ga = self._gaddr = (c.flat.data_ptr(), params, addr)
+            c.gaddr = ga[2]
+            # without a collective between backward and update, the step's last launch applies Adam itself; the head
             # advances the step number that launch reads
-            if (self.optimizer_step and self.grad_sync is None and not self._capturing_split
-                    and (self.combine == "mean" or self.exchange is not None) and hasattr(opt, "fused_update_ready")):
-                step_word = opt.fused_update_ready(flat)
-        sse = self.combine == "sse" and not _forward_only
-        mode = _lib.HCG_HEAD_SSE if sse else int(self.rmse)
-        tail = self._flat_ext[flat.numel():] if sse else None
-        fused_head = bool(lib.hcg_head_supported(D, C))
+            opt = model.optimizer
+            # (a one-shot exchange rides in that launch only when all its polling workgroups are resident at once: the
+            #  64-wide model's slabs need ~540 of ~1800; the 128-wide one's ~2100 -- it keeps the collective, see
+            #  hcg_xchg_resident_blocks)
+            if (self.optimizer_step and self.grad_sync is None and not self._capturing_split and c.head_fused
+                    and hasattr(opt, "fused_update_ready") and (self.exchange is None or c.D == 64)):
+                c.step_word = opt.fused_update_ready(c.flat)
+        return c
+
+    def _size_groups(self, batch, plan, convs, D, C, n_conv):
+        """-> n_small when the batch is size-grouped (`collate(..., group_by_size=True)`: the first n_small graphs have <= 32
+        nodes, the others 33 .. 64) and both groups are non-empty: the small graphs then run in the small-graph tiles, the
+        larger ones one graph per wave, instead of everything on the slower family."""
+        ns = getattr(batch, "n_small", None)
+        lib = _lib.load()
+        if (ns is None or not (0 < ns < plan.B) or n_conv != 2 or D != 64 or not lib.hcg_head_supported(D, C)
+                or plan.max_nodes is None or plan.max_nodes <= 32 or plan.max_edges is None):
+            return None
+        for c in convs:
+            if lib.hcg_fused_graphs_per_tile(c.in_channels, c.out_channels, 32) <= 0:
+                return None
+            if not HF.mid_supported(plan, c.in_channels, c.out_channels):
+                return None
+        return int(ns)
+
+    def _g(self, c: _Ctx, prm) -> int:
+        return c.gaddr[id(prm)]
+
+    def _job_slot(self, c: _Ctx) -> int:
+        return c.jaddr + c.njobs * c.jb
+
+    def _tiles_args(self, c: _Ctx, B, gpt, **extra):
+        plan = c.plan
+        return dict(x=c.x, W1=c.W[0], b1=c.bs[0], W2=c.W[1], b2=c.bs[1], edge_index=plan.edge_index, E=plan.E,
+                    graph_ptr=plan.graph_ptr, edge_ptr=plan.edge_ptr, N=c.N, B=B, F=c.F, D=c.D, graphs_per_tile=gpt,
+                    apply_act=1, slope=HF.LEAKY_SLOPE, out1=c.bufs["acts"][0], emb=c.bufs["emb"], status=plan.status, **extra)
+
+    def _head_in_forward(self, c: _Ctx) -> bool:
+        """The C3 form: both conv layers on small-graph tiles, pooled layer on chip, one-launch head -> everything up to
+        the loss is ONE launch."""
+        return (self.HEAD_IN_FORWARD and self.POOLBITS and c.n_small is None and c.n_conv == 2 and c.head_fused
+                and c.gpts[0] == c.gpts[1] and c.gpts[0] > 0)
+
+    def _forward_with_head(self, c: _Ctx):
+        """conv stack + pooling + readout head (forward, squared error, unscaled readout backward): one launch."""
+        lib, bufs, gpt = _lib.load(), c.bufs, c.gpts[0]
+        c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_poolbits_bytes(c.B, gpt), c.dev)
+        l0, l1 = c.l0, c.l1
+        _lib.fused_forward(**self._tiles_args(
+            c, c.B, gpt, poolbits=c.poolbits, y=c.y2, head_W0=HF._f32c(l0.weight), head_b0=HF._f32c(l0.bias),
+            head_W1=HF._f32c(l1.weight), head_b1=HF._f32c(l1.bias), C=c.C, z=bufs["z"], out=bufs["out"], demb=bufs["demb"],
+            head_workspace=bufs["ws_head"], head_workspace_bytes=bufs["ws_head_bytes"], step_counter=c.step_word,
+            head_flags=_lib.HCG_HEAD_FORWARD_ONLY if c.forward_only else 0))
+        g = (lambda q: self._g(c, q)) if not c.forward_only else (lambda q: None)
+        _lib.check(lib.hcg_fused_head_reduce_job(_lib.ptr(bufs["ws_head"]), bufs["ws_head_bytes"], c.B, gpt, c.C, g(l0.weight),
+                                                 g(l0.bias), g(l1.weight), g(l1.bias), self._job_slot(c)),
+                   "hcg_fused_head_reduce_job")
+        c.njobs += 1
+
+    def _forward_layers(self, c: _Ctx):
+        """The conv stack (+ pooling) of every other shape: one launch per layer (stacked pair: one)."""
+        lib, plan, bufs = _lib.load(), c.plan, c.bufs
+        p, stream, slope = _lib.ptr, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        acts, emb, gpts, n_conv, N, B, D = bufs["acts"], bufs["emb"], c.gpts, c.n_conv, c.N, c.B, c.D
+        mxn, mxe = plan.max_nodes, plan.max_edges
+        # small-graph tiles: the pooled layer's activations stay on chip, two bits per element (sign, is-the-column-max)
+        # are all its backward needs of them
+        if gpts[-1] > 0 and self.POOLBITS:
+            c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_poolbits_bytes(B, gpts[-1]), c.dev)
+        if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
+            _lib.fused_forward(**self._tiles_args(c, B, gpts[0], poolbits=c.poolbits,
+                                                  out2=None if c.poolbits is not None else acts[1]))
+            return
+        h = c.x
+        for l in range(n_conv):
+            pe = emb if l == n_conv - 1 else None
+            Fl = h.shape[1]
+            if gpts[l] > 0:
+                bits = c.poolbits if pe is not None else None
+                _lib.fused_forward(x=h, W1=c.W[l], b1=c.bs[l], edge_index=plan.edge_index, E=plan.E, graph_ptr=plan.graph_ptr,
+                                   edge_ptr=plan.edge_ptr, N=N, B=B, F=Fl, D=D, graphs_per_tile=gpts[l], apply_act=1,
+                                   slope=slope, out1=None if bits is not None else acts[l], emb=pe, poolbits=bits,
+                                   status=plan.status)
+            elif c.tall[l]:
+                ws, wsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
+                rc = lib.hcg_tall_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                            p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe),
+                                            p(plan.status), p(ws), wsb, stream)
+                _lib.check(rc, "hcg_tall_layer_fwd")
+            else:
+                rc = lib.hcg_mid_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe),
+                                           p(plan.status), stream)
+                _lib.check(rc, "hcg_mid_layer_fwd")
+            h = acts[l]
+
+    def _forward_routed(self, c: _Ctx, fork, join, stream_b):
+        """Size-grouped batch: graphs [0, n_small) through the tiles (both layers + pooling in one launch, pooled layer on
+        chip), graphs [n_small, B) one graph per wave -- every launch gets the sub-range of graph_ptr / edge_ptr / emb it
+        owns; node rows are absolute, so x and the activations need no offsets."""
+        lib, plan, bufs = _lib.load(), c.plan, c.bufs
+        p, slope = _lib.ptr, HF.LEAKY_SLOPE
+        Bs, Bb = c.n_small, c.B - c.n_small
+        gp_b, ep_b = plan.graph_ptr.data_ptr() + 4 * Bs, plan.edge_ptr.data_ptr() + 4 * Bs
+        acts, emb = bufs["acts"], bufs["emb"]
+        emb_b = emb.data_ptr() + 4 * 2 * c.D * Bs
+        gpt = int(lib.hcg_fused_graphs_per_tile(c.F, c.D, 32))
+        c.poolbits = self._ws(bufs, "poolbits_r", lib.hcg_fused_poolbits_bytes(Bs, gpt), c.dev)
+        mxn, mxe = plan.max_nodes, plan.max_edges
+        fork()
+        _lib.fused_forward(**self._tiles_args(c, Bs, gpt, poolbits=c.poolbits))
+        _lib.check(lib.hcg_mid_layer_fwd(p(c.x), p(c.W[0]), p(c.bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.F, c.D,
+                                         mxn, mxe, slope, 1, p(acts[0]), None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+        _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(c.W[1]), p(c.bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.D,
+                                         c.D, mxn, mxe, slope, 1, p(acts[1]), emb_b, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+        join()
+        return gpt
+
+    def _head(self, c: _Ctx):
+        """The readout head as a launch of its own (one-launch kernel for D = 64 / 128, C <= 8; five launches of the
+        any-shape kernels otherwise) -- reference model/gcn.py:70-71, utils/utils_model.py:64-65."""
+        lib, bufs = _lib.load(), c.bufs
+        p, stream, slope = _lib.ptr, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        B, D, C, l0, l1 = c.B, c.D, c.C, c.l0, c.l1
         W0, b0, W1, b1 = HF._f32c(l0.weight), HF._f32c(l0.bias), HF._f32c(l1.weight), HF._f32c(l1.bias)
-        jb = lib.hcg_reduce_job_bytes()
-        jobs = ctypes.create_string_buffer(jb * 8)
-        jaddr = ctypes.addressof(jobs)
-        njobs = 0
-        if fused_head:
-            rc = lib.hcg_head_fwd_bwd_ex(p(emb), p(y2), p(W0), p(b0), p(W1), p(b1), B, D, C, slope, mode, p(bufs["z"]),
-                                         p(bufs["out"]), p(bufs["loss"]), p(bufs["demb"]), p(bufs["ws_head"]),
-                                         bufs["ws_head_bytes"], p(self._sync_words(dev)), p(step_word), p(tail), stream)
-            _lib.check(rc, "hcg_head_fwd_bwd_ex")
-            if _forward_only:
-                self.last_out = bufs["out"]
-                return bufs["loss"][0]
-            _lib.check(lib.hcg_head_reduce_job_d(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, D, C, g(l0.weight), g(l0.bias),
-                                                 g(l1.weight), g(l1.bias), jaddr), "hcg_head_reduce_job_d")
-            njobs = 1
-        else:
-            # any-shape head (widths other than 64 / 128): Linear + LeakyReLU, Linear, loss with its gradient, two Linear backwards
-            # that write straight into the flat gradient buffer (reference model/gcn.py:70-71, utils/utils_model.py:64-65)
-            hb = self._head_buffers(bufs, B, D, C, dev)
-            z, out = bufs["z"], bufs["out"]
-            _lib.check(lib.hcg_linear_fwd(p(emb), p(W0), p(b0), p(z), B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, stream), "hcg_linear_fwd")
-            _lib.check(lib.hcg_linear_fwd(p(z), p(W1), p(b1), p(out), B, D, C, _lib.HCG_ACT_NONE, slope, stream), "hcg_linear_fwd")
-            _lib.check(lib.hcg_loss_fwd_bwd(p(out), p(y2), B * C, mode, p(bufs["loss"]), p(hb["dout"]), p(tail), stream),
-                       "hcg_loss_fwd_bwd")
-            if _forward_only:
-                self.last_out = bufs["out"]
-                return bufs["loss"][0]
-            _lib.check(lib.hcg_linear_bwd(p(hb["dout"]), p(out), p(z), p(W1), p(hb["dz"]), g(l1.weight), g(l1.bias), p(hb["dz_ws1"]),
-                                          B, D, C, _lib.HCG_ACT_NONE, slope, p(hb["ws1"]), hb["ws1"].numel(), stream), "hcg_linear_bwd")
-            _lib.check(lib.hcg_linear_bwd(p(hb["dz"]), p(z), p(emb), p(W0), p(bufs["demb"]), g(l0.weight), g(l0.bias), p(hb["dz_ws0"]),
-                                          B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, p(hb["ws0"]), hb["ws0"].numel(), stream), "hcg_linear_bwd")
-            step_word = None          # the head's gradients are not slabs: reduction and update stay two launches
-        # ---- conv stack backward, last layer first
-        # a fused-tile layer can hand its dx down already multiplied by the activation derivative of the layer below
-        # (it holds those rows anyway, for dW); that layer then never reads its own output: one tensor less per step
+        emb, z, out = bufs["emb"], bufs["z"], bufs["out"]
+        if c.head_fused:
+            rc = lib.hcg_head_fwd_bwd(p(emb), p(c.y2), p(W0), p(b0), p(W1), p(b1), B, D, C, slope,
+                                      _lib.HCG_HEAD_FORWARD_ONLY if c.forward_only else 0, p(z), p(out), p(bufs["demb"]),
+                                      p(bufs["ws_head"]), bufs["ws_head_bytes"], p(c.step_word), stream)
+            _lib.check(rc, "hcg_head_fwd_bwd")
+            g = (lambda q: self._g(c, q)) if not c.forward_only else (lambda q: None)
+            _lib.check(lib.hcg_head_reduce_job(p(bufs["ws_head"]), bufs["ws_head_bytes"], B, D, C, g(l0.weight), g(l0.bias),
+                                               g(l1.weight), g(l1.bias), self._job_slot(c)), "hcg_head_reduce_job")
+            c.njobs += 1
+            return
+        # any-shape head (widths other than 64 / 128, more than 8 classes): Linear + LeakyReLU, Linear, loss with its
+        # (scaled) gradient, two Linear backwards that write straight into the flat gradient buffer
+        hb = self._head_buffers(bufs, B, D, C, c.dev)
+        tail = self._flat_ext[c.flat.numel():] if c.sse_split else None
+        _lib.check(lib.hcg_linear_fwd(p(emb), p(W0), p(b0), p(z), B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, stream), "hcg_linear_fwd")
+        _lib.check(lib.hcg_linear_fwd(p(z), p(W1), p(b1), p(out), B, D, C, _lib.HCG_ACT_NONE, slope, stream), "hcg_linear_fwd")
+        _lib.check(lib.hcg_loss_fwd_bwd(p(out), p(c.y2), B * C, c.loss_mode, p(bufs["loss"]), p(hb["dout"]), p(tail), stream),
+                   "hcg_loss_fwd_bwd")
+        if c.forward_only:
+            return
+        g = lambda q: self._g(c, q)
+        _lib.check(lib.hcg_linear_bwd(p(hb["dout"]), p(out), p(z), p(W1), p(hb["dz"]), g(l1.weight), g(l1.bias), p(hb["dz_ws1"]),
+                                      B, D, C, _lib.HCG_ACT_NONE, slope, p(hb["ws1"]), hb["ws1"].numel(), stream), "hcg_linear_bwd")
+        _lib.check(lib.hcg_linear_bwd(p(hb["dz"]), p(z), p(emb), p(W0), p(bufs["demb"]), g(l0.weight), g(l0.bias), p(hb["dz_ws0"]),
+                                      B, 2 * D, D, _lib.HCG_ACT_LEAKY, slope, p(hb["ws0"]), hb["ws0"].numel(), stream), "hcg_linear_bwd")
+
+    def _backward_layers(self, c: _Ctx):
+        """Conv stack backward, last layer first.  A fused-tile layer can hand its dx down already multiplied by the
+        activation derivative of the layer below (it holds those rows anyway, for dW); that layer then never reads its own
+        output: one tensor less per step."""
+        lib, plan, bufs = _lib.load(), c.plan, c.bufs
+        p, stream, slope = _lib.ptr, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        acts, emb, gpts, n_conv, N, B, D = bufs["acts"], bufs["emb"], c.gpts, c.n_conv, c.N, c.B, c.D
+        mxn, mxe = plan.max_nodes, plan.max_edges
+        g = lambda q: self._g(c, q)
         dh, premasked = None, False
         for l in reversed(range(n_conv)):
-            inp = x if l == 0 else acts[l - 1]
+            inp = c.x if l == 0 else acts[l - 1]
             Fl = inp.shape[1]
             dx = bufs["dacts"][l - 1] if l > 0 else None
             small = gpts[l] > 0
             wsb = (lib.hcg_fused_workspace_bytes(B, Fl, D, gpts[l]) if small else
-                   (0 if tall[l] else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)))
-            ws = bufs["ws"].get(l)
-            if (ws is None or ws.numel() < wsb) and wsb > 0:
-                ws = torch.empty(int(wsb * 1.25), dtype=torch.uint8, device=dev)
-                bufs["ws"][l] = ws
+                   (0 if c.tall[l] else lib.hcg_mid_workspace_bytes(B, Fl, D, mxn, mxe)))
+            ws = self._ws(bufs, l, wsb, c.dev)
             last = l == n_conv - 1
-            up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
-            if small and last and poolbits is not None:
+            cv = c.convs[l]
+            geo = (p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D)
+            if small:
+                bits = c.poolbits if last else None
+                act = 1 if (last or not premasked) else 0
                 premasked = self.PREMASK and l > 0
-                rc = lib.hcg_fused_layer_bwd_poolbits(p(bufs["demb"]), p(poolbits), p(inp), p(W[l]), p(plan.edge_index), plan.E,
-                                                      p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
-                                                      1 | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
-                _lib.check(rc, "hcg_fused_layer_bwd_poolbits")
-                _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
-                                                    g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
-            elif small:
-                act = 0 if premasked else 1
-                premasked = self.PREMASK and l > 0
-                rc = lib.hcg_fused_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
-                                             plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, gpts[l], slope,
-                                             act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
+                a_out = p(acts[l]) if (bits is None and (act or last)) else None
+                rc = lib.hcg_fused_layer_bwd(None if last else p(dh), p(bufs["demb"]) if last else None,
+                                             p(emb) if (last and bits is None) else None, a_out, p(bits), p(inp), p(c.W[l]), *geo,
+                                             gpts[l], slope, act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_fused_layer_bwd")
-                _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(convs[l].lin.weight),
-                                                    g(convs[l].bias), jaddr + njobs * jb), "hcg_fused_reduce_job")
-            elif tall[l]:
-                # (never premasks: the layer below reads its own output row-contiguous instead -- the premask would be 4-byte
-                #  strided loads in the dense kernel's epilogue for the same bytes)
-                act = 0 if premasked else 1
-                premasked = False
-                tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, dev)
-                rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
-                                            plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, act,
-                                            p(dx), p(plan.status), p(tws), twsb, stream)
-                _lib.check(rc, "hcg_tall_layer_bwd")
-                _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, g(convs[l].lin.weight), g(convs[l].bias),
-                                                    jaddr + njobs * jb), "hcg_tall_reduce_jobs")
-                njobs += 1                          # (two jobs: dW, db)
+                _lib.check(lib.hcg_fused_reduce_job(p(ws), wsb, N, B, Fl, D, gpts[l], g(cv.lin.weight), g(cv.bias),
+                                                    self._job_slot(c)), "hcg_fused_reduce_job")
             else:
+                up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
                 act = 0 if premasked else 1
-                premasked = self.PREMASK and l > 0
-                rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(W[l]), p(plan.edge_index),
-                                           plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope,
-                                           act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
-                _lib.check(rc, "hcg_mid_layer_bwd")
-                for half in range(D // 64):      # one slab set (= one job) per 64-column half
-                    if half > 0:
-                        njobs += 1
-                    _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, half, g(convs[l].lin.weight),
-                                                      g(convs[l].bias), jaddr + njobs * jb), "hcg_mid_reduce_job")
-            njobs += 1
+                if c.tall[l]:
+                    # (never premasks: the layer below reads its own output row-contiguous instead -- the premask would be
+                    #  4-byte strided loads in the dense kernel's epilogue for the same bytes)
+                    premasked = False
+                    tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
+                    rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(c.W[l]), *geo, mxn, mxe,
+                                                slope, act, p(dx), p(plan.status), p(tws), twsb, stream)
+                    _lib.check(rc, "hcg_tall_layer_bwd")
+                    _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, g(cv.lin.weight), g(cv.bias),
+                                                        self._job_slot(c)), "hcg_tall_reduce_jobs")
+                    c.njobs += 1                          # (two jobs: dW, db)
+                else:
+                    premasked = self.PREMASK and l > 0
+                    rc = lib.hcg_mid_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(c.W[l]), *geo, mxn, mxe,
+                                               slope, act | (2 if premasked else 0), p(dx), p(plan.status), p(ws), wsb, stream)
+                    _lib.check(rc, "hcg_mid_layer_bwd")
+                    for half in range(D // 64):      # one slab set (= one job) per 64-column half
+                        if half > 0:
+                            c.njobs += 1
+                        _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, Fl, D, mxn, mxe, half, g(cv.lin.weight), g(cv.bias),
+                                                          self._job_slot(c)), "hcg_mid_reduce_job")
+            c.njobs += 1
             dh = dx
-        # ---- slab reduction -> flat gradient, exchange, update.  Without an exchange in between, reduction and Adam
-        #      are one launch (the update reads each gradient element as it is produced)
-        self._last_carried = step_word is not None
-        if step_word is not None:
+
+    def _backward_routed(self, c: _Ctx, gpt, fork, join, stream_b):
+        """Size-grouped batch: each layer's backward = tiles on the small graphs + waves on the others; both groups' slabs of
+        a layer sit back to back and are ONE reduction job."""
+        lib, plan, bufs = _lib.load(), c.plan, c.bufs
+        p, stream, slope = _lib.ptr, _lib.stream_ptr(), HF.LEAKY_SLOPE
+        Bs, Bb, N, D = c.n_small, c.B - c.n_small, c.N, c.D
+        gp, ep = plan.graph_ptr, plan.edge_ptr
+        gp_b, ep_b = gp.data_ptr() + 4 * Bs, ep.data_ptr() + 4 * Bs
+        acts, emb, demb = bufs["acts"], bufs["emb"], bufs["demb"]
+        emb_b, demb_b = emb.data_ptr() + 4 * 2 * D * Bs, demb.data_ptr() + 4 * 2 * D * Bs
+        mxn, mxe = plan.max_nodes, plan.max_edges
+        g = lambda q: self._g(c, q)
+        tmp = ctypes.create_string_buffer(c.jb)
+        taddr = ctypes.addressof(tmp)
+        premask = bool(self.PREMASK)
+        dx = bufs["dacts"][0]
+        fork()
+        for l in (1, 0):
+            inp = c.x if l == 0 else acts[0]
+            Fl = inp.shape[1]
+            ws_a = lib.hcg_fused_workspace_bytes(Bs, Fl, D, gpt)
+            ws_b = lib.hcg_mid_workspace_bytes(Bb, Fl, D, mxn, mxe)
+            off_b = ws_a - 256                                  # = the tile launch's slabs, exactly (the query pads by 256)
+            ws = self._ws(bufs, ("r", l), off_b + ws_b, c.dev)
+            wsb_ptr = ws.data_ptr() + off_b
+            geo_a = (p(plan.edge_index), plan.E, p(gp), p(ep), N, Bs, Fl, D)
+            geo_b = (p(plan.edge_index), plan.E, gp_b, ep_b, N, Bb, Fl, D)
+            cv = c.convs[l]
+            if l == 1:
+                flags = 1 | (2 if premask else 0)
+                _lib.check(lib.hcg_fused_layer_bwd(None, p(demb), None, None, p(c.poolbits), p(inp), p(c.W[l]), *geo_a, gpt, slope,
+                                                   flags, p(dx), p(plan.status), p(ws), off_b, stream), "hcg_fused_layer_bwd")
+                _lib.check(lib.hcg_mid_layer_bwd(None, demb_b, emb_b, p(acts[1]), p(inp), p(c.W[l]), *geo_b, mxn, mxe, slope, flags,
+                                                 p(dx), p(plan.status), wsb_ptr, ws_b, stream_b), "hcg_mid_layer_bwd")
+            else:
+                act = 0 if premask else 1
+                a_out = p(acts[0]) if act else None
+                _lib.check(lib.hcg_fused_layer_bwd(p(dx), None, None, a_out, None, p(inp), p(c.W[l]), *geo_a, gpt, slope, act, None,
+                                                   p(plan.status), p(ws), off_b, stream), "hcg_fused_layer_bwd")
+                _lib.check(lib.hcg_mid_layer_bwd(p(dx), None, None, a_out, p(inp), p(c.W[l]), *geo_b, mxn, mxe, slope, act, None,
+                                                 p(plan.status), wsb_ptr, ws_b, stream_b), "hcg_mid_layer_bwd")
+            _lib.check(lib.hcg_fused_reduce_job(p(ws), off_b, N, Bs, Fl, D, gpt, g(cv.lin.weight), g(cv.bias), self._job_slot(c)),
+                       "hcg_fused_reduce_job")
+            _lib.check(lib.hcg_mid_reduce_job(wsb_ptr, ws_b, Bb, Fl, D, mxn, mxe, 0, g(cv.lin.weight), g(cv.bias), taddr),
+                       "hcg_mid_reduce_job")
+            _lib.check(lib.hcg_reduce_job_append(self._job_slot(c), taddr), "hcg_reduce_job_append")
+            c.njobs += 1
+        join()
+
+    def _tail(self, c: _Ctx):
+        """The step's last launch: slab reductions -> ONE flat gradient, the loss and its scale, (exchange,) update, the next
+        batch's plan.  With a collective between backward and update the launch stops at the gradient."""
+        opt, bufs = self.model.optimizer, c.bufs
+        count = float(c.B * c.C)
+        self._last_carried = c.step_word is not None
+        if c.step_word is not None:
             if self.exchange is not None and self.pre_exchange_hook is not None:
                 self.pre_exchange_hook()
-            if not opt.step_with_reduction(jaddr, njobs, flat, next_plan=self.next_plan, exchange=self.exchange,
-                                           flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"]):    # (same preconditions as fused_update_ready)
+            if not opt.step_with_reduction(c.jaddr, c.njobs, c.flat, next_plan=self.next_plan, exchange=self.exchange,
+                                           flat_ext=self._flat_ext, mode=self.combine, loss_buf=bufs["loss"],
+                                           loss_mode=c.loss_mode, loss_count=count):
                 raise _lib.HcgError("optimizer state changed between head launch and update")
-        else:
-            _lib.check(lib.hcg_reduce_slabs(jaddr, njobs, stream), "hcg_reduce_slabs")
-            if self.next_plan is not None:
-                self.next_plan.rebuild()                   # (no fused update to ride in: its own launch)
-            if not self._capturing_split:
-                self._exchange_and_update(bufs["loss"])
-        self.last_out = bufs["out"]
-        return bufs["loss"][0]
+            return
+        sse_tail = self._flat_ext[c.flat.numel():] if (c.sse_split and c.head_fused) else None
+        _lib.step_tail(c.jaddr, c.njobs, loss=bufs["loss"], loss_mode=c.loss_mode, loss_count=count, sse_tail=sse_tail)
+        if self.next_plan is not None:
+            self.next_plan.rebuild()                   # (no fused update to ride in: its own launch)
+        if not self._capturing_split:
+            self._exchange_and_update(bufs["loss"], c.sse_split)
 
-    def _exchange_and_update(self, loss_buf):
-        """Behind the slab reduction: gradient exchange (data parallel), the "sse" scale, the optimiser."""
+    def _finish_forward_only(self, c: _Ctx):
+        """Forward-only steps (the reference's eval_network body, utils/utils_model.py:75-78): the loss from the head's SSE
+        partials, one tiny launch."""
+        if c.head_fused:
+            _lib.check(_lib.load().hcg_loss_finalize(c.jaddr, float(c.B * c.C), c.loss_mode, _lib.ptr(c.bufs["loss"]), None,
+                                                     _lib.stream_ptr()), "hcg_loss_finalize")
+        self.last_out = c.bufs["out"]
+        return c.bufs["loss"][0]
+
+    def evaluate(self, batch, _checked: bool = False):
+        """Forward + loss only (the reference's `eval_network` body, utils/utils_model.py:75-78): nothing is reduced or
+        updated."""
+        return self(batch, _forward_only=True, _checked=_checked)
+
+    def __call__(self, batch, _forward_only: bool = False, _checked: bool = False):
+        if not _checked:                 # (the epoch loops below have just asked `reason(batch)` themselves)
+            why = self.reason(batch)
+            if why is not None:
+                raise _lib.HcgError(f"FusedTrainStep does not cover this model/batch: {why}")
+        c = self._prepare(batch, _forward_only)
+        if c.n_small is not None:
+            return self._routed_step(c)
+        if self._head_in_forward(c):
+            self._forward_with_head(c)
+        else:
+            self._forward_layers(c)
+            self._head(c)
+        if _forward_only:
+            return self._finish_forward_only(c)
+        self._backward_layers(c)
+        self._tail(c)
+        self.last_out = c.bufs["out"]
+        return c.bufs["loss"][0]
+
+    def _routed_step(self, c: _Ctx):
+        """The step for a size-grouped batch.  The two groups' launches touch disjoint rows, graphs and slabs.  While the step
+        is being CAPTURED the larger graphs' launches go to a second stream, forked before each conv phase and joined behind
+        it = two branches of the hipGraph: each family's last workgroups fill the CUs the other has already left (neither
+        fills the chip: ~1.4 tiles per wave / ~0.6 graphs per wave slot at 4096 graphs).  Measured on the ragged bench: replay
+        0.1975 -> 0.188 ms/step; the eager step is host-bound and the four extra event calls cost it 0.196 -> 0.215, so eager
+        steps stay on one stream."""
+        dev = c.dev
+        main_s = torch.cuda.current_stream(dev)
+        side_s = self._side_stream(dev) if (self.OVERLAP_GROUPS and torch.cuda.is_current_stream_capturing()) else None
+        stream_b = ctypes.c_void_p(side_s.cuda_stream) if side_s is not None else _lib.stream_ptr()
+
+        def fork():
+            if side_s is not None:
+                side_s.wait_stream(main_s)
+
+        def join():
+            if side_s is not None:
+                main_s.wait_stream(side_s)
+        gpt = self._forward_routed(c, fork, join, stream_b)
+        self._head(c)                                   # over all graphs
+        if c.forward_only:
+            return self._finish_forward_only(c)
+        self._backward_routed(c, gpt, fork, join, stream_b)
+        self._tail(c)
+        self.last_out = c.bufs["out"]
+        return c.bufs["loss"][0]
+
+    def _exchange_and_update(self, loss_buf, sse_split: Optional[bool] = None):
+        """Behind the step tail when a collective sits between backward and update: gradient exchange (data parallel), the
+        "sse" scale, the optimiser."""
         lib, opt, flat = _lib.load(), self.model.optimizer, self._flat
         sync = self.grad_sync
         if sync is None and self.exchange is not None:
@@ -625,7 +652,9 @@ class FusedTrainStep:
             if sync is None:
                 raise _lib.HcgError("a one-shot exchange is attached, this step cannot carry it and no collective fallback is "
                                     "set: the replicas would diverge")
-        if self.combine == "sse":
+        if sse_split is None:
+            sse_split = self.combine == "sse" and sync is not None
+        if sse_split:
             ext = self._flat_ext
             if sync is not None:
                 sync(ext)                                    # SUM of [gradients | SSE | count] over the ranks

@@ -4,7 +4,7 @@ RCCL's all-reduce of the 66 KB flat gradient is latency-bound (a ring is 2 x 7 h
 with its own launch and the separate update launch, on the critical path of a ~0.11 ms step.  On MI355X every GPU has a
 direct link to each of its 7 peers, so the exchange can be ONE hop: each rank writes its partial gradient straight into
 every peer's inbox and sums the 8 contributions it received -- fused INTO the slab reduction + Adam launch
-(`hcg_reduce_slabs_xchg_adam`, csrc/reduce.hip), so the data-parallel step keeps the launch count of the single-GPU step
+(`hcg_step_tail` with an inbox, csrc/reduce.hip), so the data-parallel step keeps the launch count of the single-GPU step
 and is captured as one hipGraph.
 
     xchg = OneShotExchange(n_params)            # after torch.distributed is up: inboxes allocated, mapped across processes
@@ -23,6 +23,12 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+
+
+def inbox_slot(parity: int, world: int, writer: int, n_ext: int, elem: int) -> int:
+    """Granule index, inside ANY rank's inbox, of element `elem` written by rank `writer` in a step of parity `parity`
+    (csrc/reduce.hip: xchg_publish / xchg_gather use the same formula; tests/test_xchg_model.py walks it for world 8)."""
+    return (parity * world + writer) * n_ext + elem
 
 
 class OneShotExchange:
@@ -72,16 +78,18 @@ class OneShotExchange:
         self.ok = bool(int(verdict.item()))
 
     # ------------------------------------------------------------------ the fused launch (called by FusedAdam)
-    def launch(self, jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan=None):
-        np_ = next_plan
-        args = (None, None, 0, 0, 0, None, None, None) if np_ is None else (
-            np_.edge_index.data_ptr(), np_.batch.data_ptr(), np_.N, np_.E, np_.B, np_.graph_ptr.data_ptr(),
-            np_.edge_ptr.data_ptr(), np_.status.data_ptr())
-        _lib.check(self.lib.hcg_reduce_slabs_xchg_adam(
-            jobs_addr, njobs, flat_ext.data_ptr(), fl["p"].data_ptr(), fl["m"].data_ptr(), fl["v"].data_ptr(), fl["n"],
-            fl["lr_dev"].data_ptr(), b1, b2, eps, fl["step_dev"].data_ptr(), self.inbox, self.peers, self.rank, self.world,
-            _lib.HCG_XCHG_SSE if mode == "sse" else _lib.HCG_XCHG_MEAN, loss_buf.data_ptr(), self.err.data_ptr(), *args,
-            _lib.stream_ptr()), "hcg_reduce_slabs_xchg_adam")
+    def tail_args(self, mode: str) -> dict:
+        """The `xchg` part of `_lib.step_tail`: the exchange rides between the slab reduction and the update."""
+        return dict(inbox=self.inbox, peers_host=ctypes.addressof(self.peers), rank=self.rank, world=self.world,
+                    mode=_lib.HCG_XCHG_SSE if mode == "sse" else _lib.HCG_XCHG_MEAN, err=self.err)
+
+    def launch(self, jobs_addr, njobs, flat_ext, fl, b1, b2, eps, mode, loss_buf, next_plan=None, loss_count=0.0,
+               loss_mode=_lib.HCG_LOSS_SSE):
+        """ONE launch: slab reductions, (loss scale,) exchange, Adam update, optionally the next batch's plan."""
+        _lib.step_tail(jobs_addr, njobs, loss=loss_buf, loss_mode=loss_mode, loss_count=loss_count,
+                       adam=dict(grad_flat=flat_ext, param=fl["p"], exp_avg=fl["m"], exp_avg_sq=fl["v"], n=fl["n"],
+                                 lr_dev=fl["lr_dev"], step_dev=fl["step_dev"], beta1=b1, beta2=b2, eps=eps),
+                       next_plan=next_plan, xchg=self.tail_args(mode))
 
     def attach(self, step):
         """Route a `train.FusedTrainStep` (already made data parallel by `DataParallelGCN.attach`) through this exchange:
@@ -132,17 +140,10 @@ class OneShotExchange:
             job = ctypes.create_string_buffer(jb)
             slab = torch.empty(n, device=dev)
 
-            class _Seg(ctypes.Structure):
-                _fields_ = [("begin", ctypes.c_int32), ("count", ctypes.c_int32), ("row_in", ctypes.c_int32),
-                            ("row_out", ctypes.c_int32), ("dst", ctypes.c_void_p)]
-
-            class _Job(ctypes.Structure):
-                _fields_ = [("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int32), ("slab_floats", ctypes.c_int32),
-                            ("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("seg", _Seg * 4)]
-            assert ctypes.sizeof(_Job) == jb
-            j = _Job.from_buffer(job)
-            j.slabs, j.nslabs, j.slab_floats, j.nseg = slab.data_ptr(), 1, n, 1
-            j.seg[0] = _Seg(0, n, n, n, flat_ext.data_ptr())
+            assert ctypes.sizeof(_lib.ReduceJob) == jb
+            j = _lib.ReduceJob.from_buffer(job)
+            j.slabs, j.nslabs, j.slab_floats, j.nseg, j.sse_index = slab.data_ptr(), 1, n, 1, 0
+            j.seg[0] = _lib.ReduceSeg(0, n, n, n, flat_ext.data_ptr())
             g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         except Exception:                                           # noqa: BLE001  (any failure = fall back to RCCL)
             ok = False

@@ -65,6 +65,7 @@ extern "C" {
 #define HCG_ACT_LEAKY 1
 
 typedef void* hcg_stream_t; /* hipStream_t */
+typedef struct hcg_reduce_job hcg_reduce_job; /* defined with the slab reduction below */
 
 int hcg_version(void);
 const char* hcg_error_string(int code);
@@ -155,75 +156,87 @@ int hcg_pool_bwd(const float* demb, const float* a, const float* emb, const int3
  */
 int hcg_fused_graphs_per_tile(int64_t F, int64_t D, int64_t max_nodes_per_graph);
 size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int graphs_per_tile);
-int hcg_fused_layer_fwd(const float* x, const float* W, const float* b,
-                        const int64_t* edge_index, int64_t E,
-                        const int32_t* graph_ptr, const int32_t* edge_ptr,
-                        int64_t N, int64_t B, int64_t F, int64_t D,
-                        int graphs_per_tile, float slope, int apply_act,
-                        float* out, float* emb /*nullable*/, int32_t* status, hcg_stream_t stream);
-/* Two stacked conv layers F -> D -> D in ONE launch (the reference's default n_convolutions = 2): the
- * first layer's output tile never leaves the chip before it is consumed; out1 / out2 are still written
- * once each (the backward needs them), emb (nullable) pools out2. */
-int hcg_fused_stack2_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                         const int64_t* edge_index, int64_t E,
-                         const int32_t* graph_ptr, const int32_t* edge_ptr,
-                         int64_t N, int64_t B, int64_t F, int64_t D,
-                         int graphs_per_tile, float slope, int apply_act,
-                         float* out1, float* out2, float* emb /*nullable*/, int32_t* status, hcg_stream_t stream);
+/* EVERY forward form of the small-graph tiles is one entry point with one argument block (HOST struct; zero it first):
+ *   W2 != NULL       two stacked conv layers F -> D -> D in ONE launch (the reference's default n_convolutions = 2): the
+ *                    first layer's output tile never leaves the chip before it is consumed; out1 (and out2) are written
+ *                    once each (the backward needs them)
+ *   emb != NULL      also emb[B, 2D] = [max, mean] of the last layer per graph
+ *   poolbits != NULL training form of the POOLED (last) layer: its node activations never reach HBM (out2 / out1 of a single
+ *                    layer = NULL).  All the pooled backward needs of them is, per element, the sign (LeakyReLU') and
+ *                    whether it is its graph's column maximum (torch amax backward: ties share the gradient evenly) -- they
+ *                    leave as two bits per element (hcg_fused_poolbits_bytes: 512 B per 32-row tile, in the matrix-core
+ *                    accumulator layout) and hcg_fused_layer_bwd over the SAME plan and graphs_per_tile reads them in
+ *                    place of `out` and `emb`
+ *   head_W0 != NULL  (stacked training form only) the regression head in the TAIL of the same launch: every workgroup runs
+ *                    readout forward, squared error and (unless head_flags = HCG_HEAD_FORWARD_ONLY) the unscaled readout
+ *                    backward over its own graphs -- see hcg_head_fwd_bwd for the contract of y / z / out / demb /
+ *                    step_counter; head_workspace (hcg_fused_head_workspace_bytes) gets one gradient slab + SSE partial per
+ *                    workgroup, described by hcg_fused_head_reduce_job.  A training step is then FOUR launches: this one,
+ *                    two backward launches, hcg_step_tail.
+ * Replaces reference model/gcn.py:58-66 (+ :70-71 with the head). */
+typedef struct hcg_fused_fwd_args {
+  const float* x;
+  const float* W1;
+  const float* b1;
+  const float* W2;            /* nullable */
+  const float* b2;
+  const int64_t* edge_index;
+  int64_t E;
+  const int32_t* graph_ptr;
+  const int32_t* edge_ptr;
+  int64_t N, B, F, D;
+  int32_t graphs_per_tile;
+  int32_t apply_act;
+  float slope;
+  int32_t head_flags;
+  float* out1;                /* layer-1 node embeddings */
+  float* out2;                /* layer-2 node embeddings (stacked, no poolbits) */
+  float* emb;                 /* nullable */
+  uint32_t* poolbits;         /* nullable */
+  int32_t* status;
+  const float* y;             /* head: targets [B, C] */
+  const float* head_W0;       /* NULL = no head */
+  const float* head_b0;
+  const float* head_W1;
+  const float* head_b1;
+  int64_t C;
+  float* z;
+  float* out;
+  float* demb;
+  void* head_workspace;
+  size_t head_workspace_bytes;
+  int32_t* step_counter;      /* nullable */
+} hcg_fused_fwd_args;
+size_t hcg_fused_fwd_args_bytes(void);
+int hcg_fused_forward(const hcg_fused_fwd_args* args_host, hcg_stream_t stream);
+size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile);
+size_t hcg_fused_head_workspace_bytes(int64_t B, int graphs_per_tile);
+int hcg_fused_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int graphs_per_tile, int64_t C,
+                              float* dW0 /*NULL: partials only*/, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 /* backward, stage 1 (ONE launch).  dout == NULL selects the pooled form: the upstream gradient is
- * demb[B, 2D] and is expanded on chip with `emb` (ties of the max split evenly).  dx nullable (first
- * layer).  Leaves one partial slab [D*KPAD + D] per workgroup in `workspace`
- * (hcg_fused_workspace_bytes); stage 2 = hcg_fused_reduce_grads sums them in a fixed order into
- * dW [D, F], db [D]: bitwise reproducible.
+ * demb[B, 2D] and is expanded on chip with `emb` (ties of the max split evenly) -- or, poolbits != NULL, with the
+ * training form's bits (dout, emb, out = NULL then).  dx nullable (first layer).  Leaves one partial slab
+ * [D*KPAD + D] per workgroup in `workspace` (hcg_fused_workspace_bytes); stage 2 = hcg_fused_reduce_job + hcg_step_tail
+ * sums them in a fixed order into dW [D, F], db [D]: bitwise reproducible.
  * apply_act here is a bit set: bit 0 = multiply the upstream gradient by LeakyReLU'(out) (as in the forward);
  * bit 1 = hand dx down ALREADY multiplied by LeakyReLU'(x) -- x being the previous layer's activated output, whose
  * rows this kernel holds anyway -- so that layer's backward is called with bit 0 clear and `out` = NULL and never
- * reads its own output.  `out` is only required with bit 0 set or in the pooled form. */
+ * reads its own output.  `out` is only required with bit 0 set or in the pooled form without poolbits. */
 int hcg_fused_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
-                        const float* out, const float* x, const float* W,
+                        const float* out, const uint32_t* poolbits /*nullable*/, const float* x, const float* W,
                         const int64_t* edge_index, int64_t E,
                         const int32_t* graph_ptr, const int32_t* edge_ptr,
                         int64_t N, int64_t B, int64_t F, int64_t D,
                         int graphs_per_tile, float slope, int apply_act,
                         float* dx /*nullable*/, int32_t* status,
                         void* workspace, size_t workspace_bytes, hcg_stream_t stream);
-int hcg_fused_reduce_grads(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B,
-                           int64_t F, int64_t D, int graphs_per_tile, float* dW, float* db,
-                           hcg_stream_t stream);
-/* Training forms of the POOLED (last) conv layer: its node activations never reach HBM.  All the pooled backward needs
- * of them is, per element, the sign (LeakyReLU') and whether it is its graph's column maximum (torch amax backward:
- * ties share the gradient evenly) -- they leave as two bits per element, `poolbits` (hcg_fused_poolbits_bytes: 512 B per
- * 32-row tile, in the matrix-core accumulator layout), and hcg_fused_layer_bwd_poolbits over the SAME plan and
- * graphs_per_tile reads them in place of `out` and `emb`.  emb is required; everything else as in the plain forms
- * (apply_act bit 1 of the backward = premasked dx, see hcg_fused_layer_bwd).  Gradients equal the plain forms' up to
- * the summation order of db. */
-size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile);
-int hcg_fused_layer_fwd_train(const float* x, const float* W, const float* b,
-                              const int64_t* edge_index, int64_t E,
-                              const int32_t* graph_ptr, const int32_t* edge_ptr,
-                              int64_t N, int64_t B, int64_t F, int64_t D,
-                              int graphs_per_tile, float slope, int apply_act,
-                              float* emb, uint32_t* poolbits, int32_t* status, hcg_stream_t stream);
-int hcg_fused_stack2_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                               const int64_t* edge_index, int64_t E,
-                               const int32_t* graph_ptr, const int32_t* edge_ptr,
-                               int64_t N, int64_t B, int64_t F, int64_t D,
-                               int graphs_per_tile, float slope, int apply_act,
-                               float* out1, float* emb, uint32_t* poolbits, int32_t* status, hcg_stream_t stream);
-int hcg_fused_layer_bwd_poolbits(const float* demb, const uint32_t* poolbits, const float* x, const float* W,
-                                 const int64_t* edge_index, int64_t E,
-                                 const int32_t* graph_ptr, const int32_t* edge_ptr,
-                                 int64_t N, int64_t B, int64_t F, int64_t D,
-                                 int graphs_per_tile, float slope, int apply_act,
-                                 float* dx /*nullable*/, int32_t* status,
-                                 void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
 /* ---- fused per-layer kernels for batches of MID-SIZE graphs: one graph per workgroup, <= 224 nodes and <= 1024
  * directed edges per graph, D = 64 or 128 (two 64-column halves, one launch each), F <= 128 (contracted in chunks of 64)
  * -- the size range of the reference's own reaction graphs (56-184 atoms, F = 25 / 32) and of BASELINE's large-ligand
  * configuration (200 nodes, 128-d).  Same contract as hcg_fused_layer_*: raw int64 edge_index grouped by graph + graph_ptr / edge_ptr of
  * a BLOCKED plan, gcn_norm and the CSR rebuilt on chip per graph, unweighted edges, optional pooled epilogue /
- * pooled-gradient prologue, per-workgroup gradient slabs (hcg_mid_reduce_job + hcg_reduce_slabs).
+ * pooled-gradient prologue, per-workgroup gradient slabs (hcg_mid_reduce_job + hcg_step_tail).
  * `max_nodes` / `max_edges` = largest graph of the batch (host metadata; sizes the dynamic LDS); a graph that exceeds
  * them is skipped and flagged HCG_STATUS_SHAPE_LIMIT.  apply_act of hcg_mid_layer_bwd is the same bit set as in
  * hcg_fused_layer_bwd (bit 1 = premasked dx; `out` nullable when bit 0 is clear and dout is given). */
@@ -248,7 +261,7 @@ int hcg_mid_layer_bwd(const float* dout /*nullable*/, const float* demb, const f
  * BLOCKED plan, gcn_norm rebuilt on chip per graph, pooled epilogue / pooled-gradient prologue, apply_act bits of
  * hcg_fused_layer_bwd); F a multiple of 4, <= 128.  The forward needs the workspace too (H = x W^T makes a round trip).
  * hcg_tall_layer_bwd leaves dW / db slabs in the workspace: hcg_tall_reduce_jobs fills TWO jobs (dW, db) for
- * hcg_reduce_slabs.  Replaces the same PyG GCNConv call sites (model/gcn.py:58-63) and their autograd. */
+ * hcg_step_tail.  Replaces the same PyG GCNConv call sites (model/gcn.py:58-63) and their autograd. */
 int hcg_tall_supported(int64_t F, int64_t D, int64_t max_nodes_per_graph, int64_t max_edges_per_graph);
 size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int64_t D);
 int hcg_tall_layer_fwd(const float* x, const float* W, const float* b,
@@ -276,46 +289,37 @@ int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const 
                      float* demb, float* dW0, float* db0, float* dW1, float* db1,
                      void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
-/* ---- regression head, forward + loss + backward in ONE launch (a10 + a12 + their backward; f2) -------------
+/* ---- regression head: readout forward, squared error, readout backward in ONE launch (a10 + a12 + their backward; f2)
  * The reference's step runs  out = readout(emb); loss = torch.sqrt(MSELoss()(out, y.unsqueeze(1)));
- * loss.backward()  (model/gcn.py:70-71, utils/utils_model.py:64-65): here one kernel with a grid barrier.
- *   z [B,D], out [B,C] : forward results;  loss[0] = rmse ? sqrt(mse) : mse, loss[1] = mse
- *   demb [B,2D]        : d loss / d emb (upstream gradient 1)
- *   workspace          : gradient slabs (describe them with hcg_head_reduce_job, sum with hcg_reduce_slabs)
- *   sync               : HCG_HEAD_SYNC_WORDS int32 device words, all zero before the first launch ever and owned
- *                        by this entry point afterwards (state of the grid-wide exchange of the squared-error
- *                        partials).  Launches that share one set of words MUST be stream-ordered: give every stream
- *                        (every trainer) its own set.  The exchange is bounded: a workgroup that has waited 2 s ORs
- *                        HCG_HEAD_ERR_TIMEOUT into sync[1] and the launch ends with a NaN loss instead of hanging;
- *                        after that the words must be re-zeroed before they are used again
+ * loss.backward()  (model/gcn.py:70-71, utils/utils_model.py:64-65).  The whole backward is LINEAR in the one number
+ * that needs every graph of the batch, dloss/dout = scale * (out - y) with scale = 1 / (B C sqrt(MSE)): so this kernel --
+ * and every conv backward launch behind it -- runs on the UNSCALED error (the gradients of SSE / 2), every workgroup
+ * leaves ONE partial sum of squared errors in its slab, and the step's last launch (hcg_step_tail) adds the partials in
+ * a fixed order, derives loss and scale and multiplies each gradient element as it reduces it.  No grid-wide exchange
+ * (round 2's head kernel spent a grid barrier, 520 sync words and a time-out path on that scalar), any grid size.
+ *   z [B,D], out [B,C] : forward results
+ *   demb [B,2D]        : d (SSE / 2) / d emb  -- unscaled
+ *   workspace          : gradient slabs + SSE partials (describe them with hcg_head_reduce_job)
  *   step_counter       : nullable; one int32 device word incremented by 1 per launch -- the number of the training
- *                        step, read later in the same step by hcg_reduce_slabs_adam
+ *                        step, read later in the same step by hcg_step_tail's update
+ *   flags              : HCG_HEAD_FORWARD_ONLY = no backward (demb / gradient slabs untouched; the partials are written)
  * y is [B,C] like out.  D = 64 or 128 (8 waves per workgroup, W0 fragments from L2 instead of LDS), C <= 8
  * (hcg_head_supported). */
-#define HCG_HEAD_SYNC_WORDS 520
-#define HCG_HEAD_ERR_TIMEOUT 1 /* bit of sync[1] */
-#define HCG_HEAD_SSE 2         /* value of `rmse` for hcg_head_fwd_bwd_ex: see there */
+#define HCG_HEAD_FORWARD_ONLY 1
 int hcg_head_supported(int64_t D, int64_t C);
-size_t hcg_head_workspace_bytes(int64_t B);                 /* D = 64 */
-size_t hcg_head_workspace_bytes_d(int64_t B, int64_t D);    /* D = 64 or 128 */
+size_t hcg_head_workspace_bytes(int64_t B, int64_t D);
 int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
-                     const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
-                     float* z, float* out, float* loss, float* demb,
-                     void* workspace, size_t workspace_bytes, int32_t* sync, int32_t* step_counter /*nullable*/,
-                     hcg_stream_t stream);
+                     const float* b1, int64_t B, int64_t D, int64_t C, float slope, int flags,
+                     float* z, float* out, float* demb, void* workspace, size_t workspace_bytes,
+                     int32_t* step_counter /*nullable*/, hcg_stream_t stream);
 
-/* The same launch with the data-parallel "sum of squared errors" form: rmse = HCG_HEAD_SSE leaves every gradient
- * (demb and the slabs) as that of SSE / 2 -- dloss/dout = (out - y), no batch-dependent factor -- and stores the
- * batch's SSE and its element count B * C in sse_tail[0..1] (the two floats behind the flat gradient buffer).  Ranks sum
- * gradients, SSE and count (ONE all-reduce) and hcg_sse_finalize / hcg_adam_step_dev_sse scale by
- * 1 / (count * sqrt(SSE / count)): the gradient of sqrt(MSE) over the concatenated batch of all ranks, which is what
- * the reference's step computes on one device (utils/utils_model.py:64-65).  rmse = 0 / 1 as hcg_head_fwd_bwd
- * (sse_tail nullable; written when given). */
-int hcg_head_fwd_bwd_ex(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,
-                        const float* b1, int64_t B, int64_t D, int64_t C, float slope, int rmse,
-                        float* z, float* out, float* loss, float* demb,
-                        void* workspace, size_t workspace_bytes, int32_t* sync, int32_t* step_counter /*nullable*/,
-                        float* sse_tail /*nullable unless rmse = HCG_HEAD_SSE*/, hcg_stream_t stream);
+/* loss modes of hcg_step_tail / hcg_loss_finalize / hcg_loss_fwd_bwd */
+#define HCG_LOSS_MSE 0  /* nn.MSELoss                                  : scale 2 / count            */
+#define HCG_LOSS_RMSE 1 /* torch.sqrt(nn.MSELoss) (the reference's step): scale 1 / (count sqrt(MSE)) */
+#define HCG_LOSS_SSE 2  /* data parallel with a collective: gradients stay those of SSE / 2, [SSE, count] go to sse_tail;
+                           ranks sum gradients, SSE and count (ONE all-reduce) and hcg_sse_finalize / hcg_adam_step_dev_sse
+                           scale by 1 / (count sqrt(SSE / count)): the gradient of sqrt(MSE) over the concatenated batch of
+                           all ranks, which is what the reference's step computes on one device */
 
 /* ---- MSE loss (a12 / f2): loss[0] = mean((a - b)^2) over n elements, fixed-order reduction;
  *      backward: da = grad_loss[0] * 2 (a - b) / n, db = -da (either may be NULL). */
@@ -324,14 +328,14 @@ int hcg_mse_bwd(const float* a, const float* b, const float* grad_loss, int64_t 
                 float* da /*nullable*/, float* db /*nullable*/, hcg_stream_t stream);
 
 /* Loss AND its gradient in one launch, for heads the fused kernel does not cover (other widths): mode 0 = MSE,
- * 1 = sqrt(MSE) (the reference's step, utils/utils_model.py:64), HCG_HEAD_SSE = unscaled da = a - b with [SSE, n] stored
- * in sse_tail (see hcg_head_fwd_bwd_ex).  loss[0] = the loss, loss[1] = MSE; da [n] = d loss / d a. */
+ * 1 = sqrt(MSE) (the reference's step, utils/utils_model.py:64), HCG_LOSS_SSE = unscaled da = a - b with [SSE, n] stored
+ * in sse_tail.  loss[0] = the loss, loss[1] = MSE; da [n] = d loss / d a. */
 int hcg_loss_fwd_bwd(const float* a, const float* b, int64_t n, int mode, float* loss, float* da,
-                     float* sse_tail /*nullable unless mode = HCG_HEAD_SSE*/, hcg_stream_t stream);
+                     float* sse_tail /*nullable unless mode = HCG_LOSS_SSE*/, hcg_stream_t stream);
 
 /* ---- batched slab reduction: ONE launch for all pending gradient reductions of a backward pass.
  * hcg_fused_layer_bwd and hcg_readout2_bwd_partial leave per-workgroup slabs in their workspaces;
- * hcg_fused_reduce_job / hcg_readout2_reduce_job describe them (host-side, no launch), hcg_reduce_slabs
+ * hcg_fused_reduce_job / hcg_readout2_reduce_job describe them (host-side, no launch), hcg_step_tail
  * sums up to HCG_REDUCE_MAX_JOBS of them in a fixed order. */
 #define HCG_REDUCE_MAX_JOBS 8
 #define HCG_REDUCE_MAX_SEGS 4
@@ -342,7 +346,9 @@ typedef struct hcg_reduce_seg {
 } hcg_reduce_seg;
 typedef struct hcg_reduce_job {
   const float* slabs;        /* [nslabs][slab_floats] */
-  int32_t nslabs, slab_floats, nseg, reserved;
+  int32_t nslabs, slab_floats, nseg;
+  int32_t sse_index;         /* > 0: element `sse_index` of every slab is that workgroup's partial sum of squared errors
+                                (the head's job: hcg_head_reduce_job / hcg_fused_head_reduce_job); 0 = none */
   hcg_reduce_seg seg[HCG_REDUCE_MAX_SEGS];
 } hcg_reduce_job;
 size_t hcg_reduce_job_bytes(void);
@@ -359,13 +365,59 @@ int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B,
 /* job_host[0] = dW [D, F], job_host[1] = db [D] of hcg_tall_layer_bwd */
 int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
                          float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
-int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+/* the head's slabs; job_host->sse_index names the SSE partial of each.  dW0 == NULL (forward-only head): no segments,
+ * the job then only carries the partials (hcg_loss_finalize) */
+int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
-int hcg_head_reduce_job_d(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C,
-                          float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 /* `more` (same slab geometry and destinations, slabs directly behind `job`'s) becomes part of `job`: one fixed-order sum */
 int hcg_reduce_job_append(hcg_reduce_job* job_host, const hcg_reduce_job* more_host);
-int hcg_reduce_slabs(const hcg_reduce_job* jobs_host, int njobs, hcg_stream_t stream);
+
+/* ---- the step tail: ONE launch behind the backward launches of a training step (f2) --------------------------------
+ *   (1) every pending slab reduction (jobs_host[0 .. njobs)), each output element summed in a fixed order;
+ *   (2) the loss and its deferred scale: when a job carries SSE partials (sse_index), loss[0] = the loss (`loss_mode`),
+ *       loss[1] = MSE, and every reduced element is multiplied by the scale (see hcg_head_fwd_bwd); HCG_LOSS_SSE leaves the
+ *       gradients unscaled and stores this rank's [SSE, count] in sse_tail;
+ *   (3) inbox != NULL: the data-parallel one-shot exchange over xGMI (below) between reduction and update;
+ *   (4) param != NULL: torch.optim.Adam's update of the parameter / moments at the offset of each gradient element in the
+ *       flat buffer [grad_flat, grad_flat + n) -- every segment's dst must point into it and every element of it must be
+ *       covered by exactly one segment; `step_dev[0]` = 1-based number of THIS update, already advanced when the kernel
+ *       runs (the head launch's step_counter does that earlier in the step; this launch only reads it), lr_dev[0] = lr;
+ *   (5) next_batch != NULL: the pointers-only plan of the NEXT batch (what hcg_plan_build does with HCG_PLAN_BLOCKED |
+ *       HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS): the one launch of the next step that depends on nothing of this one.
+ * Replaces the four hcg_reduce_slabs* entry points of round 2 (one symbol per fusion combination).  HOST struct; zero it
+ * first, unused parts stay NULL. */
+typedef struct hcg_tail_args {
+  const hcg_reduce_job* jobs_host;
+  int32_t njobs;
+  int32_t loss_mode;           /* HCG_LOSS_*; only read when a job has sse_index > 0 */
+  float loss_count;            /* elements of the squared-error sum on this rank: B * C */
+  float beta1, beta2, eps;
+  float* loss;                 /* [2], nullable without exchange */
+  float* sse_tail;             /* [2], nullable */
+  float* grad_flat;            /* [n] ([n + 2] with an exchange: gradients | SSE | count) */
+  float* param;                /* NULL = no update */
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  const float* lr_dev;
+  const int32_t* step_dev;
+  const int64_t* next_edge_index;
+  const int64_t* next_batch;   /* NULL = no plan */
+  int64_t next_N, next_E, next_B;
+  int32_t* next_graph_ptr;
+  int32_t* next_edge_ptr;
+  int32_t* next_status;
+  void* inbox;                 /* NULL = no exchange */
+  void* const* peers_host;     /* HOST array of `world` device pointers (peers_host[rank] = inbox) */
+  int32_t rank, world, xchg_mode;
+  int32_t reserved;
+  int32_t* xchg_err;
+} hcg_tail_args;
+size_t hcg_tail_args_bytes(void);
+int hcg_step_tail(const hcg_tail_args* args_host, hcg_stream_t stream);
+/* forward-only steps (the reference's eval_network body, utils/utils_model.py:75-78): the loss alone from a head job's partials */
+int hcg_loss_finalize(const hcg_reduce_job* head_job_host, float count, int loss_mode, float* loss,
+                      float* sse_tail /*nullable*/, hcg_stream_t stream);
 
 /* ---- Adam update (f2) over one contiguous fp32 segment: torch.optim.Adam's rule (amsgrad / weight_decay /
  *      maximize off).  `step` = 1-based count of this update.  One launch. */
@@ -379,7 +431,7 @@ int hcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int hcg_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, hcg_stream_t stream);
 
-/* Data-parallel SSE form (hcg_head_fwd_bwd_ex): `flat` = [n summed SSE/2-gradients | SSE | count].  Scales the n
+/* Data-parallel SSE form (HCG_LOSS_SSE): `flat` = [n summed SSE/2-gradients | SSE | count].  Scales the n
  * gradients in place by 1 / (count * L), L = sqrt(SSE / count), and stores loss[0] = L, loss[1] = SSE / count.
  * hcg_adam_step_dev_sse does the same and applies hcg_adam_step_dev's update with the scaled gradient: one launch. */
 int hcg_sse_finalize(float* flat, int64_t n, float* loss, hcg_stream_t stream);
@@ -387,56 +439,34 @@ int hcg_adam_step_dev_sse(float* param, float* flat, float* exp_avg, float* exp_
                           const float* lr_dev, float beta1, float beta2, float eps, int32_t* step_dev, float* loss,
                           hcg_stream_t stream);
 
-/* hcg_reduce_slabs with the Adam update fused in: every reduced gradient element is stored at its place in the flat
- * gradient buffer [grad_flat, grad_flat + n) -- each segment's dst must point into it -- and the parameter / moments
- * at the same offset are updated at once (one launch instead of two; same rule as hcg_adam_step_dev).
- * `step_dev[0]` = 1-based number of THIS update, already advanced when the kernel runs (hcg_head_fwd_bwd's
- * step_counter does that earlier in the step; this launch only reads it).  Every element of the flat buffer must be
- * covered by exactly one segment. */
-int hcg_reduce_slabs_adam(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
-                          float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
-                          float eps, const int32_t* step_dev, hcg_stream_t stream);
-
-/* The same launch also derives the pointers-only plan of the NEXT batch (what hcg_plan_build does with
- * HCG_PLAN_BLOCKED | HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS: graph_ptr, edge_ptr, validation flags ORed into `status`):
- * the one launch of the next step that depends on nothing of this one rides in this step's last launch. */
-int hcg_reduce_slabs_adam_plan(const hcg_reduce_job* jobs_host, int njobs, const float* grad_flat, float* param_flat,
-                               float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
-                               float eps, const int32_t* step_dev, const int64_t* next_edge_index, const int64_t* next_batch,
-                               int64_t N, int64_t E, int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr,
-                               int32_t* next_status, hcg_stream_t stream);
-
 /* ---- data parallel: one-shot gradient exchange over xGMI, fused between the slab reduction and the update ------------
  * Every rank owns an inbox (hcg_xchg_inbox_bytes: 2 x world x (n + 2) eight-byte {value, step} granules) in fine-grained
- * device memory (hcg_xchg_alloc: the one allocation this library makes), exports it (hcg_xchg_ipc_export -> 64-byte handle,
- * exchanged by the host through torch.distributed) and maps its peers' (hcg_xchg_ipc_open).  hcg_reduce_slabs_xchg_adam =
- * hcg_reduce_slabs_adam where every reduced element is first written into all peers' inboxes (one 8-byte system-scope store
- * per peer, over the direct links), the peers' contributions are polled out of the own inbox and added in rank order, and
- * the update runs on the total: `mode` HCG_XCHG_MEAN divides by `world`; HCG_XCHG_SSE applies the SSE form's scale
- * (flat_ext[n], [n + 1] = this rank's SSE and count from hcg_head_fwd_bwd_ex; loss[0..1] = the global sqrt(MSE), MSE).
- * Polls are bounded (2 s): HCG_XCHG_ERR_TIMEOUT is ORed into err[0] and the element becomes NaN.  `step_dev[0]` (advanced
- * earlier in the step by the head kernel) stamps the granules: it must advance by one per exchange on every rank, and an
- * inbox must be re-zeroed before it serves another optimiser.  peers: HOST array of `world` device pointers (peers[rank] =
- * inbox).  next_batch != NULL: also derives the next batch's plan (hcg_reduce_slabs_adam_plan). */
+ * device memory (hcg_xchg_alloc: the ONE allocation this library makes -- ordinary device memory does not make a peer's
+ * stores visible to a running kernel), exports it (hcg_xchg_ipc_export -> 64-byte handle, exchanged by the host through
+ * torch.distributed) and maps its peers' (hcg_xchg_ipc_open).  hcg_step_tail with `inbox` set: every reduced element is
+ * first written into all peers' inboxes (one 8-byte system-scope store per peer, over the direct links), the peers'
+ * contributions are polled out of the own inbox and added in rank order, and the update runs on the total: xchg_mode
+ * HCG_XCHG_MEAN = mean over the ranks of each rank's own loss gradient; HCG_XCHG_SSE = the gradient of sqrt(MSE) over the
+ * concatenated batch (SSE and count travel as elements n, n + 1: from the head's partials, or, without a job that carries
+ * them, from grad_flat[n], [n + 1]; loss[0..1] = the global sqrt(MSE), MSE).  Polls are bounded (2 s): HCG_XCHG_ERR_TIMEOUT
+ * is ORed into xchg_err[0] and the element becomes NaN.  `step_dev[0]` stamps the granules: it must advance by one per
+ * exchange on every rank, and an inbox must be re-zeroed before it serves another optimiser. */
 #define HCG_XCHG_MAX_WORLD 8
 #define HCG_XCHG_HANDLE_BYTES 64
 #define HCG_XCHG_MEAN 0
 #define HCG_XCHG_SSE 1
 #define HCG_XCHG_ERR_TIMEOUT 1
 size_t hcg_xchg_inbox_bytes(int64_t n, int world);
+/* workgroups of the exchanging hcg_step_tail that are resident at once on this device (occupancy x CUs).  A launch whose
+ * jobs need more polling workgroups (sum over the jobs of ceil(slab_floats / 32)) is refused with HCG_ERR_UNSUPPORTED: two
+ * ranks' resident pollers could otherwise wait on each other's queued publishers until the bounded polls expire */
+int hcg_xchg_resident_blocks(void);
 int hcg_xchg_alloc(size_t bytes, void** ptr);
 int hcg_xchg_free(void* ptr);
 int hcg_xchg_zero(void* ptr, size_t bytes);
 int hcg_xchg_ipc_export(void* ptr, void* handle64);
 int hcg_xchg_ipc_open(const void* handle64, void** ptr);
 int hcg_xchg_ipc_close(void* ptr);
-int hcg_reduce_slabs_xchg_adam(const hcg_reduce_job* jobs_host, int njobs, float* flat_ext, float* param_flat,
-                               float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev, float beta1, float beta2,
-                               float eps, const int32_t* step_dev, void* inbox, void* const* peers_host, int rank, int world,
-                               int mode, float* loss, int32_t* err,
-                               const int64_t* next_edge_index, const int64_t* next_batch /*nullable: no plan*/, int64_t N,
-                               int64_t E, int64_t B, int32_t* next_graph_ptr, int32_t* next_edge_ptr, int32_t* next_status,
-                               hcg_stream_t stream);
 
 /* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),

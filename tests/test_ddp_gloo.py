@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 `gloo` run of the batch-of-graphs data-parallel wrapper
+"""N > 1 path on CPU: world_size-2 and world_size-8 `gloo` runs of the batch-of-graphs data-parallel wrapper
 (hcatgnet_amd/ddp.py).  Only the exchange logic runs here (flat gradient buffer all-reduce +
 parameter broadcast) -- no kernel is called; on the GPU box the same code runs over RCCL."""
 import os
@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     try:
         torch.manual_seed(0)
         model = H.make_network("GCN", H.default_options(), 64)
-        if rank == 1:                                   # diverge rank 1 on purpose: the wrapper must re-sync
+        if rank >= 1:                                   # diverge the other ranks on purpose: the wrapper must re-sync
             with torch.no_grad():
                 for p in model.parameters():
                     p.add_(1.0)
@@ -36,9 +36,10 @@ def _worker(rank, world, port, q):
         for i, p in enumerate(model.parameters()):
             p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
         flat = dp.reduce_gradients()
-        expect = torch.cat([torch.full((p.numel(),), 1.5 * (i + 1)) for i, p in enumerate(model.parameters())])
+        mean, total = (world + 1) / 2.0, world * (world + 1) / 2.0          # of (rank + 1) over the ranks
+        expect = torch.cat([torch.full((p.numel(),), mean * (i + 1)) for i, p in enumerate(model.parameters())])
         ok_flat = torch.allclose(flat, expect) and flat.numel() == 16641      # 4096+64+4096+64+8192+64+64+1
-        ok_views = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) and p.grad.data_ptr() != 0
+        ok_views = all(torch.allclose(p.grad, torch.full_like(p, mean * (i + 1))) and p.grad.data_ptr() != 0
                        for i, p in enumerate(model.parameters()))
         # the module surface the reference loops read is forwarded
         ok_attrs = dp.optimizer is model.optimizer and dp.loss is model.loss and dp.scheduler is model.scheduler
@@ -46,31 +47,34 @@ def _worker(rank, world, port, q):
         for i, p in enumerate(model.parameters()):
             p.grad = torch.full_like(p, float(rank + 1))
         s = dp.reduce_gradients(average=False)
-        ok_sum = torch.allclose(s, torch.full_like(s, 3.0))
+        ok_sum = torch.allclose(s, torch.full_like(s, total))
         # the hook of the fused trainer: one flat buffer (what the fused backward writes), averaged IN PLACE
         fb = torch.full((16641,), float(rank + 1))
         out = dp.reduce_flat(fb)
-        ok_hook = out.data_ptr() == fb.data_ptr() and torch.allclose(fb, torch.full_like(fb, 1.5))
+        ok_hook = out.data_ptr() == fb.data_ptr() and torch.allclose(fb, torch.full_like(fb, mean))
         # the "sse" form's hook: [gradients | SSE | count] is SUMMED over the ranks, never divided
         ext = torch.full((16643,), float(rank + 1))
         out2 = dp.reduce_flat_sum(ext)
-        ok_sse = out2.data_ptr() == ext.data_ptr() and torch.allclose(ext, torch.full_like(ext, 3.0))
+        ok_sse = out2.data_ptr() == ext.data_ptr() and torch.allclose(ext, torch.full_like(ext, total))
         q.put((rank, same, ok_flat, ok_views, ok_attrs, ok_sum, ok_hook, ok_sse))
     finally:
         dist.destroy_process_group()
 
 
-def test_gradient_allreduce_and_broadcast_world2_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_allreduce_and_broadcast_gloo(world):
+    """world 8 = the size the driver's scaling tier runs (BASELINE configs[3]); every rank must come back."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
     for r in res:
         assert all(r[1:]), r
 

@@ -245,8 +245,7 @@ def test_two_trainers_on_two_streams_do_not_share_exchange_words(H):
             xb = tb(bb)
         got.append((xa, xb))
     torch.cuda.synchronize()
-    ta.check_health(); tb.check_health()
-    assert ta._sync_words(torch.device("cuda", 0)).data_ptr() != tb._sync_words(torch.device("cuda", 0)).data_ptr()
+    assert ta._bufs["cap"]["ws_head"].data_ptr() != tb._bufs["cap"]["ws_head"].data_ptr()    # nothing shared between trainers
     assert abs(float(got[-1][0]) - la) <= 1e-6 * abs(la) and abs(float(got[-1][1]) - lb) <= 1e-6 * abs(lb)
 
 

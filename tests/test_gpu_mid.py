@@ -266,7 +266,7 @@ def test_mid_backward_hands_down_a_premasked_dx(H, D, feat):
         for half in range(D // 64):
             _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, F_, D, mxn, mxe, half, p(dW), p(db), ctypes.addressof(jobs) + half * jb),
                        "hcg_mid_reduce_job")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), D // 64, st), "hcg_reduce_slabs")
+        _lib.reduce_jobs(ctypes.addressof(jobs), D // 64)
         return dx, dW, db
 
     dx, dW, db = bwd(dout, out, x, W, feat, 1)

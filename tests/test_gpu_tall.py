@@ -127,7 +127,7 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
         jb = lib.hcg_reduce_job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
         _lib.check(lib.hcg_tall_reduce_jobs(p(ws), wsb, N, B, F_, D, p(dW), p(db), ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(jobs), 2, st), "hcg_reduce_slabs")
+        _lib.reduce_jobs(ctypes.addressof(jobs), 2)
         return dx, dW, db
 
     dx_plain, dW_a, db_a = bwd(dout, out, x, W, feat, 1)

@@ -18,9 +18,10 @@ TOL = 1e-5
 @pytest.mark.parametrize("B,C,rmse,D", [(1, 1, 1, 64), (31, 1, 1, 64), (32, 3, 1, 64), (4096, 1, 1, 64), (4096, 8, 0, 64), (9000, 2, 1, 64),
                                         (1, 1, 1, 128), (33, 3, 1, 128), (1024, 1, 1, 128), (1024, 8, 0, 128), (9000, 2, 1, 128)])
 def test_head_forward_loss_backward_one_launch(H, B, C, rmse, D):
-    """out / loss / demb / weight gradients of hcg_head_fwd_bwd vs torch fp64 autograd of
-    sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes workgroups loop over several tiles; D = 128 is the
-    8-wave form with W0 read from L2 (BASELINE configs[4])."""
+    """hcg_head_fwd_bwd + hcg_step_tail: out / z, the UNSCALED demb, and -- after the tail applied the deferred loss scale --
+    loss and weight gradients vs torch fp64 autograd of sqrt(mse_loss(Linear(LeakyReLU(Linear(emb))), y)); B = 9000 makes
+    workgroups loop over several tiles; D = 128 is the 8-wave form with W0 read from L2 (BASELINE configs[4]); the
+    forward-only form + hcg_loss_finalize gives the same loss."""
     from hcatgnet_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(7 * B + C)
@@ -29,22 +30,23 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse, D):
     d = [t.cuda().contiguous() for t in (emb, y, W0, b0, W1, b1)]
     z = torch.empty(B, D, device="cuda"); out = torch.empty(B, C, device="cuda"); loss = torch.empty(2, device="cuda")
     demb = torch.empty(B, 2 * D, device="cuda")
-    wsb = lib.hcg_head_workspace_bytes_d(B, D)
-    assert D != 64 or wsb == lib.hcg_head_workspace_bytes(B)
+    wsb = lib.hcg_head_workspace_bytes(B, D)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    sync = torch.zeros(_lib.HCG_HEAD_SYNC_WORDS, dtype=torch.int32, device="cuda")    # this caller's own exchange words
     grads = [torch.empty_like(t) for t in d[2:]]
+    step = torch.zeros(2, dtype=torch.int32, device="cuda")
     p = _lib.ptr
-    for rep in range(2):        # twice: the exchange words must be reusable launch after launch
-        rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, D, C, 0.01, rmse, p(z), p(out),
-                                  p(loss), p(demb), p(ws), wsb, p(sync), None, _lib.stream_ptr())
+    mode = _lib.HCG_LOSS_RMSE if rmse else _lib.HCG_LOSS_MSE
+    for rep in range(2):
+        rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, D, C, 0.01, 0, p(z), p(out),
+                                  p(demb), p(ws), wsb, p(step), _lib.stream_ptr())
         _lib.check(rc, "hcg_head_fwd_bwd")
-        job = ctypes.create_string_buffer(lib.hcg_reduce_job_bytes())
-        _lib.check(lib.hcg_head_reduce_job_d(p(ws), wsb, B, D, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
-                                             ctypes.addressof(job)), "hcg_head_reduce_job_d")
-        _lib.check(lib.hcg_reduce_slabs(ctypes.addressof(job), 1, _lib.stream_ptr()), "hcg_reduce_slabs")
+        job = _lib.ReduceJob()
+        _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, D, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
+                                           ctypes.addressof(job)), "hcg_head_reduce_job")
+        assert job.sse_index > 0 and job.nseg == 4
+        _lib.step_tail(ctypes.addressof(job), 1, loss=loss, loss_mode=mode, loss_count=float(B * C))
         torch.cuda.synchronize()
-        assert int(sync[0]) >= rep + 1        # generation advanced once per launch
+        assert int(step[0]) == rep + 1        # the step number advanced once per launch
     ref = [t.double().requires_grad_(True) for t in (emb, W0, b0, W1, b1)]
     zr = F.leaky_relu(F.linear(ref[0], ref[1], ref[2]), 0.01)
     r = F.linear(zr, ref[3], ref[4])
@@ -54,9 +56,20 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse, D):
     assert rel_inf(out, r) <= TOL and rel_inf(z, zr) <= TOL
     lref, mse = lref.detach(), mse.detach()
     assert abs(float(loss[0]) - float(lref)) <= TOL * float(lref) and abs(float(loss[1]) - float(mse)) <= TOL * float(mse)
-    assert rel_inf(demb, ref[0].grad) <= TOL
+    scale = 1.0 / (B * C * float(torch.sqrt(mse))) if rmse else 2.0 / (B * C)         # dloss/dout = scale * (out - y)
+    assert rel_inf(demb.double() * scale, ref[0].grad) <= TOL
     for a, b in zip(grads, ref[1:]):
         assert rel_inf(a, b.grad) <= TOL
+    # forward only: z / out / partials, no gradient; the loss alone from the partials
+    z2 = torch.zeros_like(z); out2 = torch.zeros_like(out); loss2 = torch.zeros(2, device="cuda")
+    rc = lib.hcg_head_fwd_bwd(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), B, D, C, 0.01, _lib.HCG_HEAD_FORWARD_ONLY,
+                              p(z2), p(out2), None, p(ws), wsb, None, _lib.stream_ptr())
+    _lib.check(rc, "hcg_head_fwd_bwd")
+    job = _lib.ReduceJob()
+    _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, D, C, None, None, None, None, ctypes.addressof(job)), "hcg_head_reduce_job")
+    assert job.nseg == 0
+    _lib.check(lib.hcg_loss_finalize(ctypes.addressof(job), float(B * C), mode, p(loss2), None, _lib.stream_ptr()), "hcg_loss_finalize")
+    assert torch.equal(z2, z) and torch.equal(out2, out) and torch.equal(loss2, loss)
 
 
 def _oracle_grads(oracle, m, sb):
@@ -348,6 +361,14 @@ def test_fused_adam_state_dict_round_trip_in_capturable_mode(H):
         assert torch.equal(pa, pb)
 
 
+def _fused_reduce(lib, _lib, ws, wsb, N, B, F_, D, gpt, dW, db):
+    """hcg_fused_reduce_job + hcg_step_tail (reduction only): the layer's slabs -> dW, db"""
+    job = _lib.ReduceJob()
+    _lib.check(lib.hcg_fused_reduce_job(_lib.ptr(ws), wsb, N, B, F_, D, gpt, _lib.ptr(dW), _lib.ptr(db), ctypes.addressof(job)),
+               "hcg_fused_reduce_job")
+    _lib.reduce_jobs(ctypes.addressof(job), 1)
+
+
 @pytest.mark.parametrize("feat,pooled", [(64, False), (64, True), (25, False)])
 def test_fused_backward_hands_down_a_premasked_dx(H, feat, pooled):
     """apply_act bit 1 of hcg_fused_layer_bwd: dx leaves the kernel multiplied by LeakyReLU'(x) and the layer below is
@@ -380,10 +401,10 @@ def test_fused_backward_hands_down_a_premasked_dx(H, feat, pooled):
         dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
         dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
         rc = lib.hcg_fused_layer_bwd(p(dout_), p(demb) if dout_ is None else None, p(emb) if dout_ is None else None, p(out_),
-                                     p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, F_, D,
+                                     None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B, F_, D,
                                      gpt, slope, flags, p(dx), p(plan.status), p(ws), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "hcg_fused_layer_bwd")
-        _lib.check(lib.hcg_fused_reduce_grads(p(ws), ws.numel(), N, B, F_, D, gpt, p(dW), p(db), _lib.stream_ptr()), "reduce")
+        _fused_reduce(lib, _lib, ws, ws.numel(), N, B, F_, D, gpt, dW, db)
         return dx, dW, db
 
     dx, dW, db = bwd(dout, out, x, W, feat, 1)
@@ -396,14 +417,14 @@ def test_fused_backward_hands_down_a_premasked_dx(H, feat, pooled):
         _, dW_b, db_b = bwd(dxm, None, x0, W0, 25, 0, want_dx=False)
         assert torch.equal(dW_a, dW_b) and torch.equal(db_a, db_b)
     # misuse is refused, not ignored
-    assert lib.hcg_fused_layer_bwd(p(dx), None, None, None, p(x), p(W), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+    assert lib.hcg_fused_layer_bwd(p(dx), None, None, None, None, p(x), p(W), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                    p(plan.edge_ptr), N, B, feat, D, gpt, slope, 1, None, p(plan.status),
                                    p(torch.empty(wsb, dtype=torch.uint8, device="cuda")), wsb, _lib.stream_ptr()) != 0
 
 
 @pytest.mark.parametrize("nodes,feat,ties", [(30, 64, False), (10, 64, False), (30, 25, False), (7, 64, True), (30, 64, True)])
 def test_training_forms_keep_the_pooled_layer_on_chip(H, nodes, feat, ties):
-    """hcg_fused_*_fwd_train + hcg_fused_layer_bwd_poolbits: the pooled layer's activations are replaced by two bits per
+    """hcg_fused_forward with poolbits + hcg_fused_layer_bwd with poolbits: the pooled layer's activations are replaced by two bits per
     element.  Same arithmetic per element as the plain forms -> emb, out1, dW, dx bitwise equal; db is summed in another
     (fixed) order.  `ties`: W2 = 0 makes every node of a graph the column maximum (gradient split n ways)."""
     from hcatgnet_amd import synth, _lib
@@ -424,31 +445,30 @@ def test_training_forms_keep_the_pooled_layer_on_chip(H, nodes, feat, ties):
     st, geo = _lib.stream_ptr(), (p(plan.edge_index), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, B)
     new = lambda *s: torch.full(s, float("nan"), device="cuda")
     out1, out2, emb = new(N, D), new(N, D), new(B, 2 * D)
-    _lib.check(lib.hcg_fused_stack2_fwd(p(x), p(W1), p(b1), p(W2), p(b2), *geo, feat, D, gpt, slope, 1, p(out1), p(out2), p(emb),
-                                        p(plan.status), st), "stack2")
+    common = dict(edge_index=plan.edge_index, E=plan.E, graph_ptr=plan.graph_ptr, edge_ptr=plan.edge_ptr, N=N, B=B, D=D,
+                  graphs_per_tile=gpt, apply_act=1, slope=slope, status=plan.status)
+    _lib.fused_forward(x=x, W1=W1, b1=b1, W2=W2, b2=b2, F=feat, out1=out1, out2=out2, emb=emb, **common)
     bits = torch.zeros(lib.hcg_fused_poolbits_bytes(B, gpt), dtype=torch.uint8, device="cuda")
     out1t, embt = new(N, D), new(B, 2 * D)
-    _lib.check(lib.hcg_fused_stack2_fwd_train(p(x), p(W1), p(b1), p(W2), p(b2), *geo, feat, D, gpt, slope, 1, p(out1t), p(embt),
-                                              p(bits), p(plan.status), st), "stack2 train")
+    _lib.fused_forward(x=x, W1=W1, b1=b1, W2=W2, b2=b2, F=feat, out1=out1t, emb=embt, poolbits=bits, **common)
     assert torch.equal(out1, out1t) and torch.equal(emb, embt)
     # single pooled layer on its own (the form a stack of != 2 layers ends with): same bits, same emb
     bits1, emb1 = torch.zeros_like(bits), new(B, 2 * D)
-    _lib.check(lib.hcg_fused_layer_fwd_train(p(out1), p(W2), p(b2), *geo, D, D, gpt, slope, 1, p(emb1), p(bits1), p(plan.status),
-                                             st), "layer train")
+    _lib.fused_forward(x=out1, W1=W2, b1=b2, F=D, emb=emb1, poolbits=bits1, **common)
     assert torch.equal(emb1, emb) and torch.equal(bits1, bits)
 
     demb = rnd(B, 2 * D)
     wsb = lib.hcg_fused_workspace_bytes(B, D, D, gpt)
 
-    def run(fn, *lead):
+    def run(*lead):
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
         dx, dW, db = new(N, D), new(D, D), new(D)
-        _lib.check(fn(*lead, p(out1), p(W2), *geo, D, D, gpt, slope, 3, p(dx), p(plan.status), p(ws), wsb, st), "bwd")
-        _lib.check(lib.hcg_fused_reduce_grads(p(ws), wsb, N, B, D, D, gpt, p(dW), p(db), st), "reduce")
+        _lib.check(lib.hcg_fused_layer_bwd(*lead, p(out1), p(W2), *geo, D, D, gpt, slope, 3, p(dx), p(plan.status), p(ws), wsb, st), "bwd")
+        _fused_reduce(lib, _lib, ws, wsb, N, B, D, D, gpt, dW, db)
         return dx, dW, db
 
-    dx, dW, db = run(lib.hcg_fused_layer_bwd, None, p(demb), p(emb), p(out2))
-    dxt, dWt, dbt = run(lib.hcg_fused_layer_bwd_poolbits, p(demb), p(bits))
+    dx, dW, db = run(None, p(demb), p(emb), p(out2), None)
+    dxt, dWt, dbt = run(None, p(demb), None, None, p(bits))
     assert torch.equal(dx, dxt) and torch.equal(dW, dWt)
     assert rel_inf(dbt, db) <= 1e-6
     if ties:        # every node shares the max: db of the max half = sum_g demb_max[g] (n_g shares of 1/n_g each)

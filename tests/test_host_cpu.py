@@ -34,6 +34,24 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert _lib.load().hcg_version() == 1
     assert _lib.load().hcg_error_string(-2) == b"workspace too small"
+    assert len(declared) <= 63, "the ABI grew: fold fusion combinations into an argument struct instead of a new symbol"
+
+
+def test_host_structs_match_the_library():
+    """The ctypes mirrors of the ABI's HOST structs (hcg_reduce_job, hcg_tail_args, hcg_fused_fwd_args) have the library's
+    sizes, and a wrong argument block is refused without touching the GPU."""
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.ReduceJob) == lib.hcg_reduce_job_bytes()
+    assert ctypes.sizeof(_lib.TailArgs) == lib.hcg_tail_args_bytes()
+    assert ctypes.sizeof(_lib.FusedFwdArgs) == lib.hcg_fused_fwd_args_bytes()
+    assert lib.hcg_step_tail(None, None) == -1 and lib.hcg_fused_forward(None, None) == -1
+    a = _lib.TailArgs()
+    assert lib.hcg_step_tail(ctypes.addressof(a), None) == 0            # no jobs, nothing else: nothing to do
+    a.njobs = 1                                                          # jobs announced but not given
+    assert lib.hcg_step_tail(ctypes.addressof(a), None) == -1
+    f = _lib.FusedFwdArgs()
+    f.D, f.F, f.graphs_per_tile = 96, 64, 1
+    assert lib.hcg_fused_forward(ctypes.addressof(f), None) == -3       # unsupported width
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():

@@ -20,9 +20,9 @@ res = []
 for rep in range(REPS):
     a1 = torch.full((N, D), float("nan"), device="cuda"); a2 = torch.full((N, D), float("nan"), device="cuda")
     emb = torch.full((4096, 128), float("nan"), device="cuda")
-    rc = lib.hcg_fused_stack2_fwd(p(x), p(m.conv1.lin.weight), p(m.conv1.bias), p(m.conv_layers[0].lin.weight), p(m.conv_layers[0].bias),
-                                  p(ei), plan.E, p(plan.graph_ptr), p(plan.edge_ptr), N, 4096, 64, D, 1, 0.01, 1, p(a1), p(a2), p(emb), p(plan.status), _lib.stream_ptr())
-    assert rc == 0
+    _lib.fused_forward(x=x, W1=m.conv1.lin.weight, b1=m.conv1.bias, W2=m.conv_layers[0].lin.weight, b2=m.conv_layers[0].bias,
+                       edge_index=ei, E=plan.E, graph_ptr=plan.graph_ptr, edge_ptr=plan.edge_ptr, N=N, B=4096, F=64, D=D,
+                       graphs_per_tile=1, slope=0.01, apply_act=1, out1=a1, out2=a2, emb=emb, status=plan.status)
     torch.cuda.synchronize()
     res.append((a1, a2, emb))
     if rep == 0: print(rep, "nan counts", int(a1.isnan().sum()), int(a2.isnan().sum()), int(emb.isnan().sum()))

@@ -14,7 +14,7 @@ m = H.make_network("GCN", H.default_options(), 64).cuda()
 batch = sb.as_batch("cuda")
 step = FusedTrainStep(m)
 for _ in range(5): step(batch)
-names = ["hcg_fused_stack2_fwd_train", "hcg_head_fwd_bwd_ex", "hcg_fused_layer_bwd_poolbits", "hcg_fused_layer_bwd", "hcg_reduce_slabs_adam"]
+names = ["hcg_fused_forward", "hcg_head_fwd_bwd", "hcg_fused_layer_bwd", "hcg_step_tail"]
 ev = {n: [] for n in names}
 for n in names:
     orig = getattr(lib, n)
