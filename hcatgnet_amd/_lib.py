@@ -35,7 +35,7 @@ class ReduceSeg(ctypes.Structure):
 
 
 class ReduceJob(ctypes.Structure):
-    _fields_ = [("slabs", P), ("nslabs", I32), ("slab_floats", I32), ("nseg", I32), ("sse_index", I32),
+    _fields_ = [("slabs", P), ("sse_part", P), ("nslabs", I32), ("slab_floats", I32), ("nseg", I32), ("reserved", I32),
                 ("seg", ReduceSeg * HCG_REDUCE_MAX_SEGS)]
 
 

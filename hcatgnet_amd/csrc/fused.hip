@@ -304,8 +304,8 @@ struct Stager {
 // HEAD (needs POOL): the regression head rides in the TAIL of this launch (head_tile.h).  A workgroup's tiles are
 // {8 b + w + k * 8 grid}: runs of 8 gpt consecutive graphs per round k; once its waves have left the tile loop their LDS is
 // free, the pooled rows they wrote are visible to the whole workgroup (workgroup-scope barrier), and the workgroup runs
-// readout forward, squared error and -- HEAD == 2 -- the UNSCALED readout backward over its own graphs: z, out, demb and
-// one gradient slab + SSE partial per workgroup.  Round 2 spent a launch of its own (15 us at C3: a grid-wide exchange of
+// readout forward, squared error and -- HEAD == 2 -- the UNSCALED readout backward over its own graphs (head_tile.h:
+// hcg_head16, 16-row tiles on all 8 waves): z, out, demb and one gradient slab + SSE partial per workgroup.  Round 2 spent a launch of its own (15 us at C3: a grid-wide exchange of
 // one scalar on 128 of 256 CUs) on this; the scalar is applied by the step's last launch now (reduce.hip).
 struct FwdHead {
   const float* y;
@@ -321,13 +321,20 @@ struct FwdHead {
   int* step_counter;
 };
 
+constexpr int SEMB_ROWS = 32;    // pooled rows a workgroup keeps in LDS for its head tail (C3: 16 graphs per workgroup)
+
 template <int RC, bool BACKWARD>
-__device__ __forceinline__ void fwd_head_tail(void* lds_base, const FwdHead& H, const float* __restrict__ emb, int gpt, int B,
-                                              int num_tiles, float slope) {
-  using namespace hcg_head;
-  HeadLds<DD>& HL = *reinterpret_cast<HeadLds<DD>*>(lds_base);
-  HeadState<DD, RC> S;
-  head_begin<DD, RC>(HL, S, H.W0, H.b0, H.W1, H.b1, H.C);
+__device__ __forceinline__ void fwd_head_tail(void* lds_base, const float* semb, const FwdHead& H, const float* __restrict__ emb,
+                                              int gpt, int B, int num_tiles, float slope) {
+  using namespace hcg_head16;
+  H16STAMP(0);
+  Prefetch<RC> P;              // the head's weights are requested while the slower waves finish their tiles
+  prefetch<RC>(P, H.W0, H.b0, H.W1, H.C);
+  State<RC> S;
+  begin<RC>(S, H.b1, H.C);
+  __syncthreads();             // every wave has left its tiles: LDS free, this workgroup's pooled rows visible to all of it
+  H16STAMP(1);
+  Lds& HL = *reinterpret_cast<Lds*>(lds_base);
   const int R = WAVES * gpt;                               // graphs of this workgroup per round of its waves
   const int stride = gridDim.x * WAVES;                    // tiles between two rounds
   int rows_total = 0;
@@ -336,12 +343,14 @@ __device__ __forceinline__ void fwd_head_tail(void* lds_base, const FwdHead& H, 
     rows_total += left < R ? left : R;
   }
   const int base = blockIdx.x * WAVES * gpt, step_g = stride * gpt;
+  const bool in_lds = rows_total <= SEMB_ROWS;             // block-uniform
+  H16STAMP(2);
   for (int j0 = 0; j0 < rows_total; j0 += RT) {
     const int n = rows_total - j0 < RT ? rows_total - j0 : RT;
-    head_tile<DD, RC, BACKWARD>(HL, S, [=](int row) { const int j = j0 + row, k = j / R; return base + k * step_g + (j - k * R); },
-                                n, H.C, slope, emb, H.y, H.W0, H.z, H.out, H.demb);
+    tile<RC, BACKWARD>(HL, S, P, [=](int row) { const int j = j0 + row, k = j / R; return base + k * step_g + (j - k * R); },
+                       n, H.C, slope, in_lds ? semb + j0 * ES : nullptr, emb, H.y, H.z, H.out, H.demb, j0 == 0);
   }
-  head_end<DD, RC, BACKWARD>(HL, S, H.C, H.slabs + (size_t)blockIdx.x * HC<DD>::SLAB);
+  end<RC, BACKWARD>(HL, S, H.C, H.slabs + (size_t)blockIdx.x * SLAB, H.slabs + (size_t)gridDim.x * SLAB + blockIdx.x);
 }
 
 template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false, int HEAD = 0>
@@ -355,7 +364,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   static_assert(!BITS || POOL, "the bit form belongs to the pooled layer");
   static_assert(HEAD == 0 || POOL, "the head reads the pooled embedding");
   __shared__ WaveLdsF lds[WAVES];
-  static_assert(HEAD == 0 || sizeof(hcg_head::HeadLds<DD>) <= sizeof(WaveLdsF) * WAVES, "the head's LDS aliases the tile buffers");
+  static_assert(HEAD == 0 || sizeof(hcg_head16::Lds) <= sizeof(WaveLdsF) * WAVES, "the head's LDS aliases the tile buffers");
+  __shared__ float semb[HEAD != 0 ? SEMB_ROWS * hcg_head16::ES : 4];   // this workgroup's pooled rows, for its head tail
   if (HEAD != 0 && HA.step_counter && blockIdx.x == 0 && threadIdx.x == 0) HA.step_counter[0] += 1;   // this step's number
   __shared__ __attribute__((aligned(16))) short w1l[3 * DD * (KPAD + WPAD)];
   __shared__ __attribute__((aligned(16))) short w2l[STACK2 ? 3 * DD * (DD + WPAD) : 8];
@@ -407,6 +417,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
     sx.write(L.buf, F, ti.n, lane);
   }
+  int round_it = 0;      // rounds of this wave so far (tile t = first + round_it * stride)
   while (have) {
     STAMP(1 + 8 * stamp_it);
     // prefetch the next tile of this wave (registers only) while this one computes
@@ -540,6 +551,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
           e[32 + r] = m1;
           e[DD + r] = s0 / cntf;
           e[DD + 32 + r] = s1 / cntf;
+          if constexpr (HEAD != 0) {      // row of this graph among the workgroup's graphs (round, wave, graph of the tile)
+            const int j = round_it * WAVES * gpt + wave * gpt + (g - ti.g0);
+            if (j < SEMB_ROWS) {
+              float* se = semb + j * hcg_head16::ES;
+              se[r] = m0;
+              se[32 + r] = m1;
+              se[DD + r] = s0 / cntf;
+              se[DD + 32 + r] = s1 / cntf;
+            }
+          }
         }
       }
       if (BITS) {
@@ -551,6 +572,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     if (stamp_it < 6) ++stamp_it;
 
     have = have_next;
+    ++round_it;
     if (have_next) {
       if (!VEC) {
         tin = tile_finish(raw_cur, gpt, lane, status);
@@ -572,9 +594,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   STAMP(63);
   STAMP_FLUSH();
   if constexpr (HEAD != 0) {
-    __syncthreads();           // every wave has left its tiles: LDS free, this workgroup's pooled rows visible to all of it
-    if (HA.C == 1) fwd_head_tail<1, HEAD == 2>(&lds[0], HA, emb, gpt, B, num_tiles, slope);
-    else fwd_head_tail<hcg_head::RCMAX, HEAD == 2>(&lds[0], HA, emb, gpt, B, num_tiles, slope);
+    if (HA.C == 1) fwd_head_tail<1, HEAD == 2>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
+    else fwd_head_tail<hcg_head::RCMAX, HEAD == 2>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
   }
 }
 
@@ -1022,7 +1043,7 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
 extern "C" size_t hcg_fused_head_workspace_bytes(int64_t B, int graphs_per_tile) {
   if (graphs_per_tile <= 0 || B <= 0) return 0;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
-  return hcg_align_up((size_t)pick_grid(tiles) * hcg_head::HC<DD>::SLAB * sizeof(float), 256) + 256;
+  return hcg_align_up((size_t)pick_grid(tiles) * (hcg_head::HC<DD>::SLAB + 1) * sizeof(float), 256) + 256;
 }
 
 extern "C" int hcg_fused_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int graphs_per_tile, int64_t C,
@@ -1182,7 +1203,8 @@ extern "C" int hcg_fused_reduce_job(const void* workspace, size_t workspace_byte
   job->nslabs = grid;
   job->slab_floats = slab_floats;
   job->nseg = 2;
-  job->sse_index = 0;
+  job->sse_part = nullptr;
+  job->reserved = 0;
   job->seg[0] = hcg_reduce_seg{0, DD * kpad, kpad, (int32_t)F, dW};
   job->seg[1] = hcg_reduce_seg{DD * kpad, DD, 1, 1, db};
   return HCG_OK;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(HC<RD>::NT, 1) void k_head(const float* __restrict_
     const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
     head_tile<RD, RC, BACKWARD>(L, S, [g0](int row) { return g0 + row; }, n, C, slope, emb, y, W0, z, out, demb);
   }
-  head_end<RD, RC, BACKWARD>(L, S, C, slabs + (size_t)blockIdx.x * HC<RD>::SLAB);
+  head_end<RD, RC, BACKWARD>(L, S, C, slabs + (size_t)blockIdx.x * HC<RD>::SLAB, slabs + (size_t)gridDim.x * HC<RD>::SLAB + blockIdx.x);
 }
 
 int head_grid(int64_t B) {
@@ -48,10 +48,10 @@ size_t head_slab(int64_t D) { return D == 128 ? (size_t)HC<128>::SLAB : (size_t)
 
 extern "C" int hcg_head_supported(int64_t D, int64_t C) { return ((D == 64 || D == 128) && C >= 1 && C <= RCMAX) ? 1 : 0; }
 
-// workspace: [grid][SLAB] gradient slabs (+ SSE partials)
+// workspace: [grid][SLAB] gradient slabs | [grid] SSE partials
 extern "C" size_t hcg_head_workspace_bytes(int64_t B, int64_t D) {
   if (D != 64 && D != 128) return 0;
-  return hcg_align_up((size_t)head_grid(B) * head_slab(D) * sizeof(float), 256) + 256;
+  return hcg_align_up((size_t)head_grid(B) * (head_slab(D) + 1) * sizeof(float), 256) + 256;
 }
 
 extern "C" int hcg_head_fwd_bwd(const float* emb, const float* y, const float* W0, const float* b0, const float* W1,

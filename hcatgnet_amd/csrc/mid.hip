@@ -826,7 +826,8 @@ extern "C" int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes,
   job->nslabs = gsz;
   job->slab_floats = DD * fpad + DD;
   job->nseg = 2;
-  job->sse_index = 0;
+  job->sse_part = nullptr;
+  job->reserved = 0;
   job->seg[0] = hcg_reduce_seg{0, DD * fpad, fpad, (int32_t)F, dW + (size_t)half * DD * F};
   job->seg[1] = hcg_reduce_seg{DD * fpad, DD, 1, 1, db + half * DD};
   return HCG_OK;

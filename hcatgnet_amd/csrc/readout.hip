@@ -345,7 +345,8 @@ extern "C" int hcg_readout2_reduce_job(const void* workspace, size_t workspace_b
   job->nslabs = grid;
   job->slab_floats = SLAB;
   job->nseg = 4;
-  job->sse_index = 0;
+  job->sse_part = nullptr;
+  job->reserved = 0;
   job->seg[0] = hcg_reduce_seg{0, RD * RK, RK, RK, dW0};
   job->seg[1] = hcg_reduce_seg{RD * RK, RD, 1, 1, db0};
   job->seg[2] = hcg_reduce_seg{RD * RK + RD, (int32_t)C * RD, RD, RD, dW1};

@@ -23,6 +23,7 @@ __device__ __forceinline__ double hcg_powi(double b, int t) {
 
 struct Jobs {
   int njobs;
+  int nblk[HCG_REDUCE_MAX_JOBS];     // workgroups of job j: ceil(slab_floats / RO) -- the grid is their sum (+ the plan's)
   hcg_reduce_job job[HCG_REDUCE_MAX_JOBS];
 };
 
@@ -113,12 +114,12 @@ __device__ __forceinline__ float xchg_gather(const XchgArgs& X, int parity, int6
 // LOSS: the deferred loss scale.  Every backward launch of the step ran on the UNSCALED error (out - y): the whole
 // backward is linear in dloss/dout = scale * (out - y), scale being the one number that depends on the whole batch
 // (1 / (count * sqrt(MSE)) for the reference's sqrt(MSE), utils/utils_model.py:64).  The readout head leaves one partial sum
-// of squared errors per workgroup in its slabs (hcg_reduce_job.sse_index); every block of THIS launch adds them in the same
+// of squared errors per workgroup behind its slabs (hcg_reduce_job.sse_part); every block of THIS launch adds them in the same
 // fixed order (bitwise the same scale everywhere), and the scale multiplies each gradient element as it is reduced --
 // no grid-wide exchange, no launch of its own (round 2's head kernel spent a grid barrier on this scalar).
 struct LossArgs {
-  const float* sse_part;    // first partial; nullptr = the slabs hold final gradients (scale 1)
-  int nparts, stride;       // partial b at sse_part[b * stride]
+  const float* sse_part;    // [nparts] partials; nullptr = the slabs hold final gradients (scale 1)
+  int nparts;
   float count;              // elements of the squared-error sum on this rank (B * C)
   int mode;                 // HCG_LOSS_MSE / HCG_LOSS_RMSE / HCG_LOSS_SSE
   float* loss;              // [2] nullable: the loss, the MSE
@@ -128,7 +129,7 @@ struct LossArgs {
 // sum of the SSE partials: lanes take partials l, l + 64, ... in ascending order, then a fixed xor tree
 __device__ __forceinline__ float loss_sse_sum(const LossArgs& L, int lane) {
   float s = 0.f;
-  for (int b = lane; b < L.nparts; b += 64) s += L.sse_part[(size_t)b * L.stride];
+  for (int b = lane; b < L.nparts; b += 64) s += L.sse_part[b];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   return s;
@@ -136,23 +137,25 @@ __device__ __forceinline__ float loss_sse_sum(const LossArgs& L, int lane) {
 
 template <bool ADAM, bool XCHG = false>
 __global__ __launch_bounds__(256) void k_step_tail(Jobs jobs, AdamArgs A, PlanArgs P, LossArgs L, XchgArgs X = XchgArgs{}) {
-  if (P.batch != nullptr && (int)blockIdx.y == jobs.njobs) {        // block-uniform: the NEXT batch's plan
-    const int64_t total = P.N + P.E + 2, stride = (int64_t)gridDim.x * 256;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride)
-      hcg_ptrs_thread(t, P.ei, P.batch, P.N, P.E, P.B, P.graph_ptr, P.edge_ptr, P.status);
+  // a 1-D grid without idle workgroups: [blocks of job 0 | blocks of job 1 | ... | the plan's blocks] (as a 2-D grid of
+  // njobs + 1 rows as wide as the widest -- the plan's -- two thirds of the 6 000 workgroups at C3 returned at once)
+  int blk = blockIdx.x, jsel = 0;
+  while (jsel < jobs.njobs && blk >= jobs.nblk[jsel]) { blk -= jobs.nblk[jsel]; ++jsel; }
+  if (jsel == jobs.njobs) {                          // block-uniform: the NEXT batch's plan
+    const int64_t t = (int64_t)blk * 256 + threadIdx.x;
+    if (t < P.N + P.E + 2) hcg_ptrs_thread(t, P.ei, P.batch, P.N, P.E, P.B, P.graph_ptr, P.edge_ptr, P.status);
     return;
   }
   __shared__ float part[RS][RO];
-  const hcg_reduce_job& J = jobs.job[blockIdx.y];
+  const hcg_reduce_job& J = jobs.job[jsel];
   const int o = threadIdx.x % RO, sl = threadIdx.x / RO;
-  const int idx = blockIdx.x * RO + o;
-  if (blockIdx.x * RO >= J.slab_floats) return;   // block-uniform
+  const int idx = blk * RO + o;
   // [0] lr / bias-correction-1, [1] sqrt(bias-correction-2), [2] scale applied to this rank's sum (before an exchange),
   // [3] scale applied to the exchanged total
   __shared__ float adam_c[4];
   const unsigned xstep = XCHG ? (unsigned)A.step_dev[0] : 0u;
   const int parity = (int)(xstep & 1u);
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  const bool first = blockIdx.x == 0;
   if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation
     const int t = A.step_dev[0];                     // number of THIS update (advanced earlier in the step)
     adam_c[0] = A.lr_dev[0] / (float)(1.0 - hcg_powi((double)A.b1, t));
@@ -261,11 +264,10 @@ static int loss_args_from_jobs(const hcg_reduce_job* jobs_host, int njobs, float
   LossArgs L{};
   for (int j = 0; j < njobs; ++j) {
     const hcg_reduce_job& J = jobs_host[j];
-    if (J.sse_index <= 0) continue;
-    if (L.sse_part || J.sse_index >= J.slab_floats || J.nslabs < 1) return HCG_ERR_INVALID_ARG;
-    L.sse_part = J.slabs + J.sse_index;
+    if (!J.sse_part) continue;
+    if (L.sse_part || J.nslabs < 1) return HCG_ERR_INVALID_ARG;
+    L.sse_part = J.sse_part;
     L.nparts = J.nslabs;
-    L.stride = J.slab_floats;
   }
   if (L.sse_part) {
     if (!(count > 0.f) || (mode != HCG_LOSS_MSE && mode != HCG_LOSS_RMSE && mode != HCG_LOSS_SSE)) return HCG_ERR_INVALID_ARG;
@@ -331,7 +333,7 @@ extern "C" int hcg_step_tail(const hcg_tail_args* a, hcg_stream_t stream_) {
   HCG_TRY(loss_args_from_jobs(jobs_host, njobs, a->loss_count, a->loss_mode, a->loss, a->sse_tail, &L));
   Jobs jobs;
   jobs.njobs = njobs;
-  int max_floats = 0;
+  unsigned total_blocks = 0;
   for (int j = 0; j < njobs; ++j) {
     const hcg_reduce_job& J = jobs_host[j];
     if (!J.slabs || J.nslabs < 0 || J.slab_floats <= 0 || J.nseg < 0 || J.nseg > HCG_REDUCE_MAX_SEGS) return HCG_ERR_INVALID_ARG;
@@ -344,18 +346,15 @@ extern "C" int hcg_step_tail(const hcg_tail_args* a, hcg_stream_t stream_) {
       }
     }
     jobs.job[j] = J;
-    if (J.slab_floats > max_floats) max_floats = J.slab_floats;
+    jobs.nblk[j] = J.nseg > 0 ? (J.slab_floats + RO - 1) / RO : 0;      // (a job without segments only carries partials)
+    total_blocks += (unsigned)jobs.nblk[j];
   }
-  for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) jobs.job[j] = jobs.job[0];
-  // (plan row: one thread per node / edge as k_ptrs runs it -- fewer, looping blocks serialise its dependent loads: +3 us)
-  unsigned gx = (max_floats + RO - 1) / RO;
-  if (plan) { const unsigned px = (unsigned)hcg_cdiv(P.N + P.E + 2, 256); if (px > gx) gx = px; }
-  const dim3 grid(gx, njobs + (plan ? 1 : 0));
-  if (xchg) {
-    int polling = 0;
-    for (int j = 0; j < njobs; ++j) polling += (jobs.job[j].slab_floats + RO - 1) / RO;
-    if (polling > hcg_xchg_resident_blocks()) return HCG_ERR_UNSUPPORTED;
-  }
+  for (int j = njobs; j < HCG_REDUCE_MAX_JOBS; ++j) { jobs.job[j] = jobs.job[0]; jobs.nblk[j] = 0; }
+  if (xchg && (int)total_blocks > hcg_xchg_resident_blocks()) return HCG_ERR_UNSUPPORTED;   // (see hcg_xchg_resident_blocks)
+  // (plan blocks: one thread per node / edge as k_ptrs runs it -- fewer, looping blocks serialise its dependent loads: +3 us)
+  if (plan) total_blocks += (unsigned)hcg_cdiv(P.N + P.E + 2, 256);
+  if (total_blocks == 0) return HCG_OK;
+  const dim3 grid(total_blocks);
   if (xchg) hipLaunchKernelGGL((k_step_tail<true, true>), grid, dim3(256), 0, stream, jobs, A, P, L, X);
   else if (adam) hipLaunchKernelGGL((k_step_tail<true, false>), grid, dim3(256), 0, stream, jobs, A, P, L, XchgArgs{});
   else hipLaunchKernelGGL((k_step_tail<false, false>), grid, dim3(256), 0, stream, jobs, A, P, L, XchgArgs{});

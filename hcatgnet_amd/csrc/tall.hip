@@ -1240,14 +1240,16 @@ extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_byte
   j->nslabs = dw_grid(N, D);
   j->slab_floats = (int32_t)(D * fp);
   j->nseg = 1;
-  j->sse_index = 0;
+  j->sse_part = nullptr;
+  j->reserved = 0;
   j->seg[0] = hcg_reduce_seg{0, (int32_t)(D * fp), fp, (int32_t)F, dW};
   j = job_host + 1;
   j->slabs = ws.db_slabs;
   j->nslabs = seg_grid64(B);
   j->slab_floats = (int32_t)D;
   j->nseg = 1;
-  j->sse_index = 0;
+  j->sse_part = nullptr;
+  j->reserved = 0;
   j->seg[0] = hcg_reduce_seg{0, (int32_t)D, 1, 1, db};
   return HCG_OK;
 }

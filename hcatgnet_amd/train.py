@@ -833,6 +833,144 @@ class StepWindow:
         return self.losses
 
 
+class EpochWindow:
+    """One training epoch of the reference's loop (utils/utils_model.py:55-70: every batch of a shuffled
+    `DataLoader(dataset, batch_size, shuffle=True)`, call_methods.py:41-46, through zero_grad / forward / sqrt(MSE) /
+    backward / Adam) as ONE hipGraph launch over a `store.DeviceLoader`.
+
+    What makes an epoch capturable although its batches change shape with every shuffle: the NUMBER of batches and their
+    graph counts are fixed (batch_size 40, options/base_options.py:269-274: 13 x 40 + 15 for 535 graphs), and every kernel
+    of the fused step takes its sizes from graph_ptr / edge_ptr on the device, not from the launch arguments.  So every batch
+    slot owns buffers of a fixed CAPACITY (the batch_size largest graphs of the dataset), the collate launch of slot i reads
+    its graph ids and prefix sums from a fixed device buffer, and an epoch is: draw the permutation on the host (a few KB,
+    the loader's own generator: the same sequence of permutations as iterating the loader), ONE host-to-device copy of the
+    epoch's index arrays, ONE graph launch (collate + 4..6 launches per batch, weights carried from batch to batch), one
+    reduction of the per-batch losses.  The per-batch loop of round 2 was host-bound at ~140 us per 77 us of kernels.
+
+    Bitwise the per-batch loop on the same permutations (tests/test_gpu_train_step.py).  Applies when every layer of the
+    model runs on a per-graph kernel family at capacity shape (not the dense row-streaming kernels of csrc/tall.hip, which
+    walk all N rows of a batch); `build` returns None otherwise and the caller keeps its loop."""
+
+    MAX_BATCHES = 64
+
+    @staticmethod
+    def build(model, loader):
+        try:
+            return EpochWindow(model, loader)
+        except _lib.HcgError:
+            return None
+
+    def __init__(self, model, loader):
+        import numpy as np
+        from .batch import Batch
+        from .plan import BatchPlan, _shared_status
+        st, bs = loader.store, loader.batch_size
+        G, dev, F = len(st), st.device, st.F
+        starts = [i for i in range(0, G, bs) if not (loader.drop_last and G - i < bs)]
+        if not starts or len(starts) > self.MAX_BATCHES or st.y_all is None:
+            raise _lib.HcgError("EpochWindow: no batches, too many batches, or a dataset without targets")
+        self.model, self.loader, self.G = model, loader, G
+        self.Bs = [min(bs, G - i) for i in starts]
+        self.starts = starts
+        n_desc, e_desc = np.sort(st.n_host)[::-1], np.sort(st.e_host)[::-1]
+        maxn, maxe = int(n_desc[0]), int(e_desc[0])
+        words = lambda B: (B + 2) // 2                       # int64 words that hold B + 1 int32 (as DeviceLoader.__iter__)
+        tot = sum(words(B) for B in self.Bs)
+        self.tot = tot
+        self.host = torch.zeros(G + 2 * tot, dtype=torch.int64).pin_memory()
+        self.dbuf = torch.zeros(G + 2 * tot, dtype=torch.int64, device=dev)
+        d32 = self.dbuf[G:].view(torch.int32)
+        lib, p = _lib.load(), _lib.ptr
+        self.batches, self.spans, fns, off = [], [], [], 0
+        for i, B in zip(starts, self.Bs):
+            Ncap, Ecap = int(n_desc[:B].sum()), max(int(e_desc[:B].sum()), 1)
+            x = torch.zeros(Ncap, F, dtype=torch.float32, device=dev)
+            ei = torch.zeros(2, Ecap, dtype=torch.int64, device=dev)
+            bvec = torch.zeros(Ncap, dtype=torch.int64, device=dev)
+            y = torch.zeros(B, dtype=torch.float32, device=dev)
+            idx = torch.zeros(B, dtype=torch.int64, device=dev) if st.idx_all is not None else None
+            ids_d, gp_d, ep_d = self.dbuf[i:i + B], d32[off:off + B + 1], d32[2 * tot + off:2 * tot + off + B + 1]
+            batch = Batch(x, ei, bvec, B, y=y, idx=idx, max_nodes=maxn, max_edges=maxe, edges_grouped=True)
+            plan = BatchPlan()
+            plan.N, plan.E, plan.B, plan.fill, plan.mode = Ncap, Ecap, B, 1.0, "blocked"
+            plan.edge_index, plan.batch, plan.edge_weight = ei, bvec, None
+            plan.graph_ptr, plan.edge_ptr = gp_d, ep_d
+            plan.max_nodes, plan.max_edges, plan.validated, plan.has_csr = maxn, maxe, True, False
+            plan.shared_status, plan.status, plan.want_eid = True, _shared_status(dev), False
+            plan.rowptr = plan.col = plan.eid = plan.rowptr_t = plan.col_t = plan.eid_t = None
+            plan.dinv = plan.ew_csr = plan.ew_csc = plan.dinv_unw = None
+            batch._hcg_plan = plan
+            for c in [model.conv1] + list(model.conv_layers):
+                if HF.fused_graphs_per_tile(plan, c.in_channels, c.out_channels) <= 0 and HF.tall_supported(plan, c.in_channels, c.out_channels):
+                    raise _lib.HcgError("EpochWindow: a layer would run on the dense row-streaming kernels (capacity-padded rows)")
+            self.batches.append(batch)
+            self.spans.append((i, B, off))
+
+            def collate_slot(batch=batch, ids_d=ids_d, gp_d=gp_d, ep_d=ep_d, B=B, Ncap=Ncap, Ecap=Ecap):
+                rc = lib.hcg_collate(p(st.x_all), p(st.src_all), p(st.dst_all), p(st.node_ptr_all), p(st.edge_ptr_all), p(st.y_all),
+                                     p(st.idx_all), p(ids_d), p(gp_d), p(ep_d), B, F, Ncap, Ecap, p(batch.x), p(batch.edge_index),
+                                     p(batch.batch), p(batch.y), p(batch.idx), _lib.stream_ptr())
+                _lib.check(rc, "hcg_collate")
+                return batch
+            fns.append(collate_slot)
+            off += 2 * words(B)
+        self.steps = [FusedTrainStep(model) for _ in self.Bs]
+        why = self.steps[0].reason(self.batches[0])
+        if why is not None:
+            raise _lib.HcgError(f"EpochWindow: {why}")
+        self.counts = torch.tensor([float(B) for B in self.Bs], dtype=torch.float64, device=dev)
+        # the capture's warm-up runs every step once: a hidden extra epoch.  It is undone: parameters, moments and the step
+        # count go back to what they were, in place (same storages, so the captured addresses stay valid)
+        self._layout(np.arange(G))
+        opt = model.optimizer
+        opt.enable_capturable()
+        for q in model.parameters():                    # re-base onto the optimiser's flat storages BEFORE the snapshot
+            _lib.require_gpu(q)
+        fl = opt._flat.get(0)
+        ps = [q for q in opt.param_groups[0]["params"] if q.requires_grad]
+        if (fl is None or len(fl["params"]) != len(ps) or any(a is not b for a, b in zip(fl["params"], ps))
+                or ps[0].data_ptr() != fl["p"].data_ptr()):
+            with torch.no_grad():
+                fl = opt._rebase(0, opt.param_groups[0])
+        opt._make_dev_state(fl, opt.param_groups[0])
+        saved = [fl["p"].clone(), fl["m"].clone(), fl["v"].clone(), fl["step_dev"].clone()]
+        self.window = StepWindow(self.steps, fns)
+        fl2 = opt._flat.get(0)
+        if fl2 is not fl:
+            raise _lib.HcgError("EpochWindow: the optimiser re-based its state during the capture")
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            fl["p"].copy_(saved[0]); fl["m"].copy_(saved[1]); fl["v"].copy_(saved[2]); fl["step_dev"].copy_(saved[3])
+
+    def _layout(self, order):
+        """The epoch's index arrays [ids of every batch | graph_ptr of every batch | edge_ptr of every batch] -> device."""
+        import numpy as np
+        st, G, tot = self.loader.store, self.G, self.tot
+        buf = self.host.numpy()
+        buf[:] = 0
+        buf[:G] = order
+        ptr32 = buf[G:].view(np.int32)
+        for i, B, off in self.spans:
+            ids = order[i:i + B]
+            ptr32[off + 1:off + B + 1] = np.cumsum(st.n_host[ids])
+            ptr32[2 * tot + off + 1:2 * tot + off + B + 1] = np.cumsum(st.e_host[ids])
+        self.dbuf.copy_(self.host, non_blocking=True)
+
+    def draw_order(self):
+        """The next permutation of the loader's generator (what iterating the loader would have drawn)."""
+        import numpy as np
+        ld = self.loader
+        return ld.rng.permutation(self.G) if ld.shuffle else np.arange(self.G)
+
+    def run_epoch(self, order=None) -> float:
+        """-> sum(loss_i * num_graphs_i) / len(dataset), the reference's `train_network` return value."""
+        if order is None:
+            order = self.draw_order()
+        self._layout(order)
+        losses = self.window.replay()
+        return _weighted_loss_sum(losses, self.counts) / self.G   # (the sync also keeps the pinned buffer from being rewritten too early)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the reference's loops (same names / arguments / return values)
 # ---------------------------------------------------------------------------------------------------------------
@@ -841,11 +979,28 @@ def _rmse_autograd(model, batch):
     return torch.sqrt(model.loss(out, batch.y.unsqueeze(1)))
 
 
-def _accumulate(total, loss, num_graphs):
-    """total += loss * num_graphs on the device, one launch (the reference does `loss.item() * batch.num_graphs`)."""
-    if total is None:
-        return loss.detach() * float(num_graphs)
-    return total.add_(loss.detach(), alpha=float(num_graphs))
+class _EpochSum:
+    """sum(loss_i * num_graphs_i) of an epoch, on the device, in float64 like the reference's Python-float accumulation
+    (`loss.item() * batch.num_graphs`, utils/utils_model.py:68): the per-batch losses are kept (one tiny copy each, no
+    sync) and meet in ONE dot product at the end of the epoch -- the same operation the one-graph epoch forms
+    (`EpochWindow`, `_eval_window`) apply to their loss buffers, so both forms return bitwise the same value."""
+
+    def __init__(self):
+        self.vals, self.ns = [], []
+
+    def add(self, loss, num_graphs):
+        self.vals.append(loss.detach().clone())
+        self.ns.append(float(num_graphs))
+
+    def value(self, denom) -> float:
+        if not self.vals:
+            return 0.0
+        return _weighted_loss_sum(self.vals, torch.tensor(self.ns, dtype=torch.float64, device=self.vals[0].device)) / denom
+
+
+def _weighted_loss_sum(losses, counts64) -> float:
+    """One synchronising read: dot(losses, counts) in float64."""
+    return float(torch.dot(torch.stack([v.reshape(()) for v in losses]).double(), counts64).item())
 
 
 def train_network(model, train_loader, device):
@@ -859,7 +1014,10 @@ def train_network(model, train_loader, device):
             model._hcg_train_step = fused
         except Exception:
             pass
-    total = None
+    val = _epoch_window(model, train_loader)
+    if val is not None:
+        return val
+    total = _EpochSum()
     for batch in train_loader:
         batch = batch.to(device)
         if fused.reason(batch) is None:
@@ -870,10 +1028,48 @@ def train_network(model, train_loader, device):
             loss.backward()
             model.optimizer.step()
             loss = loss.detach()
-        total = _accumulate(total, loss, batch.num_graphs)
-    if total is None:
-        return 0.0
-    return float(total.item()) / len(train_loader.dataset)
+        total.add(loss, batch.num_graphs)
+    return total.value(len(train_loader.dataset))
+
+
+EPOCH_WINDOW = True      # train_network over a DeviceLoader: whole epochs as one hipGraph (EpochWindow); False = per-batch loop
+
+
+def _epoch_window(model, loader):
+    """-> the epoch's value through the loader's cached `EpochWindow` (built on first use; rebuilt when the model or the
+    optimiser's storages changed), or None when that form does not apply."""
+    from .store import DeviceLoader
+    if not (EPOCH_WINDOW and isinstance(loader, DeviceLoader) and hasattr(model.optimizer, "enable_capturable")):
+        return None
+    if dist_initialized_multi():
+        return None                          # (data parallel epochs keep the per-batch loop: the exchange form is the caller's)
+    order = None
+    for attempt in range(2):
+        cache = getattr(loader, "_hcg_epoch_window", None)
+        key = (id(model), loader.batch_size, loader.drop_last, len(loader.store))
+        if cache is None or cache[0] != key:
+            win = EpochWindow.build(model, loader)
+            cache = (key, win)
+            try:
+                loader._hcg_epoch_window = cache
+            except Exception:
+                pass
+        if cache[1] is None:
+            return None
+        try:
+            if order is None:
+                order = cache[1].draw_order()            # (drawn once: a rebuild must not skip a permutation)
+            return cache[1].run_epoch(order)
+        except _lib.HcgError:                 # parameters / optimiser re-based since the capture: build again
+            try:
+                loader._hcg_epoch_window = None
+            except Exception:
+                return None
+    return None
+
+
+def dist_initialized_multi() -> bool:
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
 EVAL_WINDOW_MAX_BATCHES = 64
@@ -888,15 +1084,19 @@ def _eval_window(model, loader, fused):
     if not (isinstance(loader, DeviceLoader) and not loader.shuffle and 0 < len(loader) <= EVAL_WINDOW_MAX_BATCHES):
         return None
     cache = getattr(loader, "_hcg_eval_window", None)
+    key = (loader.batch_size, loader.drop_last, len(loader.store), bool(getattr(model, "use_fused", True)))
     for attempt in range(2):
-        if cache is None or cache["model"] is not model:
+        if cache is None or cache["model"] is not model or cache.get("key") != key:
             batches = list(loader)
             if not all(fused.reason(b) is None for b in batches):
                 return None
-            steps = [FusedTrainStep(model, optimizer_step=False) for _ in batches]
-            win = StepWindow(steps, batches, forward_only=True)
-            counts = torch.tensor([float(b.num_graphs) for b in batches], dtype=torch.float32, device=batches[0].x.device)
-            cache = {"model": model, "window": win, "batches": batches, "counts": counts}
+            try:
+                steps = [FusedTrainStep(model, optimizer_step=False) for _ in batches]
+                win = StepWindow(steps, batches, forward_only=True)
+            except (_lib.HcgError, RuntimeError):        # capture failed (memory, an unsupported launch): the per-batch loop runs
+                return None
+            counts = torch.tensor([float(b.num_graphs) for b in batches], dtype=torch.float64, device=batches[0].x.device)
+            cache = {"model": model, "key": key, "window": win, "batches": batches, "counts": counts}
             try:
                 loader._hcg_eval_window = cache
             except Exception:
@@ -906,8 +1106,7 @@ def _eval_window(model, loader, fused):
         except _lib.HcgError:                 # parameters re-based since the capture (load_state_dict on new storages ...)
             cache = None
             continue
-        total = torch.dot(torch.stack(losses), cache["counts"])
-        return float(total.item()) / len(loader.dataset)
+        return _weighted_loss_sum(losses, cache["counts"]) / len(loader.dataset)
     return None
 
 
@@ -924,7 +1123,7 @@ def eval_network(model, loader, device):
     total = _eval_window(model, loader, fused)
     if total is not None:
         return total
-    total = None
+    total = _EpochSum()
     with torch.no_grad():
         for batch in loader:
             batch = batch.to(device)
@@ -932,10 +1131,8 @@ def eval_network(model, loader, device):
                 loss = fused.evaluate(batch, _checked=True)
             else:
                 loss = _rmse_autograd(model, batch)
-            total = _accumulate(total, loss, batch.num_graphs)
-    if total is None:
-        return 0.0
-    return float(total.item()) / len(loader.dataset)
+            total.add(loss, batch.num_graphs)
+    return total.value(len(loader.dataset))
 
 
 def predict_network(model, loader, return_emb: bool = False, device=None):

@@ -142,7 +142,7 @@ class OneShotExchange:
 
             assert ctypes.sizeof(_lib.ReduceJob) == jb
             j = _lib.ReduceJob.from_buffer(job)
-            j.slabs, j.nslabs, j.slab_floats, j.nseg, j.sse_index = slab.data_ptr(), 1, n, 1, 0
+            j.slabs, j.sse_part, j.nslabs, j.slab_floats, j.nseg = slab.data_ptr(), None, 1, n, 1
             j.seg[0] = _lib.ReduceSeg(0, n, n, n, flat_ext.data_ptr())
             g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         except Exception:                                           # noqa: BLE001  (any failure = fall back to RCCL)

@@ -346,9 +346,9 @@ typedef struct hcg_reduce_seg {
 } hcg_reduce_seg;
 typedef struct hcg_reduce_job {
   const float* slabs;        /* [nslabs][slab_floats] */
-  int32_t nslabs, slab_floats, nseg;
-  int32_t sse_index;         /* > 0: element `sse_index` of every slab is that workgroup's partial sum of squared errors
-                                (the head's job: hcg_head_reduce_job / hcg_fused_head_reduce_job); 0 = none */
+  const float* sse_part;     /* != NULL: [nslabs] partial sums of squared errors, one per workgroup, contiguous (the head's
+                                job: hcg_head_reduce_job / hcg_fused_head_reduce_job fill it in); NULL = none */
+  int32_t nslabs, slab_floats, nseg, reserved;
   hcg_reduce_seg seg[HCG_REDUCE_MAX_SEGS];
 } hcg_reduce_job;
 size_t hcg_reduce_job_bytes(void);
@@ -365,7 +365,7 @@ int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B,
 /* job_host[0] = dW [D, F], job_host[1] = db [D] of hcg_tall_layer_bwd */
 int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
                          float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
-/* the head's slabs; job_host->sse_index names the SSE partial of each.  dW0 == NULL (forward-only head): no segments,
+/* the head's slabs; job_host->sse_part = the workgroups' SSE partials.  dW0 == NULL (forward-only head): no segments,
  * the job then only carries the partials (hcg_loss_finalize) */
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C,
                         float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
@@ -374,7 +374,7 @@ int hcg_reduce_job_append(hcg_reduce_job* job_host, const hcg_reduce_job* more_h
 
 /* ---- the step tail: ONE launch behind the backward launches of a training step (f2) --------------------------------
  *   (1) every pending slab reduction (jobs_host[0 .. njobs)), each output element summed in a fixed order;
- *   (2) the loss and its deferred scale: when a job carries SSE partials (sse_index), loss[0] = the loss (`loss_mode`),
+ *   (2) the loss and its deferred scale: when a job carries SSE partials (sse_part), loss[0] = the loss (`loss_mode`),
  *       loss[1] = MSE, and every reduced element is multiplied by the scale (see hcg_head_fwd_bwd); HCG_LOSS_SSE leaves the
  *       gradients unscaled and stores this rank's [SSE, count] in sse_tail;
  *   (3) inbox != NULL: the data-parallel one-shot exchange over xGMI (below) between reduction and update;
@@ -389,7 +389,7 @@ int hcg_reduce_job_append(hcg_reduce_job* job_host, const hcg_reduce_job* more_h
 typedef struct hcg_tail_args {
   const hcg_reduce_job* jobs_host;
   int32_t njobs;
-  int32_t loss_mode;           /* HCG_LOSS_*; only read when a job has sse_index > 0 */
+  int32_t loss_mode;           /* HCG_LOSS_*; only read when a job has sse_part */
   float loss_count;            /* elements of the squared-error sum on this rank: B * C */
   float beta1, beta2, eps;
   float* loss;                 /* [2], nullable without exchange */

@@ -43,7 +43,7 @@ def test_head_forward_loss_backward_one_launch(H, B, C, rmse, D):
         job = _lib.ReduceJob()
         _lib.check(lib.hcg_head_reduce_job(p(ws), wsb, B, D, C, p(grads[0]), p(grads[1]), p(grads[2]), p(grads[3]),
                                            ctypes.addressof(job)), "hcg_head_reduce_job")
-        assert job.sse_index > 0 and job.nseg == 4
+        assert job.sse_part and job.nseg == 4
         _lib.step_tail(ctypes.addressof(job), 1, loss=loss, loss_mode=mode, loss_count=float(B * C))
         torch.cuda.synchronize()
         assert int(step[0]) == rep + 1        # the step number advanced once per launch
@@ -228,6 +228,51 @@ def test_eval_network_window_equals_the_batch_loop(H):
     assert getattr(trn, "_hcg_eval_window", None) is None
     v = eval_network(m, trn, "cuda")                      # shuffling loader: the loop, no window
     assert getattr(trn, "_hcg_eval_window", None) is None and v > 0
+
+
+@pytest.mark.parametrize("cfg,feat,G,bs", [("REAL", 25, 135, 40), ("C2", 64, 100, 32)])
+def test_epoch_window_equals_the_per_batch_loop_on_the_same_permutations(H, cfg, feat, G, bs):
+    """`train_network` over a shuffling DeviceLoader runs whole epochs as ONE hipGraph (train.EpochWindow: capacity-padded
+    batch slots, the collate launch inside the graph, one upload of the epoch's index arrays).  Two loaders with the same
+    seed draw the same permutations: the window's epoch values and the weights after four epochs are BITWISE those of the
+    per-batch loop (EPOCH_WINDOW off) -- including the last, smaller batch -- and building the window leaves the model
+    untouched (its warm-up epoch is undone)."""
+    from hcatgnet_amd import synth, train
+    sb = synth.make_config(cfg, num_graphs=G)
+    store = H.DeviceGraphStore(sb.as_graph_list(), device="cuda")
+    a = H.make_network("GCN", H.default_options(), feat).cuda()
+    b = H.make_network("GCN", H.default_options(), feat).cuda()
+    b.load_state_dict(a.state_dict())
+    la, lb = H.DeviceLoader(store, batch_size=bs, shuffle=True, seed=11), H.DeviceLoader(store, batch_size=bs, shuffle=True, seed=11)
+    before = [q.detach().clone() for q in a.parameters()]
+    win = train.EpochWindow.build(a, la)
+    assert win is not None, "the epoch window must apply to the reference's own regime"
+    la._hcg_epoch_window = ((id(a), la.batch_size, la.drop_last, len(la.store)), win)
+    assert all(torch.equal(q, r) for q, r in zip(a.parameters(), before))          # the capture's warm-up epoch was undone
+    assert a.optimizer.steps_done() == 0
+    va = [train.train_network(a, la, "cuda") for _ in range(4)]
+    train.EPOCH_WINDOW = False
+    try:
+        vb = [train.train_network(b, lb, "cuda") for _ in range(4)]
+    finally:
+        train.EPOCH_WINDOW = True
+    assert va == vb, (va, vb)
+    for q, r in zip(a.parameters(), b.parameters()):
+        assert torch.equal(q, r)
+    assert a.optimizer.steps_done() == b.optimizer.steps_done() == 4 * len(la)
+    assert va[-1] < va[0]                                                              # and it learns
+    # a scheduler's new learning rate reaches the captured update; reloading the weights rebuilds the window
+    for g in a.optimizer.param_groups + b.optimizer.param_groups:
+        g["lr"] = 0.003
+    b2 = {k: v.clone() for k, v in b.state_dict().items()}
+    a.load_state_dict(b2)
+    va2 = train.train_network(a, la, "cuda")
+    train.EPOCH_WINDOW = False
+    try:
+        vb2 = train.train_network(b, lb, "cuda")
+    finally:
+        train.EPOCH_WINDOW = True
+    assert va2 == vb2
 
 
 def test_train_network_mirror_runs_an_epoch_and_learns(H):

@@ -224,7 +224,10 @@ def test_exchange_probe_failure_in_the_child_is_a_verdict_not_an_exception(monke
         monkeypatch.setenv(k, v)
     if torch.cuda.is_available():
         pytest.skip("the point is a child that cannot reach a GPU")
-    assert bench.isolated_probe(1, False, "sse", timeout_s=240.0) == {"oneshot": False, "captured": False}
+    got = bench.isolated_probe(1, 0, False, "sse", timeout_s=240.0)
+    assert got["oneshot"] is False and got["captured"] is False
+    assert got["exit"] not in (None, 0) and got["seconds"] > 0 and got["note"]          # which phase failed and why is recorded
+    assert bench.PROBE_BUDGET_S <= 120.0
 
 
 def test_trainer_parameter_cache_follows_the_model():

@@ -22,7 +22,19 @@ EP = 20
 for _ in range(EP):
     loss = train_network(model, loader, "cuda")
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / EP
-print(f"MI355X  train_network: {dt * 1e3:8.2f} ms/epoch ({len(loader)} batches of {BS}; {G / dt:10.0f} graphs/s), last epoch loss {loss:.4f}")
+print(f"MI355X  train_network: {dt * 1e3:8.2f} ms/epoch ({len(loader)} batches of {BS}; {G / dt:10.0f} graphs/s), last epoch loss {loss:.4f}"
+      f"  [whole epochs as one hipGraph: {getattr(loader, '_hcg_epoch_window', (None, None))[1] is not None}]")
+from hcatgnet_amd import train as _train
+_train.EPOCH_WINDOW = False
+loader_b = H.DeviceLoader(store, batch_size=BS, shuffle=True, seed=0)
+for _ in range(3):
+    train_network(model, loader_b, "cuda")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(EP):
+    train_network(model, loader_b, "cuda")
+torch.cuda.synchronize(); dtl = (time.perf_counter() - t0) / EP
+_train.EPOCH_WINDOW = True
+print(f"MI355X  train_network: {dtl * 1e3:8.2f} ms/epoch with the per-batch loop (round 2's form)")
 t0 = time.perf_counter()
 for _ in range(EP):
     eval_network(model, loader, "cuda")

@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.log || exit 1
 echo "bench done"
-PROF="--steps 100 --warmup 20 --no-cpu-baseline --no-ragged --sustain 0.3 --distinct-batches 4"
+PROF="--steps 100 --warmup 20 --no-cpu-baseline --no-ragged --sustain 0.3 --distinct-batches 4 --no-parity-gate"
 for cfg in C3 C5 REAL RAGGED; do
   rm -rf /tmp/p_stats
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python $R/bench.py --config $cfg $PROF > /dev/null 2> $O/${tag}_stats_$cfg.log || exit 1
@@ -17,7 +17,7 @@ for cfg in C3 C5 REAL RAGGED; do
   echo "kernel stats $cfg done"
 done
 cp $O/${tag}_kernel_stats_C3.csv $O/${tag}_kernel_stats.csv
-PMC="--steps 10 --warmup 5 --no-cpu-baseline --no-ragged --no-graph --sustain 0 --distinct-batches 2"
+PMC="--steps 10 --warmup 5 --no-cpu-baseline --no-ragged --no-graph --sustain 0 --distinct-batches 2 --no-parity-gate"
 rm -f $O/${tag}_traffic.json
 for cfg in C3 C5 REAL; do
   rm -rf /tmp/p_fetch /tmp/p_write
@@ -26,6 +26,13 @@ for cfg in C3 C5 REAL; do
   python $R/tools/pmc_traffic.py /tmp/p_fetch /tmp/p_write $O/${tag}_traffic.json $cfg > $O/${tag}_traffic_$cfg.txt
   echo "pmc $cfg done"
 done
+# SQ counters of the C3 kernels (the headline's limiter measured, not argued): wave cycles, waits, instruction mix
+rm -rf /tmp/p_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/p_sq -- python $R/bench.py --config C3 $PMC > /dev/null 2> $O/${tag}_sq_C3.log || exit 1
+python $R/tools/pmc_sq.py /tmp/p_sq > $O/${tag}_sq_c3.txt
+rm -rf /tmp/p_sq2
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/p_sq2 -- python $R/bench.py --config C3 $PMC > /dev/null 2> $O/${tag}_sq2_C3.log && python $R/tools/pmc_sq.py /tmp/p_sq2 >> $O/${tag}_sq_c3.txt
+echo "sq C3 done"
 [ "$2" = quick ] && { echo "all done (quick)"; exit 0; }
 python $R/bench.py --forward-only --no-cpu-baseline > $O/${tag}_bench_forward_only_C2.json 2>/dev/null || exit 1
 python $R/bench.py --config REAL --steps 100 --warmup 10 --no-cpu-baseline > $O/${tag}_bench_REAL.json 2>/dev/null || exit 1
