@@ -17,6 +17,9 @@ HCG_PLAN_GENERAL, HCG_PLAN_BLOCKED, HCG_PLAN_PTRS_ONLY, HCG_PLAN_KEEP_STATUS = 0
 HCG_ACT_NONE, HCG_ACT_LEAKY = 0, 1
 HCG_LOSS_MSE, HCG_LOSS_RMSE, HCG_LOSS_SSE = 0, 1, 2      # loss modes of hcg_step_tail / hcg_loss_finalize / hcg_loss_fwd_bwd
 HCG_HEAD_FORWARD_ONLY = 1
+HCG_WS_PLAN, HCG_WS_LINEAR, HCG_WS_GCN_LAYER_BWD, HCG_WS_READOUT2 = 0, 1, 2, 3        # hcg_general_workspace_bytes kinds
+HCG_FUSED_POOLBITS, HCG_FUSED_HEAD_WS = 0, 1                                          # hcg_fused_aux_bytes kinds
+HCG_STRUCT_REDUCE_JOB, HCG_STRUCT_TAIL_ARGS, HCG_STRUCT_FUSED_FWD_ARGS = 0, 1, 2     # hcg_struct_bytes
 HCG_REDUCE_MAX_JOBS, HCG_REDUCE_MAX_SEGS = 8, 4
 HCG_XCHG_MEAN, HCG_XCHG_SSE, HCG_XCHG_ERR_TIMEOUT, HCG_XCHG_MAX_WORLD = 0, 1, 1, 8
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
@@ -60,24 +63,21 @@ class FusedFwdArgs(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol of include/hcatgnet_hip.h
 SIGNATURES = {
     "hcg_version": (INT, []),
+    "hcg_struct_bytes": (SZ, [INT]),
+    "hcg_general_workspace_bytes": (SZ, [INT, I64, I64, I64, INT]),
+    "hcg_fused_aux_bytes": (SZ, [INT, I64, INT]),
     "hcg_error_string": (c_char_p, [INT]),
-    "hcg_plan_workspace_bytes": (SZ, [I64, I64, I64, INT]),
     "hcg_plan_build": (INT, [P, P, P, I64, I64, I64, F32, INT, P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
-    "hcg_linear_workspace_bytes": (SZ, [I64, I64, I64]),
     "hcg_linear_fwd": (INT, [P, P, P, P, I64, I64, I64, INT, F32, P]),
     "hcg_linear_bwd": (INT, [P, P, P, P, P, P, P, P, I64, I64, I64, INT, F32, P, SZ, P]),
     "hcg_gcn_layer_fwd": (INT, [P, P, P, P, P, P, P, F32, F32, INT, P, P, I64, I64, I64, I64, P]),
-    "hcg_gcn_layer_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
     "hcg_gcn_layer_bwd": (INT, [P, P, P, P, P, P, P, P, F32, F32, INT, P, P, P, P, I64, I64, I64, I64, P, SZ, P]),
     "hcg_gcn_edge_weight_grad": (INT, [P, P, P, P, P, P, F32, INT, P, I64, I64, I64, P]),
     "hcg_pool_fwd": (INT, [P, P, P, I64, I64, I64, P]),
     "hcg_pool_bwd": (INT, [P, P, P, P, P, I64, I64, I64, P]),
     "hcg_fused_graphs_per_tile": (INT, [I64, I64, I64]),
     "hcg_fused_workspace_bytes": (SZ, [I64, I64, I64, INT]),
-    "hcg_fused_poolbits_bytes": (SZ, [I64, INT]),
-    "hcg_fused_fwd_args_bytes": (SZ, []),
     "hcg_fused_forward": (INT, [P, P]),
-    "hcg_fused_head_workspace_bytes": (SZ, [I64, INT]),
     "hcg_fused_head_reduce_job": (INT, [P, SZ, I64, INT, I64, P, P, P, P, P]),
     "hcg_fused_layer_bwd": (INT, [P, P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, INT, F32, INT, P, P, P, SZ, P]),
     "hcg_mid_supported": (INT, [I64, I64, I64, I64]),
@@ -90,12 +90,10 @@ SIGNATURES = {
     "hcg_tall_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, P, SZ, P]),
     "hcg_tall_layer_bwd": (INT, [P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, SZ, P]),
     "hcg_tall_reduce_jobs": (INT, [P, SZ, I64, I64, I64, I64, P, P, P]),
-    "hcg_reduce_job_bytes": (SZ, []),
     "hcg_fused_reduce_job": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
     "hcg_readout2_bwd_partial": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, SZ, P]),
     "hcg_readout2_reduce_job": (INT, [P, SZ, I64, I64, P, P, P, P, P]),
     "hcg_reduce_job_append": (INT, [P, P]),
-    "hcg_tail_args_bytes": (SZ, []),
     "hcg_step_tail": (INT, [P, P]),
     "hcg_loss_finalize": (INT, [P, F32, INT, P, P, P]),
     "hcg_collate": (INT, [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P]),
@@ -103,10 +101,7 @@ SIGNATURES = {
     "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
     "hcg_mse_bwd": (INT, [P, P, P, I64, P, P, P]),
     "hcg_loss_fwd_bwd": (INT, [P, P, I64, INT, P, P, P, P]),
-    "hcg_readout2_supported": (INT, [I64, I64]),
-    "hcg_readout2_workspace_bytes": (SZ, [I64]),
     "hcg_readout2_fwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P]),
-    "hcg_readout2_bwd": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P, SZ, P]),
     "hcg_head_supported": (INT, [I64, I64]),
     "hcg_head_workspace_bytes": (SZ, [I64, I64]),
     "hcg_head_fwd_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, F32, INT, P, P, P, P, SZ, P, P]),
@@ -239,6 +234,11 @@ def step_tail(jobs_addr: int, njobs: int, *, loss=None, loss_mode: int = HCG_LOS
         a.inbox, a.peers_host, a.rank, a.world, a.xchg_mode = xchg["inbox"], xchg["peers_host"], xchg["rank"], xchg["world"], xchg["mode"]
         a.xchg_err = xchg["err"].data_ptr()
     check(load().hcg_step_tail(ctypes.addressof(a), stream_ptr()), "hcg_step_tail")
+
+
+def job_bytes() -> int:
+    """sizeof(hcg_reduce_job): the stride of a host array of jobs (tests/test_host_cpu.py checks the mirror against the library)."""
+    return ctypes.sizeof(ReduceJob)
 
 
 def reduce_jobs(jobs_addr: int, njobs: int):

@@ -1040,7 +1040,7 @@ extern "C" size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int
 }
 
 // workspace of the head in the forward's tail: one slab (gradient partial sums + SSE partial) per workgroup of the launch
-extern "C" size_t hcg_fused_head_workspace_bytes(int64_t B, int graphs_per_tile) {
+static size_t fused_head_workspace_bytes(int64_t B, int graphs_per_tile) {
   if (graphs_per_tile <= 0 || B <= 0) return 0;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   return hcg_align_up((size_t)pick_grid(tiles) * (hcg_head::HC<DD>::SLAB + 1) * sizeof(float), 256) + 256;
@@ -1050,7 +1050,7 @@ extern "C" int hcg_fused_head_reduce_job(const void* workspace, size_t workspace
                                          float* dW0, float* db0, float* dW1, float* db1, hcg_reduce_job* job) {
   if (B <= 0 || graphs_per_tile < 1 || C < 1 || C > hcg_head::RCMAX || !job || !workspace) return HCG_ERR_INVALID_ARG;
   if (dW0 && (!db0 || !dW1 || !db1)) return HCG_ERR_INVALID_ARG;
-  if (workspace_bytes < hcg_fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
+  if (workspace_bytes < fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
   const int tiles = (int)((B + graphs_per_tile - 1) / graphs_per_tile);
   hcg_head::head_fill_job<DD>((const float*)workspace, pick_grid(tiles), (int)C, dW0, db0, dW1, db1, job);
   return HCG_OK;
@@ -1059,8 +1059,6 @@ extern "C" int hcg_fused_head_reduce_job(const void* workspace, size_t workspace
 // Every forward form of the small-graph tiles: one or two stacked conv layers, optional [max, mean] pooling of the last one,
 // optional training form (the pooled layer's activations stay on chip, 2 bits per element leave), optional readout head in
 // the tail of the launch.
-extern "C" size_t hcg_fused_fwd_args_bytes(void) { return sizeof(hcg_fused_fwd_args); }
-
 extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t stream_) {
   if (!a) return HCG_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1093,7 +1091,7 @@ extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t strea
     if (a->C < 1 || a->C > hcg_head::RCMAX) return HCG_ERR_UNSUPPORTED;
     if (!a->y || !a->head_b0 || !a->head_W1 || !a->head_b1 || !a->z || !a->out || (head_bwd && !a->demb) || !a->head_workspace)
       return HCG_ERR_INVALID_ARG;
-    if (a->head_workspace_bytes < hcg_fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
+    if (a->head_workspace_bytes < fused_head_workspace_bytes(B, graphs_per_tile)) return HCG_ERR_WORKSPACE;
     H = FwdHead{a->y, a->head_W0, a->head_b0, a->head_W1, a->head_b1, (int)a->C, a->z, a->out, a->demb, (float*)a->head_workspace,
                 (int*)a->step_counter};
   }
@@ -1121,9 +1119,12 @@ extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t strea
   return HCG_OK;
 }
 
-// 2 bits per element of the pooled layer (training forms): see k_fused_layer_fwd<BITS>
-extern "C" size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile) {
+// kind HCG_FUSED_POOLBITS: 2 bits per element of the pooled layer (training forms, see k_fused_layer_fwd<BITS>);
+// kind HCG_FUSED_HEAD_WS: the head-in-the-forward's slabs + SSE partials
+extern "C" size_t hcg_fused_aux_bytes(int kind, int64_t B, int graphs_per_tile) {
   if (graphs_per_tile <= 0 || B <= 0) return 0;
+  if (kind == HCG_FUSED_HEAD_WS) return fused_head_workspace_bytes(B, graphs_per_tile);
+  if (kind != HCG_FUSED_POOLBITS) return 0;
   return (size_t)((B + graphs_per_tile - 1) / graphs_per_tile) * 128 * sizeof(uint32_t);
 }
 

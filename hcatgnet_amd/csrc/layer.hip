@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
 }  // namespace
 
 // ------------------------------------------------------------------------------ dense linear
-extern "C" size_t hcg_linear_workspace_bytes(int64_t M, int64_t D_in, int64_t D_out) {
+static size_t linear_workspace_bytes(int64_t M, int64_t D_in, int64_t D_out) {
   size_t f = hcg_gemm_partial_floats(D_out, D_in, M, nullptr) + hcg_colsum_partial_floats(M, D_out);
   return hcg_align_up(f * sizeof(float), 256) + 512;
 }
@@ -202,9 +202,17 @@ extern "C" int hcg_gcn_layer_fwd(const float* x, const float* W, const float* b,
                                  stream);                                                      // a5-a8
 }
 
-extern "C" size_t hcg_gcn_layer_bwd_workspace_bytes(int64_t N, int64_t F, int64_t D) {
-  size_t f = hcg_gemm_partial_floats(D, F, N, nullptr) + hcg_colsum_partial_floats(N, D);
-  return hcg_align_up(f * sizeof(float), 256) + 512;
+// workspace sizes of the any-shape entry points, one query (a, b, c as the kind names them)
+size_t hcg_plan_workspace_bytes_impl(int64_t N, int64_t E, int64_t B, int mode);   // plan.hip
+size_t hcg_readout2_workspace_bytes_impl(int64_t B);                               // readout.hip
+extern "C" size_t hcg_general_workspace_bytes(int kind, int64_t a, int64_t b, int64_t c, int mode) {
+  switch (kind) {
+    case HCG_WS_PLAN: return hcg_plan_workspace_bytes_impl(a, b, c, mode);
+    case HCG_WS_LINEAR: return linear_workspace_bytes(a, b, c);           // M, D_in, D_out
+    case HCG_WS_GCN_LAYER_BWD: return linear_workspace_bytes(a, b, c);    // N, F, D: dW = dH^T X split-K + the bias column sum
+    case HCG_WS_READOUT2: return hcg_readout2_workspace_bytes_impl(a);    // B
+    default: return 0;
+  }
 }
 
 extern "C" int hcg_gcn_layer_bwd(const float* dout, const float* out, const float* x, const float* W,

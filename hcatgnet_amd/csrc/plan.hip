@@ -209,7 +209,7 @@ int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) <= v && b < 31) ++
 
 }  // namespace
 
-extern "C" size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode) {
+size_t hcg_plan_workspace_bytes_impl(int64_t N, int64_t E, int64_t B, int mode) {
   (void)N; (void)B;
   if ((mode & ~(HCG_PLAN_PTRS_ONLY | HCG_PLAN_KEEP_STATUS)) == HCG_PLAN_BLOCKED || E <= 0) return 256;
   const size_t keys = hcg_align_up((size_t)E * sizeof(uint64_t), 256);

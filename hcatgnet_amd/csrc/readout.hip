@@ -274,9 +274,9 @@ int readout_fwd_grid(int64_t B) {
 }  // namespace
 
 // 1 when the fused readout applies: two readout layers [2D -> D -> C], D = 64, C <= 8
-extern "C" int hcg_readout2_supported(int64_t D, int64_t C) { return (D == RD && C >= 1 && C <= RCMAX) ? 1 : 0; }
+static int hcg_readout2_supported(int64_t D, int64_t C) { return (D == RD && C >= 1 && C <= RCMAX) ? 1 : 0; }
 
-extern "C" size_t hcg_readout2_workspace_bytes(int64_t B) { return (size_t)readout_grid(B) * SLAB * sizeof(float) + 256; }
+size_t hcg_readout2_workspace_bytes_impl(int64_t B) { return (size_t)readout_grid(B) * SLAB * sizeof(float) + 256; }
 
 extern "C" int hcg_readout2_fwd(const float* emb, const float* W0, const float* b0, const float* W1, const float* b1,
                                 int64_t B, int64_t D, int64_t C, float slope, float* z, float* out, hcg_stream_t stream) {
@@ -288,37 +288,6 @@ extern "C" int hcg_readout2_fwd(const float* emb, const float* W0, const float* 
                      (int)B, (int)C, slope, z, out);
   HCG_CHECK_LAUNCH();
   return HCG_OK;
-}
-
-extern "C" int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const float* W0, const float* W1,
-                                int64_t B, int64_t D, int64_t C, float slope, float* demb, float* dW0, float* db0,
-                                float* dW1, float* db1, void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!hcg_readout2_supported(D, C)) return HCG_ERR_UNSUPPORTED;
-  if (B < 0 || !dW0 || !db0 || !dW1 || !db1 || !W0 || !W1) return HCG_ERR_INVALID_ARG;
-  if (B > 0 && (!dout || !emb || !z || !demb)) return HCG_ERR_INVALID_ARG;
-  const int grid = B > 0 ? readout_grid(B) : 0;
-  if (workspace_bytes < (size_t)grid * SLAB * sizeof(float)) return HCG_ERR_WORKSPACE;
-  if (grid > 0) {
-    hipLaunchKernelGGL(k_readout_bwd, dim3(grid), dim3(RWAVES * 64), 0, stream, dout, emb, z, W0, W1, (int)B, (int)C,
-                       slope, demb, (float*)workspace);
-    HCG_CHECK_LAUNCH();
-  }
-  if (grid == 0) {   // empty batch: the gradients are zero
-    HCG_TRY(hcg_hip_err(hipMemsetAsync(dW0, 0, sizeof(float) * RD * RK, stream)));
-    HCG_TRY(hcg_hip_err(hipMemsetAsync(db0, 0, sizeof(float) * RD, stream)));
-    HCG_TRY(hcg_hip_err(hipMemsetAsync(dW1, 0, sizeof(float) * C * RD, stream)));
-    HCG_TRY(hcg_hip_err(hipMemsetAsync(db1, 0, sizeof(float) * C, stream)));
-    return HCG_OK;
-  }
-  // the shared slab-reduction kernel (same summation order as the batched reduction of a whole step)
-  hcg_reduce_job job;
-  const int rc = hcg_readout2_reduce_job(workspace, workspace_bytes, B, C, dW0, db0, dW1, db1, &job);
-  if (rc != HCG_OK) return rc;
-  hcg_tail_args ta{};
-  ta.jobs_host = &job;
-  ta.njobs = 1;
-  return hcg_step_tail(&ta, stream_);
 }
 
 // backward without the slab reduction (pair with hcg_readout2_reduce_job + hcg_step_tail)

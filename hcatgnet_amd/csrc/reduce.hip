@@ -292,8 +292,15 @@ extern "C" int hcg_xchg_resident_blocks(void) {
   return cap;
 }
 
-extern "C" size_t hcg_tail_args_bytes(void) { return sizeof(hcg_tail_args); }
-extern "C" size_t hcg_reduce_job_bytes(void) { return sizeof(hcg_reduce_job); }
+// sizeof of the ABI's HOST structs, for bindings to check their mirrors against
+extern "C" size_t hcg_struct_bytes(int which) {
+  switch (which) {
+    case HCG_STRUCT_REDUCE_JOB: return sizeof(hcg_reduce_job);
+    case HCG_STRUCT_TAIL_ARGS: return sizeof(hcg_tail_args);
+    case HCG_STRUCT_FUSED_FWD_ARGS: return sizeof(hcg_fused_fwd_args);
+    default: return 0;
+  }
+}
 
 extern "C" int hcg_step_tail(const hcg_tail_args* a, hcg_stream_t stream_) {
   if (!a) return HCG_ERR_INVALID_ARG;

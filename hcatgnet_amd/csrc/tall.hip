@@ -71,12 +71,8 @@ __global__ __launch_bounds__(TT, 4) void k_tall_mm(const float* __restrict__ A, 
       int k0 = (c * CK + s) * 16 + 8 * h, k1 = k0 + 4;
       if (k0 > lda - 4) k0 = lda - 4;
       if (k1 > lda - 4) k1 = lda - 4;
-#ifdef HCG_PROBE_NOLOAD
-      const float4 v0 = make_float4((float)k0, 1.f, 2.f, 3.f), v1 = make_float4((float)k1, (float)row, 1.f, 0.f);
-#else
       const float4 v0 = *reinterpret_cast<const float4*>(base + k0);
       const float4 v1 = *reinterpret_cast<const float4*>(base + k1);
-#endif
       a[s][0] = v0.x; a[s][1] = v0.y; a[s][2] = v0.z; a[s][3] = v0.w;
       a[s][4] = v1.x; a[s][5] = v1.y; a[s][6] = v1.z; a[s][7] = v1.w;
     }
@@ -102,12 +98,8 @@ __global__ __launch_bounds__(TT, 4) void k_tall_mm(const float* __restrict__ A, 
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
           const short* w0 = wl + ((nb0 + nb) * 32 + r) * ld + (c * CK + s) * 16 + 8 * h;
-#ifdef HCG_PROBE_NOMFMA
-          acc[nb][0] += cur[s][nb] + (float)As.p1[0] + (float)(*reinterpret_cast<const bf16x8*>(w0))[0];
-#else
           mfma_split(acc[nb], As, *reinterpret_cast<const bf16x8*>(w0), *reinterpret_cast<const bf16x8*>(w0 + plane),
                      *reinterpret_cast<const bf16x8*>(w0 + 2 * plane));
-#endif
         }
       }
 #pragma unroll
@@ -139,11 +131,7 @@ __global__ __launch_bounds__(TT, 4) void k_tall_mm(const float* __restrict__ A, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = row0 + krow(i, h);
-#ifdef HCG_PROBE_NOSTORE
-        if (row < N && col < ldo && acc[nb][i] == 1.2345e30f) out[(size_t)row * ldo + col] = acc[nb][i];
-#else
         if (row < N && col < ldo) out[(size_t)row * ldo + col] = acc[nb][i];
-#endif
       }
     }
   }

@@ -77,7 +77,7 @@ class _GCNLayerFn(torch.autograd.Function):
         dW = torch.empty_like(weight)
         db = torch.empty(D, dtype=torch.float32, device=dev)
         dh_ws = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
-        wsb = lib.hcg_gcn_layer_bwd_workspace_bytes(N, F, D)
+        wsb = lib.hcg_general_workspace_bytes(_lib.HCG_WS_GCN_LAYER_BWD, N, F, D, 0)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         ew = plan.ew_csc if ctx.use_ew else (saved[3] if ctx.masked else None)
         fill = plan.fill if ctx.use_ew else 1.0
@@ -173,7 +173,7 @@ class _LinearFn(torch.autograd.Function):
         dW = torch.empty_like(weight)
         db = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_bias else None
         dz = torch.empty(max(M, 1), O, dtype=torch.float32, device=dev)
-        wsb = lib.hcg_linear_workspace_bytes(M, K, O)
+        wsb = lib.hcg_general_workspace_bytes(_lib.HCG_WS_LINEAR, M, K, O, 0)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = lib.hcg_linear_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(dx), _lib.ptr(dW),
                                 _lib.ptr(db), _lib.ptr(dz), M, K, O,
@@ -293,7 +293,7 @@ class _MidLayerFn(torch.autograd.Function):
                                    plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
                                    _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)
         _lib.check(rc, "hcg_mid_layer_bwd")
-        jb, halves = lib.hcg_reduce_job_bytes(), D // 64          # one slab set (= one job) per 64-column half
+        jb, halves = _lib.job_bytes(), D // 64          # one slab set (= one job) per 64-column half
         jobs = ctypes.create_string_buffer(jb * halves)
         for half in range(halves):
             _lib.check(lib.hcg_mid_reduce_job(_lib.ptr(ws), wsb, plan.B, F, D, plan.max_nodes, plan.max_edges, half,
@@ -370,7 +370,7 @@ class _TallLayerFn(torch.autograd.Function):
                                     plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
                                     _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)
         _lib.check(rc, "hcg_tall_layer_bwd")
-        jb = lib.hcg_reduce_job_bytes()
+        jb = _lib.job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
         _lib.check(lib.hcg_tall_reduce_jobs(_lib.ptr(ws), wsb, N, plan.B, F, D, _lib.ptr(dW), _lib.ptr(db),
                                             ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
@@ -429,12 +429,15 @@ class _Readout2Fn(torch.autograd.Function):
         dW0, dW1 = torch.empty_like(W0), torch.empty_like(W1)
         db0 = torch.empty(D, dtype=torch.float32, device=dev)
         db1 = torch.empty(C, dtype=torch.float32, device=dev)
-        wsb = lib.hcg_readout2_workspace_bytes(B)
+        wsb = lib.hcg_general_workspace_bytes(_lib.HCG_WS_READOUT2, B, 0, 0, 0)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        rc = lib.hcg_readout2_bwd(_lib.ptr(dout), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(W0), _lib.ptr(W1), B, D, C, ctx.slope,
-                                  _lib.ptr(demb), _lib.ptr(dW0), _lib.ptr(db0), _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(ws),
-                                  wsb, _lib.stream_ptr())
-        _lib.check(rc, "hcg_readout2_bwd")
+        rc = lib.hcg_readout2_bwd_partial(_lib.ptr(dout), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(W0), _lib.ptr(W1), B, D, C, ctx.slope,
+                                          _lib.ptr(demb), _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "hcg_readout2_bwd_partial")
+        job = _lib.ReduceJob()
+        _lib.check(lib.hcg_readout2_reduce_job(_lib.ptr(ws), wsb, B, C, _lib.ptr(dW0), _lib.ptr(db0), _lib.ptr(dW1), _lib.ptr(db1),
+                                               ctypes.addressof(job)), "hcg_readout2_reduce_job")
+        _lib.reduce_jobs(ctypes.addressof(job), 1)
         return demb, dW0, db0, dW1, db1, None
 
 
@@ -472,7 +475,7 @@ def mse_loss(inp, target):
 
 
 def readout2_supported(D: int, C: int) -> bool:
-    return bool(_lib.load().hcg_readout2_supported(D, C))
+    return D == 64 and bool(_lib.load().hcg_head_supported(D, C))
 
 
 def readout2(emb, W0, b0, W1, b1, slope=LEAKY_SLOPE):
@@ -540,7 +543,7 @@ class _FusedModelFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         # every backward kernel leaves per-workgroup slabs; ONE batched launch reduces them all at the end
         import ctypes
-        jb = lib.hcg_reduce_job_bytes()
+        jb = _lib.job_bytes()
         batched = n_conv + 1 <= 8
         jobs = ctypes.create_string_buffer(jb * 8) if batched else None
         jaddr = ctypes.addressof(jobs) if batched else 0
@@ -564,7 +567,7 @@ class _FusedModelFn(torch.autograd.Function):
         # readout head
         dy = _f32c(dy) if dy is not None else torch.zeros(B, C, **f32)
         demb = torch.empty_like(emb)
-        wsb = lib.hcg_readout2_workspace_bytes(B)
+        wsb = lib.hcg_general_workspace_bytes(_lib.HCG_WS_READOUT2, B, 0, 0, 0)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         keep.append(ws)
         if batched:
@@ -574,10 +577,13 @@ class _FusedModelFn(torch.autograd.Function):
             _lib.check(lib.hcg_readout2_reduce_job(_lib.ptr(ws), wsb, B, C, _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w),
                                                    _lib.ptr(dR1b), jaddr), "hcg_readout2_reduce_job")
         else:
-            rc = lib.hcg_readout2_bwd(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C, slope,
-                                      _lib.ptr(demb), _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w), _lib.ptr(dR1b),
-                                      _lib.ptr(ws), wsb, stream)
-            _lib.check(rc, "hcg_readout2_bwd")
+            rc = lib.hcg_readout2_bwd_partial(_lib.ptr(dy), _lib.ptr(emb), _lib.ptr(z), _lib.ptr(R0w), _lib.ptr(R1w), B, D, C,
+                                              slope, _lib.ptr(demb), _lib.ptr(ws), wsb, stream)
+            _lib.check(rc, "hcg_readout2_bwd_partial")
+            rjob = _lib.ReduceJob()
+            _lib.check(lib.hcg_readout2_reduce_job(_lib.ptr(ws), wsb, B, C, _lib.ptr(dR0w), _lib.ptr(dR0b), _lib.ptr(dR1w),
+                                                   _lib.ptr(dR1b), ctypes.addressof(rjob)), "hcg_readout2_reduce_job")
+            _lib.reduce_jobs(ctypes.addressof(rjob), 1)
         if demb_ext is not None:          # the caller also used graph_emb downstream
             demb = demb + _f32c(demb_ext)
         # conv stack, last layer first

@@ -72,7 +72,7 @@ class BatchPlan:
             m |= _lib.HCG_PLAN_PTRS_ONLY
         if self.shared_status:
             m |= _lib.HCG_PLAN_KEEP_STATUS
-        wsb = lib.hcg_plan_workspace_bytes(N, E, B, m)
+        wsb = lib.hcg_general_workspace_bytes(_lib.HCG_WS_PLAN, N, E, B, m)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         p = _lib.ptr
         rc = lib.hcg_plan_build(p(self.edge_index), p(self.batch), p(self.edge_weight), N, E, B, self.fill, m,

@@ -174,7 +174,7 @@ class FusedTrainStep:
             # head slabs: the stand-alone head's (<= one per CU) or the forward tail's (one per workgroup of the tile launch:
             # graphs_per_tile 1 bounds it)
             hb = max(lib.hcg_head_workspace_bytes(capB, D if lib.hcg_head_supported(D, C) else 64),
-                     lib.hcg_fused_head_workspace_bytes(capB, 1))
+                     lib.hcg_fused_aux_bytes(_lib.HCG_FUSED_HEAD_WS, capB, 1))
             cap = {"sig": sig, "N": capN, "B": capB,
                    "acts": [torch.empty(capN, D, **f32) for _ in range(n_conv)],
                    "dacts": [torch.empty(capN, D, **f32) for _ in range(n_conv - 1)],
@@ -214,8 +214,8 @@ class FusedTrainStep:
             u8 = dict(dtype=torch.uint8, device=dev)
             hb = {"B": B, "dout": torch.empty(B, C, **f32), "dz": torch.empty(B, D, **f32),
                   "dz_ws1": torch.empty(B, C, **f32), "dz_ws0": torch.empty(B, D, **f32),
-                  "ws1": torch.empty(max(lib.hcg_linear_workspace_bytes(B, D, C), 256), **u8),
-                  "ws0": torch.empty(max(lib.hcg_linear_workspace_bytes(B, 2 * D, D), 256), **u8)}
+                  "ws1": torch.empty(max(lib.hcg_general_workspace_bytes(_lib.HCG_WS_LINEAR, B, D, C, 0), 256), **u8),
+                  "ws0": torch.empty(max(lib.hcg_general_workspace_bytes(_lib.HCG_WS_LINEAR, B, 2 * D, D, 0), 256), **u8)}
             bufs["ws"]["head_generic"] = hb
         return hb
 
@@ -271,7 +271,7 @@ class FusedTrainStep:
         c.bs = [HF._f32c(cv.bias) for cv in convs]
         c.head_fused = bool(lib.hcg_head_supported(c.D, c.C))
         c.n_small = self._size_groups(batch, plan, convs, c.D, c.C, c.n_conv)
-        c.jb = lib.hcg_reduce_job_bytes()
+        c.jb = _lib.job_bytes()
         c.jobs = ctypes.create_string_buffer(c.jb * _lib.HCG_REDUCE_MAX_JOBS)
         c.jaddr, c.njobs = ctypes.addressof(c.jobs), 0
         c.flat = c.gaddr = c.step_word = None
@@ -343,7 +343,7 @@ class FusedTrainStep:
     def _forward_with_head(self, c: _Ctx):
         """conv stack + pooling + readout head (forward, squared error, unscaled readout backward): one launch."""
         lib, bufs, gpt = _lib.load(), c.bufs, c.gpts[0]
-        c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_poolbits_bytes(c.B, gpt), c.dev)
+        c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_aux_bytes(_lib.HCG_FUSED_POOLBITS, c.B, gpt), c.dev)
         l0, l1 = c.l0, c.l1
         _lib.fused_forward(**self._tiles_args(
             c, c.B, gpt, poolbits=c.poolbits, y=c.y2, head_W0=HF._f32c(l0.weight), head_b0=HF._f32c(l0.bias),
@@ -365,7 +365,7 @@ class FusedTrainStep:
         # small-graph tiles: the pooled layer's activations stay on chip, two bits per element (sign, is-the-column-max)
         # are all its backward needs of them
         if gpts[-1] > 0 and self.POOLBITS:
-            c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_poolbits_bytes(B, gpts[-1]), c.dev)
+            c.poolbits = self._ws(bufs, "poolbits", lib.hcg_fused_aux_bytes(_lib.HCG_FUSED_POOLBITS, B, gpts[-1]), c.dev)
         if n_conv == 2 and gpts[0] == gpts[1] and gpts[0] > 0:
             _lib.fused_forward(**self._tiles_args(c, B, gpts[0], poolbits=c.poolbits,
                                                   out2=None if c.poolbits is not None else acts[1]))
@@ -404,7 +404,7 @@ class FusedTrainStep:
         acts, emb = bufs["acts"], bufs["emb"]
         emb_b = emb.data_ptr() + 4 * 2 * c.D * Bs
         gpt = int(lib.hcg_fused_graphs_per_tile(c.F, c.D, 32))
-        c.poolbits = self._ws(bufs, "poolbits_r", lib.hcg_fused_poolbits_bytes(Bs, gpt), c.dev)
+        c.poolbits = self._ws(bufs, "poolbits_r", lib.hcg_fused_aux_bytes(_lib.HCG_FUSED_POOLBITS, Bs, gpt), c.dev)
         mxn, mxe = plan.max_nodes, plan.max_edges
         fork()
         _lib.fused_forward(**self._tiles_args(c, Bs, gpt, poolbits=c.poolbits))

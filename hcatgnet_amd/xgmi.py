@@ -136,7 +136,7 @@ class OneShotExchange:
             fl = opt._flat[0]
             loss = torch.zeros(2, device=dev)
             # one reduction job over ONE slab = the data itself
-            jb = self.lib.hcg_reduce_job_bytes()
+            jb = _lib.job_bytes()
             job = ctypes.create_string_buffer(jb)
             slab = torch.empty(n, device=dev)
 

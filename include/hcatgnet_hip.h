@@ -72,7 +72,13 @@ const char* hcg_error_string(int code);
 
 /* ---- batch plan: gcn_norm + CSR/CSC + graph_ptr, ONCE per batch (reference recomputes
  *      gcn_norm every layer, every step: PyG GCNConv(cached=False)) ---------- */
-size_t hcg_plan_workspace_bytes(int64_t N, int64_t E, int64_t B, int mode);
+/* workspace sizes of the any-shape entry points, ONE query: kind HCG_WS_PLAN (a, b, c = N, E, B; mode = the plan flags),
+ * HCG_WS_LINEAR (M, D_in, D_out), HCG_WS_GCN_LAYER_BWD (N, F, D), HCG_WS_READOUT2 (B) */
+#define HCG_WS_PLAN 0
+#define HCG_WS_LINEAR 1
+#define HCG_WS_GCN_LAYER_BWD 2
+#define HCG_WS_READOUT2 3
+size_t hcg_general_workspace_bytes(int kind, int64_t a, int64_t b, int64_t c, int mode);
 
 /* Outputs (all caller-allocated):
  *   graph_ptr [B+1]  node range of each graph                    (a9's `batch`)
@@ -98,7 +104,6 @@ int hcg_plan_build(const int64_t* edge_index, const int64_t* batch, const float*
                    void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
 /* ---- dense linear (a4, a10):  y = act(x W^T + b),  W is [D_out, D_in] like nn.Linear ------ */
-size_t hcg_linear_workspace_bytes(int64_t M, int64_t D_in, int64_t D_out);
 int hcg_linear_fwd(const float* x, const float* W, const float* b /*nullable*/, float* y,
                    int64_t M, int64_t D_in, int64_t D_out, int act, float slope, hcg_stream_t stream);
 /* dz = dy * act'(y) is formed internally (y = saved OUTPUT); then dW = dz^T x, db = colsum dz,
@@ -119,7 +124,6 @@ int hcg_gcn_layer_fwd(const float* x, const float* W, const float* b,
                       hcg_stream_t stream);
 /* backward of the above.  `out` = saved output (gives the LeakyReLU mask), `x` = saved input.
  *   dh_ws: caller buffer [N, D].  dx nullable (first layer: x has no grad). */
-size_t hcg_gcn_layer_bwd_workspace_bytes(int64_t N, int64_t F, int64_t D);
 int hcg_gcn_layer_bwd(const float* dout, const float* out, const float* x, const float* W,
                       const int32_t* rowptr_t, const int32_t* col_t, const float* ew_csc /*nullable*/,
                       const float* dinv, float fill, float slope, int apply_act,
@@ -164,13 +168,13 @@ size_t hcg_fused_workspace_bytes(int64_t B, int64_t F, int64_t D, int graphs_per
  *   poolbits != NULL training form of the POOLED (last) layer: its node activations never reach HBM (out2 / out1 of a single
  *                    layer = NULL).  All the pooled backward needs of them is, per element, the sign (LeakyReLU') and
  *                    whether it is its graph's column maximum (torch amax backward: ties share the gradient evenly) -- they
- *                    leave as two bits per element (hcg_fused_poolbits_bytes: 512 B per 32-row tile, in the matrix-core
+ *                    leave as two bits per element (hcg_fused_aux_bytes: 512 B per 32-row tile, in the matrix-core
  *                    accumulator layout) and hcg_fused_layer_bwd over the SAME plan and graphs_per_tile reads them in
  *                    place of `out` and `emb`
  *   head_W0 != NULL  (stacked training form only) the regression head in the TAIL of the same launch: every workgroup runs
  *                    readout forward, squared error and (unless head_flags = HCG_HEAD_FORWARD_ONLY) the unscaled readout
  *                    backward over its own graphs -- see hcg_head_fwd_bwd for the contract of y / z / out / demb /
- *                    step_counter; head_workspace (hcg_fused_head_workspace_bytes) gets one gradient slab + SSE partial per
+ *                    step_counter; head_workspace (hcg_fused_aux_bytes) gets one gradient slab + SSE partial per
  *                    workgroup, described by hcg_fused_head_reduce_job.  A training step is then FOUR launches: this one,
  *                    two backward launches, hcg_step_tail.
  * Replaces reference model/gcn.py:58-66 (+ :70-71 with the head). */
@@ -207,10 +211,10 @@ typedef struct hcg_fused_fwd_args {
   size_t head_workspace_bytes;
   int32_t* step_counter;      /* nullable */
 } hcg_fused_fwd_args;
-size_t hcg_fused_fwd_args_bytes(void);
 int hcg_fused_forward(const hcg_fused_fwd_args* args_host, hcg_stream_t stream);
-size_t hcg_fused_poolbits_bytes(int64_t B, int graphs_per_tile);
-size_t hcg_fused_head_workspace_bytes(int64_t B, int graphs_per_tile);
+#define HCG_FUSED_POOLBITS 0 /* bytes of `poolbits` */
+#define HCG_FUSED_HEAD_WS 1  /* bytes of `head_workspace` */
+size_t hcg_fused_aux_bytes(int kind, int64_t B, int graphs_per_tile);
 int hcg_fused_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int graphs_per_tile, int64_t C,
                               float* dW0 /*NULL: partials only*/, float* db0, float* dW1, float* db1, hcg_reduce_job* job_host);
 /* backward, stage 1 (ONE launch).  dout == NULL selects the pooled form: the upstream gradient is
@@ -276,18 +280,12 @@ int hcg_tall_layer_bwd(const float* dout /*nullable*/, const float* demb, const 
                        float slope, int apply_act, float* dx /*nullable*/, int32_t* status,
                        void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
-/* ---- fused readout head (a10 + its backward) for the reference's default shape:
- *      z = LeakyReLU(emb W0^T + b0) [B,2D]->[B,D];  out = z W1^T + b1 [B,D]->[B,C];  D = 64, C <= 8.
- * forward: one launch (z is kept for the backward).  backward: one launch + fixed-order slab reduce;
- * writes demb [B,2D], dW0 [D,2D], db0 [D], dW1 [C,D], db1 [C]. */
-int hcg_readout2_supported(int64_t D, int64_t C);
-size_t hcg_readout2_workspace_bytes(int64_t B);
+/* ---- fused readout head (a10 + its backward) for the reference's default shape (the autograd path's form):
+ *      z = LeakyReLU(emb W0^T + b0) [B,2D]->[B,D];  out = z W1^T + b1 [B,D]->[B,C];  D = 64, C <= 8 (= hcg_head_supported
+ *      with D = 64).  forward: one launch (z is kept for the backward).  backward: hcg_readout2_bwd_partial (below: demb
+ *      + per-workgroup slabs, workspace HCG_WS_READOUT2) + hcg_readout2_reduce_job + hcg_step_tail. */
 int hcg_readout2_fwd(const float* emb, const float* W0, const float* b0, const float* W1, const float* b1,
                      int64_t B, int64_t D, int64_t C, float slope, float* z, float* out, hcg_stream_t stream);
-int hcg_readout2_bwd(const float* dout, const float* emb, const float* z, const float* W0, const float* W1,
-                     int64_t B, int64_t D, int64_t C, float slope,
-                     float* demb, float* dW0, float* db0, float* dW1, float* db1,
-                     void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 
 /* ---- regression head: readout forward, squared error, readout backward in ONE launch (a10 + a12 + their backward; f2)
  * The reference's step runs  out = readout(emb); loss = torch.sqrt(MSELoss()(out, y.unsqueeze(1)));
@@ -351,7 +349,11 @@ typedef struct hcg_reduce_job {
   int32_t nslabs, slab_floats, nseg, reserved;
   hcg_reduce_seg seg[HCG_REDUCE_MAX_SEGS];
 } hcg_reduce_job;
-size_t hcg_reduce_job_bytes(void);
+/* sizeof of the ABI's HOST structs (a binding checks its mirrors against them) */
+#define HCG_STRUCT_REDUCE_JOB 0
+#define HCG_STRUCT_TAIL_ARGS 1
+#define HCG_STRUCT_FUSED_FWD_ARGS 2
+size_t hcg_struct_bytes(int which);
 int hcg_fused_reduce_job(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F,
                          int64_t D, int graphs_per_tile, float* dW, float* db, hcg_reduce_job* job_host);
 int hcg_readout2_bwd_partial(const float* dout, const float* emb, const float* z, const float* W0,
@@ -413,7 +415,6 @@ typedef struct hcg_tail_args {
   int32_t reserved;
   int32_t* xchg_err;
 } hcg_tail_args;
-size_t hcg_tail_args_bytes(void);
 int hcg_step_tail(const hcg_tail_args* args_host, hcg_stream_t stream);
 /* forward-only steps (the reference's eval_network body, utils/utils_model.py:75-78): the loss alone from a head job's partials */
 int hcg_loss_finalize(const hcg_reduce_job* head_job_host, float count, int loss_mode, float* loss,

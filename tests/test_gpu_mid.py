@@ -261,7 +261,7 @@ def test_mid_backward_hands_down_a_premasked_dx(H, D, feat):
         _lib.check(lib.hcg_mid_layer_bwd(p(dout_), None, None, p(out_), p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                          p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
                                          st), "hcg_mid_layer_bwd")
-        jb = lib.hcg_reduce_job_bytes()
+        jb = _lib.job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
         for half in range(D // 64):
             _lib.check(lib.hcg_mid_reduce_job(p(ws), wsb, B, F_, D, mxn, mxe, half, p(dW), p(db), ctypes.addressof(jobs) + half * jb),

@@ -124,7 +124,7 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
         _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                           p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
                                           st), "hcg_tall_layer_bwd")
-        jb = lib.hcg_reduce_job_bytes()
+        jb = _lib.job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
         _lib.check(lib.hcg_tall_reduce_jobs(p(ws), wsb, N, B, F_, D, p(dW), p(db), ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
         _lib.reduce_jobs(ctypes.addressof(jobs), 2)

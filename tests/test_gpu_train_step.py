@@ -493,7 +493,7 @@ def test_training_forms_keep_the_pooled_layer_on_chip(H, nodes, feat, ties):
     common = dict(edge_index=plan.edge_index, E=plan.E, graph_ptr=plan.graph_ptr, edge_ptr=plan.edge_ptr, N=N, B=B, D=D,
                   graphs_per_tile=gpt, apply_act=1, slope=slope, status=plan.status)
     _lib.fused_forward(x=x, W1=W1, b1=b1, W2=W2, b2=b2, F=feat, out1=out1, out2=out2, emb=emb, **common)
-    bits = torch.zeros(lib.hcg_fused_poolbits_bytes(B, gpt), dtype=torch.uint8, device="cuda")
+    bits = torch.zeros(lib.hcg_fused_aux_bytes(_lib.HCG_FUSED_POOLBITS, B, gpt), dtype=torch.uint8, device="cuda")
     out1t, embt = new(N, D), new(B, 2 * D)
     _lib.fused_forward(x=x, W1=W1, b1=b1, W2=W2, b2=b2, F=feat, out1=out1t, emb=embt, poolbits=bits, **common)
     assert torch.equal(out1, out1t) and torch.equal(emb, embt)

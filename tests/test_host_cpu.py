@@ -34,16 +34,16 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert _lib.load().hcg_version() == 1
     assert _lib.load().hcg_error_string(-2) == b"workspace too small"
-    assert len(declared) <= 63, "the ABI grew: fold fusion combinations into an argument struct instead of a new symbol"
+    assert len(declared) <= 55, "the ABI grew: fold fusion combinations into an argument struct instead of a new symbol"
 
 
 def test_host_structs_match_the_library():
     """The ctypes mirrors of the ABI's HOST structs (hcg_reduce_job, hcg_tail_args, hcg_fused_fwd_args) have the library's
     sizes, and a wrong argument block is refused without touching the GPU."""
     lib = _lib.load()
-    assert ctypes.sizeof(_lib.ReduceJob) == lib.hcg_reduce_job_bytes()
-    assert ctypes.sizeof(_lib.TailArgs) == lib.hcg_tail_args_bytes()
-    assert ctypes.sizeof(_lib.FusedFwdArgs) == lib.hcg_fused_fwd_args_bytes()
+    assert ctypes.sizeof(_lib.ReduceJob) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_REDUCE_JOB)
+    assert ctypes.sizeof(_lib.TailArgs) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_TAIL_ARGS)
+    assert ctypes.sizeof(_lib.FusedFwdArgs) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_FUSED_FWD_ARGS)
     assert lib.hcg_step_tail(None, None) == -1 and lib.hcg_fused_forward(None, None) == -1
     a = _lib.TailArgs()
     assert lib.hcg_step_tail(ctypes.addressof(a), None) == 0            # no jobs, nothing else: nothing to do

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hcatgnet_amd as H
 from hcatgnet_amd import synth
 from hcatgnet_amd.train import train_network
+from hcatgnet_amd import train as _t
+if os.environ.get("HCG_LOOP") == "1":
+    _t.EPOCH_WINDOW = False
 sb = synth.make_config("REAL", num_graphs=535)
 store = H.DeviceGraphStore(sb.as_graph_list(), device="cuda")
 loader = H.DeviceLoader(store, batch_size=40, shuffle=True, seed=0)

@@ -32,8 +32,8 @@ int main() {
   CK(hipMalloc(&dW0, W0.size() * 4)); CK(hipMalloc(&dy, B * 4)); CK(hipMalloc(&dout1, (size_t)N * D * 4));
   CK(hipMalloc(&demb0, (size_t)B * 2 * D * 4)); CK(hipMalloc(&ddemb, (size_t)B * 2 * D * 4)); CK(hipMalloc(&dz, (size_t)B * D * 4));
   CK(hipMalloc(&dout, B * 4)); CK(hipMalloc(&dei, ei.size() * 8)); CK(hipMalloc(&dgp, (B + 1) * 4)); CK(hipMalloc(&dep, (B + 1) * 4));
-  CK(hipMalloc(&dstatus, 16)); CK(hipMalloc(&bits, hcg_fused_poolbits_bytes(B, 1)));
-  const size_t hwb = hcg_fused_head_workspace_bytes(B, 1); CK(hipMalloc(&hws, hwb));
+  CK(hipMalloc(&dstatus, 16)); CK(hipMalloc(&bits, hcg_fused_aux_bytes(HCG_FUSED_POOLBITS, B, 1)));
+  const size_t hwb = hcg_fused_aux_bytes(HCG_FUSED_HEAD_WS, B, 1); CK(hipMalloc(&hws, hwb));
   CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dW2, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, bias.data(), D * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dW0, W0.data(), W0.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dy, y.data(), B * 4, hipMemcpyHostToDevice));
