@@ -40,6 +40,19 @@ struct HcgArena {
   }
 };
 
+// torch.optim.Adam's update of one element (amsgrad / weight_decay / maximize off), shared by every kernel that applies it
+// (optim.hip, reduce.hip) and written with explicit roundings: left to the compiler, the fused and the stand-alone update
+// contracted these expressions into different fma's, and with eps = 1e-9 (model/networks.py:38) a last-bit difference in a
+// moment of a near-zero gradient becomes an lr-sized difference of the parameter.
+//   step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t)
+__device__ __forceinline__ float hcg_adam_update(float p, float g, float& m, float& v, float b1, float b2, float eps,
+                                                 float step_size, float bc2_sqrt) {
+  m = __fmaf_rn(b1, m, __fmul_rn(1.0f - b1, g));
+  v = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(1.0f - b2, g), g));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+  return __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, denom)));
+}
+
 __device__ __forceinline__ float hcg_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float hcg_leaky_grad(float y_out, float slope) { return y_out > 0.f ? 1.f : slope; }
 

@@ -236,7 +236,8 @@ __device__ __forceinline__ void head_tile(HeadLds<RD>& L, HeadState<RD, RC>& S, 
       if (c < C) {                                     // block-uniform
         const float4 wa = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj);
         const float4 wb = *reinterpret_cast<const float4*>(L.w1 + c * RD + 8 * oj + 4);
-        float s = ((za.x * wa.x + za.y * wa.y) + (za.z * wa.z + za.w * wa.w)) + ((zb.x * wb.x + zb.y * wb.y) + (zb.z * wb.z + zb.w * wb.w));
+        float s = __fmaf_rn(zb.w, wb.w, __fmaf_rn(zb.z, wb.z, __fmaf_rn(zb.y, wb.y, __fmaf_rn(zb.x, wb.x,
+                  __fmaf_rn(za.w, wa.w, __fmaf_rn(za.z, wa.z, __fmaf_rn(za.y, wa.y, za.x * wa.x)))))));
 #pragma unroll
         for (int off = 1; off < OJ; off <<= 1) s += __shfl_xor(s, off, 64);
         if (oj == 0) {
@@ -622,7 +623,9 @@ __device__ __forceinline__ void tile(Lds& L, State<RC>& S, const Prefetch<RC>& P
     for (int c = 0; c < RC; ++c) {
       if (c < C) {                                     // block-uniform
         const float4 w = P.w1r[c];
-        float s = (zz.x * w.x + zz.y * w.y) + (zz.z * w.z + zz.w * w.w);
+        // (explicit fma chain: left to the compiler, the forward-only and the training instantiation contracted this
+        //  expression differently and their outputs differed in the last bit)
+        float s = __fmaf_rn(zz.w, w.w, __fmaf_rn(zz.z, w.z, __fmaf_rn(zz.y, w.y, zz.x * w.x)));
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
         s += S.b1v[c];

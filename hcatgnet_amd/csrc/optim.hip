@@ -26,13 +26,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
                                               float bc1, float bc2_sqrt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i];
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  float mi = m[i], vi = v[i];
+  p[i] = hcg_adam_update(p[i], g[i], mi, vi, b1, b2, eps, lr / bc1, bc2_sqrt);
   m[i] = mi;
   v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] -= (lr / bc1) * (mi / denom);
 }
 
 }  // namespace
@@ -74,12 +71,10 @@ __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, float* 
     const float bc2_sqrt = (float)sqrt(1.0 - hcg_powi((double)b2, t));
     const float gi = g[i] * gs;
     if (SSE) g[i] = gi;
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float mi = m[i], vi = v[i];
+    p[i] = hcg_adam_update(p[i], gi, mi, vi, b1, b2, eps, lr / bc1, bc2_sqrt);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
   }
   __syncthreads();                                     // every thread of this block has read the step word
   if (threadIdx.x == 0) {

@@ -236,11 +236,10 @@ __global__ __launch_bounds__(256) void k_step_tail(Jobs jobs, AdamArgs A, PlanAr
     }
     *gdst = tot;
     if (ADAM) {
-      const float mi = A.b1 * m0 + (1.0f - A.b1) * tot;
-      const float vi = A.b2 * v0 + (1.0f - A.b2) * tot * tot;
+      float mi = m0, vi = v0;
+      A.p[off] = hcg_adam_update(p0, tot, mi, vi, A.b1, A.b2, A.eps, adam_c[0], adam_c[1]);
       A.m[off] = mi;
       A.v[off] = vi;
-      A.p[off] = p0 - adam_c[0] * (mi / (sqrtf(vi) / adam_c[1] + A.eps));
     }
   }
 }
