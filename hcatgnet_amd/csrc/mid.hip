@@ -22,7 +22,22 @@ namespace {
 constexpr int MW = 8;                 // waves per workgroup (two per SIMD: the per-graph phases are latency chains)
 constexpr int MT = MW * 64;           // threads
 constexpr int MID_MAX_NODES = 224;    // 7 row blocks of 32 (two fp32 tiles + one weight image still fit 160 KB of LDS)
-constexpr int MID_MAX_EDGES = 1024;   // directed edges of one graph (2 per thread kept in registers; LDS col array, 16-bit ids)
+constexpr int MID_MAX_EDGES = 1024;
+                                       // directed edges of one graph (2 per thread kept in registers; LDS col array, 16-bit ids)
+
+#ifdef HCG_MID_STAMP        // tools/probe_mid.hip: s_memtime stamps of the per-graph phases of the first workgroup's first graphs
+__device__ unsigned long long g_mid_stamp[MW][4][16];
+#define MSTAMP(i)                                                                                           \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    unsigned long long _t;                                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && mstamp_it < 4) g_mid_stamp[threadIdx.x >> 6][mstamp_it][(i)] = _t; \
+  } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
 
 struct MidLds {   // carved out of dynamic shared memory by carve()
   float* t0;              // [npad][HS]   forward: X -> H';   backward: dY' -> X
@@ -46,24 +61,27 @@ __host__ __device__ inline size_t mid_lds_bytes(int npad, int emax, int wl_rows,
   return b + 64;
 }
 
+// (offsets are rounded as INTEGERS: a pointer -> integer -> pointer round trip makes the compiler forget that the carved
+//  arrays are LDS -- every access to them became a flat load, whose s_waitcnt vmcnt(0) also waits for the prefetched HBM loads)
 __device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_rows, int wl_k, bool two_tiles) {
   MidLds L;
+  unsigned off = 0;
   L.t0 = reinterpret_cast<float*>(base);
-  base += (size_t)npad * HS * 4;
-  L.t1 = two_tiles ? reinterpret_cast<float*>(base) : nullptr;
-  if (two_tiles) base += (size_t)npad * HS * 4;
-  L.wl = reinterpret_cast<short*>(base);
-  base += (size_t)3 * wl_rows * (wl_k + WPAD) * 2;
-  base = reinterpret_cast<char*>(((uintptr_t)base + 15) / 16 * 16);
-  L.rowptr = reinterpret_cast<int*>(base);
-  base += (size_t)(npad + 1 + 3) / 4 * 16;
-  L.cursor = reinterpret_cast<int*>(base);
-  base += (size_t)(npad + 3) / 4 * 16;
-  L.dinv = reinterpret_cast<float*>(base);
-  base += (size_t)(npad + 3) / 4 * 16;
-  L.col = reinterpret_cast<unsigned short*>(base);
-  base += (size_t)(emax + 7) / 8 * 16;
-  L.red = reinterpret_cast<float*>(base);
+  off += (unsigned)npad * HS * 4;
+  L.t1 = two_tiles ? reinterpret_cast<float*>(base + off) : nullptr;
+  if (two_tiles) off += (unsigned)npad * HS * 4;
+  L.wl = reinterpret_cast<short*>(base + off);
+  off += 3u * wl_rows * (wl_k + WPAD) * 2;
+  off = (off + 15u) / 16u * 16u;
+  L.rowptr = reinterpret_cast<int*>(base + off);
+  off += (unsigned)(npad + 1 + 3) / 4 * 16;
+  L.cursor = reinterpret_cast<int*>(base + off);
+  off += (unsigned)(npad + 3) / 4 * 16;
+  L.dinv = reinterpret_cast<float*>(base + off);
+  off += (unsigned)(npad + 3) / 4 * 16;
+  L.col = reinterpret_cast<unsigned short*>(base + off);
+  off += (unsigned)(emax + 7) / 8 * 16;
+  L.red = reinterpret_cast<float*>(base + off);
   return L;
 }
 
@@ -76,6 +94,30 @@ __device__ __forceinline__ GraphInfo graph_info(int g, const int32_t* __restrict
   gi.n = graph_ptr[g + 1] - gi.nbase;
   gi.ebase = edge_ptr[g];
   gi.ne = edge_ptr[g + 1] - gi.ebase;
+  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax) {     // host metadata was wrong: refuse the graph
+    if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
+    gi.n = 0;
+    gi.ne = 0;
+  }
+  gi.nblk = (gi.n + 31) / 32;
+  return gi;
+}
+
+// The four scalars of graph g, requested TWO graphs ahead.  A workgroup-uniform index would compile to s_load (counted on
+// lgkmcnt, which every LDS read waits on: ~1 000 cycles exposed per graph in front of the edge prefetch, measured); a
+// per-lane index makes them ONE vector load per lane (lanes 4k + 0..3: graph_ptr[g], graph_ptr[g + 1], edge_ptr[g],
+// edge_ptr[g + 1]), counted on vmcnt, long complete when graph_finish reads them a whole graph later.
+__device__ __forceinline__ int graph_raw(int g, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr) {
+  const int l = threadIdx.x & 3;
+  const int32_t* p = (l & 2) ? edge_ptr : graph_ptr;
+  return p[g + (l & 1)];
+}
+__device__ __forceinline__ GraphInfo graph_finish(int raw, int npad, int emax, int32_t* status) {
+  GraphInfo gi;
+  gi.nbase = __builtin_amdgcn_readlane(raw, 0);
+  gi.n = __builtin_amdgcn_readlane(raw, 1) - gi.nbase;
+  gi.ebase = __builtin_amdgcn_readlane(raw, 2);
+  gi.ne = __builtin_amdgcn_readlane(raw, 3) - gi.ebase;
   if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax) {     // host metadata was wrong: refuse the graph
     if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
     gi.n = 0;
@@ -106,13 +148,19 @@ struct EdgeRegs {
 // aggregation); BY_SRC = true: rows = sources, col = targets (the transpose, for the backward).  dinv is always
 // (1 + in-degree)^-1/2.  Explicit (i, i) edges collapse into the unit self loop (PyG add_remaining_self_loops).
 // Every row ends up sorted by id, whatever order the LDS atomics ran in.  All MT threads; ends with a barrier.
+// PRECONDITION: cursor[0 .. npad) (and degin_scratch) are ZERO -- csr_counters_clear() before the graph loop; the fill
+// pass counts every row's cursor back down to zero, so the invariant holds from graph to graph with no clearing pass.
+// Four barriers: count | scan (wave 0) beside dinv (the other waves) | fill (csr_count_scan_fill) | sort (csr_sort_rows).
+__device__ __forceinline__ void csr_counters_clear(const MidLds& L, int npad, int* degin_scratch) {
+  for (int i = threadIdx.x; i < npad; i += MT) { L.cursor[i] = 0; if (degin_scratch) degin_scratch[i] = 0; }
+}
+
 template <bool BY_SRC>
-__device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, const EdgeRegs& er, int32_t* status,
-                                          int* degin_scratch) {
+__device__ __forceinline__ void csr_count_scan_fill(const MidLds& L, const GraphInfo& gi, const EdgeRegs& er, int32_t* status,
+                                                    int* degin_scratch, int mstamp_it = 4) {
+  static_assert(MT - 64 >= MID_MAX_NODES, "one dinv row per thread beside the scan wave");
   const int tid = threadIdx.x;
   const int nrows = gi.nblk * 32;
-  for (int i = tid; i < nrows; i += MT) { L.cursor[i] = 0; if (BY_SRC) degin_scratch[i] = 0; }
-  __syncthreads();
   // this thread's edges (already in registers) -> local ids, kept from the counting pass to the fill pass
   unsigned short es[EPT], ed[EPT];
   bool bad = false;
@@ -136,8 +184,8 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
   }
   if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
   __syncthreads();
-  // exclusive scan of the row sizes by wave 0 (<= 256 rows: 4 per lane), dinv for every row
-  if (tid < 64) {
+  MSTAMP(2);
+  if (tid < 64) {     // exclusive scan of the row sizes by wave 0 (<= 256 rows: 4 per lane) ...
     constexpr int RPL = (MID_MAX_NODES + 63) / 64;
     int v[RPL], tot = 0;
 #pragma unroll
@@ -160,24 +208,30 @@ __device__ __forceinline__ void build_csr(const MidLds& L, const GraphInfo& gi, 
       run += v[j];
     }
     if (tid == 63) L.rowptr[nrows] = incl;
-  }
-  __syncthreads();
-  for (int i = tid; i < nrows; i += MT) {
+  } else if (tid - 64 < nrows) {     // ... while the other waves turn the in-degrees into dinv (MT - 64 >= MID_MAX_NODES rows)
+    const int i = tid - 64;
     const int degin = BY_SRC ? degin_scratch[i] : L.cursor[i];
     L.dinv[i] = i < gi.n ? 1.0f / sqrtf(1.0f + (float)degin) : 0.f;
+    if (BY_SRC) degin_scratch[i] = 0;
   }
   __syncthreads();
-  for (int i = tid; i < nrows; i += MT) L.cursor[i] = L.rowptr[i];
-  __syncthreads();
+  MSTAMP(3);
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     if (es[j] != 0xffff) {
-      const int p = atomicAdd(&L.cursor[BY_SRC ? es[j] : ed[j]], 1);
-      L.col[p] = BY_SRC ? ed[j] : es[j];
+      const int rowi = BY_SRC ? es[j] : ed[j];
+      const int left = atomicSub(&L.cursor[rowi], 1);          // counts the row back down to zero
+      L.col[L.rowptr[rowi] + left - 1] = BY_SRC ? ed[j] : es[j];
     }
   }
   __syncthreads();
-  for (int i = tid; i < gi.n; i += MT) {          // every row sorted by id: fixed summation order
+  MSTAMP(4);
+}
+
+// second half of the CSR build: every row sorted by id (fixed summation order).  Ends with a barrier.
+__device__ __forceinline__ void csr_sort_rows(const MidLds& L, const GraphInfo& gi) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < gi.n; i += MT) {
     const int kb = L.rowptr[i], ke = L.rowptr[i + 1], len = ke - kb;
     if (len > 1 && len <= 4) {                      // (every row of a molecular graph) a register network: no dependent LDS chain
       unsigned a0 = L.col[kb], a1 = L.col[kb + 1], a2 = len > 2 ? L.col[kb + 2] : 0xffffu, a3 = len > 3 ? L.col[kb + 3] : 0xffffu;
@@ -267,6 +321,61 @@ __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restri
   }
 }
 
+// A graph's x rows in registers, requested a whole graph AHEAD (loads only: unconditional, clamped addresses -- hipcc ends
+// every guarded load with its own s_waitcnt vmcnt(0), which would turn the prefetch into an exposed HBM round trip) and
+// written to the LDS tile at the start of the graph's own iteration.  Staging the rows inside the iteration cost 4 400 ..
+// 5 900 of a graph's ~18 600 cycles (F = 25: eight dependent round trips), measured with tools/probe_mid.hip.
+// Element (row, k) of the padded [NR][KPAD] tile per slot: VEC (F == KPAD, 16-byte aligned rows): one float4 per slot;
+// otherwise one dword.  NR = the row capacity the kernel is compiled for (128 or MID_MAX_NODES): 8 .. 28 registers.
+template <int KPAD, bool VEC, int NR>
+struct XRows {
+  static constexpr int NV = (NR * KPAD / 4 + MT - 1) / MT;     // float4 slots per thread (VEC)
+  static constexpr int NS = (NR * KPAD + MT - 1) / MT;         // dword slots per thread
+  float4 v4[VEC ? NV : 1];
+  float v1[VEC ? 1 : NS];
+  __device__ __forceinline__ void load(const float* __restrict__ g, int F, const GraphInfo& gi) {
+    const int nlast = gi.n > 0 ? gi.n - 1 : 0;
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));      // (opaque: the per-slot row / column indices are recomputed here, not kept live in
+                                      //  14 registers across the whole graph loop -- that alone cost the second workgroup)
+    const float* base = g + (size_t)(gi.n > 0 ? gi.nbase : 0) * F;       // (an empty graph at the end of the batch has nbase == N)
+    // (workgroup-uniform base + unsigned 32-bit BYTE offset = the scalar-base form of global_load: one offset register per
+    //  load instead of a 64-bit address pair -- with 14 pairs live at once the kernel needed 152+ VGPRs and lost its second
+    //  workgroup per CU.  A graph's x rows span < 4 GB.)
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = t0 + j * MT, row = e / (KPAD / 4), c4 = e % (KPAD / 4);
+        v4[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + 4u * (unsigned)((row < gi.n ? row : nlast) * F + 4 * c4));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int e = t0 + j * MT, row = e / KPAD, k = e % KPAD;
+        v1[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + 4u * (unsigned)((row < gi.n ? row : nlast) * F + (k < F ? k : F - 1)));
+      }
+    }
+  }
+  __device__ __forceinline__ void write(float* t, int F, const GraphInfo& gi) const {
+    const int nrows = gi.nblk * 32;
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int e = t0 + j * MT, row = e / (KPAD / 4), c4 = e % (KPAD / 4);
+        if (row < nrows) *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = row < gi.n ? v4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int e = t0 + j * MT, row = e / KPAD, k = e % KPAD;
+        if (row < nrows) t[row * HS + k] = (row < gi.n && k < F) ? v1[j] : 0.f;
+      }
+    }
+  }
+};
+
 // =====================================================================================================
 // forward of one layer, one graph per workgroup iteration
 // =====================================================================================================
@@ -274,7 +383,8 @@ __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restri
 // 128: one of two independent column halves -- W / bias already point at the half's rows).  Inputs wider than 64
 // features are contracted in K-chunks of 64 through the same LDS tile (accumulators stay in registers: a wave owns ONE
 // 32-row block, the host guarantees nblk <= 8).
-template <int KPAD, bool POOL, bool MULTIK>
+// VEC / NR: how the x rows are prefetched (XRows; unused by MULTIK, which stages chunk by chunk inside the iteration).
+template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR>
 __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int64_t* __restrict__ ei,
                                                          int64_t E, const int32_t* __restrict__ graph_ptr,
@@ -297,17 +407,28 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
     for (int kc = 0; kc < nkc; ++kc) stage_weight_split<false, MT, DD, KPAD>(L.wl + kc * IMG, W, DD, F, kc * KPAD);
   }
   const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+  csr_counters_clear(L, npad, nullptr);
   __syncthreads();
 
-  GraphInfo gi;
+  // (the grid never exceeds B: every workgroup has a first graph; past its last graph a workgroup requests the batch's
+  //  last graph again and drops it -- the prefetches are unconditional)
+  const int G = (int)gridDim.x;
+  GraphInfo gi = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
   EdgeRegs er;
-  if ((int)blockIdx.x < B) {
-    gi = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
-    er.load(gi, ei, E);
-  }
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
-    stage_graph_rows<KPAD, MULTIK>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
-    build_csr<false>(L, gi, er, status, nullptr);                   // (ends with a barrier: the x tile is complete too)
+  XRows<KPAD, VEC, MULTIK ? 32 : NR> xr;
+  er.load(gi, ei, E);
+  if constexpr (!MULTIK) xr.load(x, F, gi);
+  int raw_next = graph_raw(min((int)blockIdx.x + G, B - 1), graph_ptr, edge_ptr);
+  int mstamp_it = 0;
+  (void)mstamp_it;
+  for (int g = blockIdx.x; g < B; g += G) {
+    MSTAMP(0);
+    if constexpr (MULTIK) stage_graph_rows<KPAD, true>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
+    MSTAMP(1);
+    csr_count_scan_fill<false>(L, gi, er, status, nullptr, mstamp_it);
+    if constexpr (!MULTIK) xr.write(L.t0, F, gi);     // (requested at the end of the previous graph: ~3 500 cycles ago)
+    csr_sort_rows(L, gi);                               // (ends with a barrier: the x tile is complete too)
+    MSTAMP(5);
 
     // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
     if constexpr (!MULTIK) {
@@ -354,14 +475,19 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         }
       }
     }
+    MSTAMP(6);
     __syncthreads();
+    MSTAMP(7);
 
-    // the NEXT graph's scalars and edges are requested here: they land while this graph is aggregated and stored
+    // the NEXT graph's edges are requested here (its scalars were requested a graph ago): they land while this graph is
+    // aggregated and stored; the scalars of the graph after next follow.  Its x rows are requested BEHIND the aggregation
+    // (whose registers they would otherwise share: 150+ VGPRs = one workgroup per CU) and written to the tile between the
+    // next graph's fill and sort passes -- pooling, two barriers, count, scan and fill in between cover the HBM latency
     const GraphInfo gcur = gi;
-    if (g + (int)gridDim.x < B) {
-      gi = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
-      er.load(gi, ei, E);
-    }
+    gi = graph_finish(raw_next, npad, emax, status);
+    er.load(gi, ei, E);
+    raw_next = graph_raw(min(g + 2 * G, B - 1), graph_ptr, edge_ptr);
+    MSTAMP(8);
 
     // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -384,6 +510,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         }
       }
     }
+    if constexpr (!MULTIK) xr.load(x, F, gi);
+    MSTAMP(9);
     if (POOL) {   // rows of this lane's (r4, q) slot -> wave (xor 16, 32) -> workgroup (LDS, fixed order)
       pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 16, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 16, 64)),
                          fmaxf(pmax.z, __shfl_xor(pmax.z, 16, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 16, 64)));
@@ -408,7 +536,12 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
         emb[(size_t)g * 2 * ldo + ldo + coff + tid] = s / (float)(gcur.n > 0 ? gcur.n : 1);
       }
     }
+    MSTAMP(10);
     __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
+    MSTAMP(11);
+#ifdef HCG_MID_STAMP
+    ++mstamp_it;
+#endif
   }
 }
 
@@ -457,6 +590,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int i = 0; i < 16; ++i) dw[fc][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  csr_counters_clear(L, npad, reinterpret_cast<int*>(L.red));
+  __syncthreads();
   GraphInfo gnext;
   EdgeRegs er;
   if ((int)blockIdx.x < B) {
@@ -465,7 +600,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   }
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const GraphInfo gi = gnext;
-    build_csr<true>(L, gi, er, status, reinterpret_cast<int*>(L.red));
+    csr_count_scan_fill<true>(L, gi, er, status, reinterpret_cast<int*>(L.red));
+    csr_sort_rows(L, gi);
     const int rows = gi.nblk * 32;
     if (g + (int)gridDim.x < B) {                          // the NEXT graph's scalars and edges: in flight for the whole graph
       gnext = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
@@ -719,23 +855,30 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   const int nimg = F > 64 ? (int)((F + 63) / 64) : 1;                 // K-chunk weight images kept resident (MULTIK)
   const size_t lds = mid_lds_bytes(npad, emax, DD * nimg, kpad, false);
   const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
-#define LAUNCH_MID_FWD(KP, PL, MK)                                                                                         \
+#define LAUNCH_MID_FWD(KP, PL, MK, VC, NRC)                                                                                \
   do {                                                                                                                     \
-    auto kfn = k_mid_layer_fwd<KP, PL, MK>;                                                                                \
-    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK>>();                                                           \
+    auto kfn = k_mid_layer_fwd<KP, PL, MK, VC, NRC>;                                                                       \
+    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK, VC, NRC>>();                                                  \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
     hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, Wh, bh, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,    \
                        emax, slope, apply_act, out, (int)D, coff, emb, status);                                            \
   } while (0)
+#define LAUNCH_MID_FWD_X(KP, PL)                                                                                           \
+  do {                                                                                                                     \
+    if (npad <= 128) { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, 128); else LAUNCH_MID_FWD(KP, PL, false, false, 128); } \
+    else { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, MID_MAX_NODES); else LAUNCH_MID_FWD(KP, PL, false, false, MID_MAX_NODES); } \
+  } while (0)
+  const bool vec = F == kpad && ((uintptr_t)x % 16 == 0);     // whole float4 rows in the x prefetch
   for (int half = 0; half < (int)(D / DD); ++half) {     // 64 output columns per launch
     const float* Wh = W + (size_t)half * DD * F;
     const float* bh = b + half * DD;
     const int coff = half * DD;
-    if (kpad == 32)   { if (emb) LAUNCH_MID_FWD(32, true, false); else LAUNCH_MID_FWD(32, false, false); }
-    else if (F <= 64) { if (emb) LAUNCH_MID_FWD(64, true, false); else LAUNCH_MID_FWD(64, false, false); }
-    else              { if (emb) LAUNCH_MID_FWD(64, true, true); else LAUNCH_MID_FWD(64, false, true); }
+    if (kpad == 32)   { if (emb) LAUNCH_MID_FWD_X(32, true); else LAUNCH_MID_FWD_X(32, false); }
+    else if (F <= 64) { if (emb) LAUNCH_MID_FWD_X(64, true); else LAUNCH_MID_FWD_X(64, false); }
+    else              { if (emb) LAUNCH_MID_FWD(64, true, true, false, 32); else LAUNCH_MID_FWD(64, false, true, false, 32); }
     HCG_CHECK_LAUNCH();
   }
+#undef LAUNCH_MID_FWD_X
 #undef LAUNCH_MID_FWD
   return HCG_OK;
 }

@@ -40,3 +40,21 @@ def test_built_code_objects_keep_the_distance():
     rep = isa_lint.lint_objects([os.path.join(csrc, f) for f in isa_lint.MFMA_FILES])
     for path, viol in rep.items():
         assert viol == [], (path, viol[:3])
+
+
+def test_flat_rule_on_a_listing():
+    lines = ["kern:", "global_load_dword v1, v[2:3], off", "flat_load_dword v4, v[5:6]", "ds_read_b32 v7, v8"]
+    hits = isa_lint.lint_flat(lines)
+    assert len(hits) == 1 and hits[0][0] == "kern" and hits[0][2].startswith("flat_load_dword")
+
+
+def test_built_code_objects_have_no_flat_memory_instructions():
+    """Every pointer is a global kernel argument or carved from LDS: a flat access = the compiler lost the address space
+    (and a flat LDS read's s_waitcnt vmcnt(0) serialises the prefetch pipelines; tools/isa_lint.py, second rule)."""
+    csrc = os.path.join(REPO, "hcatgnet_amd", "csrc")
+    if not os.path.isfile(isa_lint.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    subprocess.run(["make", "-C", csrc, "-j", "3"], check=True, stdout=subprocess.DEVNULL)
+    rep = isa_lint.lint_objects_flat(isa_lint.all_kernel_objects())
+    for path, hits in rep.items():
+        assert hits == [], (path, hits[:3])

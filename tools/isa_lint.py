@@ -16,7 +16,12 @@ distance that is safe at two waves per SIMD.  Evidence: with the co
 launches returned one stale 1x16 block of the chain's LAST pass; 0 of 80 with >= 64 more idle cycles.  The failing sites
 of the pre-fix build are listed in DESIGN 4.0.
 
-    python tools/isa_lint.py                 # lint hcatgnet_amd/csrc/{fused,mid,head}.o ; exit 1 on a violation
+Second rule (round 3): no `flat_*` memory instruction in any kernel.  Every pointer these kernels dereference is either a
+kernel argument (global) or carved from dynamic shared memory; a flat access means the compiler lost the address space
+(mid.hip's carve() rounded a POINTER through uintptr_t: all LDS arrays behind the rounding were read with flat_load, whose
+`s_waitcnt vmcnt(0)` also waits for every prefetched HBM load -- the prefetch-a-graph-ahead pipelines were serialised).
+
+    python tools/isa_lint.py                 # lint hcatgnet_amd/csrc/*.o ; exit 1 on a violation
     python tools/isa_lint.py --required 12 --dis file.dis   # lint an existing llvm-objdump listing
 """
 from __future__ import annotations
@@ -93,13 +98,31 @@ def lint_listing(lines, required=REQUIRED):
     return viol
 
 
-def disassemble(obj_path, workdir):
+def lint_flat(lines):
+    """-> list of (kernel, line_no, text) of flat_* memory instructions."""
+    out, kernel = [], "?"
+    for no, raw in enumerate(lines, 1):
+        line = raw.split("//")[0].strip()
+        if not line or line[0] in ";.#":
+            continue
+        if line.endswith(":") and not line.startswith(("s_", "v_", "ds_", "global_", "buffer_", "flat_")):
+            m = re.match(r"^[0-9a-f]*\s*<?([^>]+)>?:$", line)
+            kernel = m.group(1) if m else line[:-1]
+            continue
+        if line.startswith("flat_"):
+            out.append((kernel, no, line))
+    return out
+
+
+def disassemble(obj_path, workdir, allow_host_only=False):
     """Host object with an embedded gfx950 code object -> llvm-objdump listing (list of lines)."""
     local = os.path.join(workdir, os.path.basename(obj_path))
     shutil.copy(obj_path, local)
     subprocess.run([OBJDUMP, "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     co = [f for f in os.listdir(workdir) if f.startswith(os.path.basename(obj_path) + ".") and "gfx950" in f]
     if not co:
+        if allow_host_only:
+            return []
         raise RuntimeError(f"no gfx950 code object inside {obj_path}")
     out = subprocess.run([OBJDUMP, "-d", os.path.join(workdir, co[0])], check=True, capture_output=True, text=True).stdout
     return out.splitlines()
@@ -113,6 +136,19 @@ def lint_objects(paths, required=REQUIRED):
     return report
 
 
+def lint_objects_flat(paths):
+    report = {}
+    with tempfile.TemporaryDirectory() as td:
+        for p in paths:
+            report[p] = lint_flat(disassemble(p, td, allow_host_only=True))      # (api.o holds no kernel)
+    return report
+
+
+def all_kernel_objects():
+    d = os.path.join(REPO, "hcatgnet_amd", "csrc")
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".o"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--required", type=int, default=REQUIRED)
@@ -120,11 +156,19 @@ def main():
     ap.add_argument("objects", nargs="*")
     a = ap.parse_args()
     if a.dis:
-        rep = {a.dis: lint_listing(open(a.dis).read().splitlines(), a.required)}
+        listing = open(a.dis).read().splitlines()
+        rep = {a.dis: lint_listing(listing, a.required)}
+        flat = {a.dis: lint_flat(listing)}
     else:
         objs = a.objects or [os.path.join(REPO, "hcatgnet_amd", "csrc", f) for f in MFMA_FILES]
         rep = lint_objects(objs, a.required)
+        flat = lint_objects_flat(a.objects or all_kernel_objects())
     bad = 0
+    for path, hits in flat.items():
+        print(f"{path}: {len(hits)} flat_* memory instructions")
+        for k, no, text in hits[:10]:
+            print(f"  {k[:80]} line {no}: {text}")
+        bad += len(hits)
     for path, viol in rep.items():
         print(f"{path}: {len(viol)} MFMA-result reads closer than {a.required} wait states")
         for k, no, mf, use, w in viol[:20]:
