@@ -39,24 +39,30 @@ __device__ unsigned long long g_mid_stamp[MW][4][16];
 #define MSTAMP(i) do { } while (0)
 #endif
 
+constexpr int NSLOT = 4;              // neighbour slots per row of the forward's slot table (rows of higher in-degree: CSR route)
+
 struct MidLds {   // carved out of dynamic shared memory by carve()
-  float* t0;              // [npad][HS]   forward: X -> H';   backward: dY' -> X
+  float* t0;              // [npad][HS]   forward: X -> H' (+ one all-zero row behind it);   backward: dY' -> X
   float* t1;              // [npad][HS]   backward only: dH
   short* wl;              // 3 planes of the pre-split weight image
   int* rowptr;            // [npad + 1]
-  int* cursor;            // [npad]   degree counter, then fill cursor
+  int* cursor;            // [npad]   degree counter (the fill pass counts it back down to zero)
   float* dinv;            // [npad]
   unsigned short* col;    // [emax]
+  unsigned short* nbr;    // [npad][NSLOT]   forward: the first NSLOT sources of every target, 0xffff = empty
+  int* flag;              // [4]      forward: [0] = some row of this graph overflowed its slots
   float* red;             // [MW * 2 * DD]   pooling / bias-gradient combine
 };
 
 __host__ __device__ inline size_t mid_lds_bytes(int npad, int emax, int wl_rows, int wl_k, bool two_tiles) {
   size_t b = (size_t)npad * HS * 4 * (two_tiles ? 2 : 1);
+  if (!two_tiles) b += (size_t)HS * 4;         // the zero row
   b += (size_t)3 * wl_rows * (wl_k + WPAD) * 2;
   b = (b + 15) / 16 * 16;
   b += (size_t)(npad + 1 + 3) / 4 * 16;       // rowptr
   b += (size_t)(npad + 3) / 4 * 16 * 2;       // cursor, dinv
   b += (size_t)(emax + 7) / 8 * 16;           // col (u16)
+  b += (size_t)npad * NSLOT * 2 + 16;         // nbr, flag
   b += (size_t)MW * 2 * DD * 4;
   return b + 64;
 }
@@ -69,7 +75,7 @@ __device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_r
   L.t0 = reinterpret_cast<float*>(base);
   off += (unsigned)npad * HS * 4;
   L.t1 = two_tiles ? reinterpret_cast<float*>(base + off) : nullptr;
-  if (two_tiles) off += (unsigned)npad * HS * 4;
+  off += two_tiles ? (unsigned)npad * HS * 4 : (unsigned)HS * 4;      // (one tile: row npad of t0 = the zero row)
   L.wl = reinterpret_cast<short*>(base + off);
   off += 3u * wl_rows * (wl_k + WPAD) * 2;
   off = (off + 15u) / 16u * 16u;
@@ -81,6 +87,10 @@ __device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_r
   off += (unsigned)(npad + 3) / 4 * 16;
   L.col = reinterpret_cast<unsigned short*>(base + off);
   off += (unsigned)(emax + 7) / 8 * 16;
+  L.nbr = reinterpret_cast<unsigned short*>(base + off);
+  off += (unsigned)npad * NSLOT * 2;
+  L.flag = reinterpret_cast<int*>(base + off);
+  off += 16;
   L.red = reinterpret_cast<float*>(base + off);
   return L;
 }
@@ -132,17 +142,52 @@ __device__ __forceinline__ GraphInfo graph_finish(int raw, int npad, int emax, i
 constexpr int EPT = MID_MAX_EDGES / MT;
 struct EdgeRegs {
   long long s[EPT], d[EPT];
+  // (workgroup-uniform bases + one unsigned 32-bit byte offset per slot = the scalar-base form of global_load; the clamps of
+  //  the graph's edge range are scalar work.  The kernels are bound by VALU issue: per-slot 64-bit index arithmetic counts.)
   __device__ __forceinline__ void load(const GraphInfo& gi, const int64_t* __restrict__ ei, int64_t E) {
+    long long eb = gi.ebase;
+    eb = eb < 0 ? 0 : (eb > E - 1 ? E - 1 : eb);
+    const long long room = E - eb;
+    const int nec = (long long)gi.ne < room ? gi.ne : (int)room;
+    const int last = nec > 0 ? nec - 1 : 0;
+    const char* sb = reinterpret_cast<const char*>(ei + eb);
+    const char* db = reinterpret_cast<const char*>(ei + E + eb);
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int e = threadIdx.x + j * MT;
-      int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
-      if (k > E - 1) k = E - 1;
-      s[j] = ei[k];
-      d[j] = ei[E + k];
+      const unsigned off = 8u * (unsigned)(e < last ? e : last);
+      s[j] = *reinterpret_cast<const long long*>(sb + off);
+      d[j] = *reinterpret_cast<const long long*>(db + off);
     }
   }
 };
+
+// exclusive scan of the row sizes (cursor) into rowptr by ONE wave (<= 256 rows: 4 per lane); tid = lane of wave 0
+__device__ __forceinline__ void csr_scan_rows(const MidLds& L, int nrows) {
+  const int tid = threadIdx.x;
+  constexpr int RPL = (MID_MAX_NODES + 63) / 64;
+  int v[RPL], tot = 0;
+#pragma unroll
+  for (int j = 0; j < RPL; ++j) {
+    const int i = tid * RPL + j;
+    v[j] = i < nrows ? L.cursor[i] : 0;
+    tot += v[j];
+  }
+  int incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (tid >= off) incl += t;
+  }
+  int run = incl - tot;
+#pragma unroll
+  for (int j = 0; j < RPL; ++j) {
+    const int i = tid * RPL + j;
+    if (i < nrows) L.rowptr[i] = run;
+    run += v[j];
+  }
+  if (tid == 63) L.rowptr[nrows] = incl;
+}
 
 // In-degree -> dinv, and a CSR of the graph in LDS.  BY_SRC = false: rows = targets, col = sources (forward
 // aggregation); BY_SRC = true: rows = sources, col = targets (the transpose, for the backward).  dinv is always
@@ -185,29 +230,8 @@ __device__ __forceinline__ void csr_count_scan_fill(const MidLds& L, const Graph
   if (__ballot(bad) != 0ull && (tid & 63) == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
   __syncthreads();
   MSTAMP(2);
-  if (tid < 64) {     // exclusive scan of the row sizes by wave 0 (<= 256 rows: 4 per lane) ...
-    constexpr int RPL = (MID_MAX_NODES + 63) / 64;
-    int v[RPL], tot = 0;
-#pragma unroll
-    for (int j = 0; j < RPL; ++j) {
-      const int i = tid * RPL + j;
-      v[j] = i < nrows ? L.cursor[i] : 0;
-      tot += v[j];
-    }
-    int incl = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (tid >= off) incl += t;
-    }
-    int run = incl - tot;
-#pragma unroll
-    for (int j = 0; j < RPL; ++j) {
-      const int i = tid * RPL + j;
-      if (i < nrows) L.rowptr[i] = run;
-      run += v[j];
-    }
-    if (tid == 63) L.rowptr[nrows] = incl;
+  if (tid < 64) {     // exclusive scan of the row sizes by wave 0 ...
+    csr_scan_rows(L, nrows);
   } else if (tid - 64 < nrows) {     // ... while the other waves turn the in-degrees into dinv (MT - 64 >= MID_MAX_NODES rows)
     const int i = tid - 64;
     const int degin = BY_SRC ? degin_scratch[i] : L.cursor[i];
@@ -329,63 +353,173 @@ __device__ __forceinline__ void stage_graph_rows(float* t, const float* __restri
 // otherwise one dword.  NR = the row capacity the kernel is compiled for (128 or MID_MAX_NODES): 8 .. 28 registers.
 template <int KPAD, bool VEC, int NR>
 struct XRows {
-  static constexpr int NV = (NR * KPAD / 4 + MT - 1) / MT;     // float4 slots per thread (VEC)
-  static constexpr int NS = (NR * KPAD + MT - 1) / MT;         // dword slots per thread
-  float4 v4[VEC ? NV : 1];
-  float v1[VEC ? 1 : NS];
+  static constexpr int PER_ROW = VEC ? KPAD / 4 : KPAD;        // slots per tile row
+  static constexpr int RSTEP = MT / PER_ROW;                   // rows between a thread's consecutive slots
+  static constexpr int NJ = (NR + RSTEP - 1) / RSTEP;          // slots per thread
+  static_assert(MT % PER_ROW == 0, "a thread keeps its column over all its slots");
+  float4 v4[VEC ? NJ : 1];
+  float v1[VEC ? 1 : NJ];
+  // slot j of thread t: row = t / PER_ROW + j * RSTEP, column (group) = t % PER_ROW -- the column is the thread's own, so the
+  // per-slot work is one min and one 24-bit multiply-add (global offset) or a compile-time LDS offset (write)
   __device__ __forceinline__ void load(const float* __restrict__ g, int F, const GraphInfo& gi) {
     const int nlast = gi.n > 0 ? gi.n - 1 : 0;
+    const char* base = reinterpret_cast<const char*>(g + (size_t)(gi.n > 0 ? gi.nbase : 0) * F);   // (an empty graph at the end of the batch has nbase == N)
     int t0 = threadIdx.x;
-    asm volatile("" : "+v"(t0));      // (opaque: the per-slot row / column indices are recomputed here, not kept live in
-                                      //  14 registers across the whole graph loop -- that alone cost the second workgroup)
-    const float* base = g + (size_t)(gi.n > 0 ? gi.nbase : 0) * F;       // (an empty graph at the end of the batch has nbase == N)
-    // (workgroup-uniform base + unsigned 32-bit BYTE offset = the scalar-base form of global_load: one offset register per
-    //  load instead of a 64-bit address pair -- with 14 pairs live at once the kernel needed 152+ VGPRs and lost its second
-    //  workgroup per CU.  A graph's x rows span < 4 GB.)
-    if constexpr (VEC) {
+    asm volatile("" : "+v"(t0));      // (opaque: the slot indices are recomputed here, not kept live across the graph loop)
+    const int row0 = t0 / PER_ROW, c = t0 % PER_ROW;
+    // workgroup-uniform base + unsigned 32-bit BYTE offset = the scalar-base form of global_load (one offset register per
+    // load; with a 64-bit address pair per slot the kernel lost its second workgroup per CU).  A graph's rows span < 16 MB.
+    const unsigned F4 = 4u * (unsigned)F;
+    const unsigned c4 = VEC ? 16u * (unsigned)c : 4u * (unsigned)(c < F ? c : F - 1);
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int e = t0 + j * MT, row = e / (KPAD / 4), c4 = e % (KPAD / 4);
-        v4[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + 4u * (unsigned)((row < gi.n ? row : nlast) * F + 4 * c4));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int e = t0 + j * MT, row = e / KPAD, k = e % KPAD;
-        v1[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + 4u * (unsigned)((row < gi.n ? row : nlast) * F + (k < F ? k : F - 1)));
-      }
+    for (int j = 0; j < NJ; ++j) {
+      const int row = row0 + j * RSTEP;
+      const unsigned off = __umul24((unsigned)(row < nlast ? row : nlast), F4) + c4;
+      if constexpr (VEC) v4[j] = *reinterpret_cast<const float4*>(base + off);
+      else v1[j] = *reinterpret_cast<const float*>(base + off);
     }
   }
   __device__ __forceinline__ void write(float* t, int F, const GraphInfo& gi) const {
     const int nrows = gi.nblk * 32;
     int t0 = threadIdx.x;
     asm volatile("" : "+v"(t0));
-    if constexpr (VEC) {
+    const int row0 = t0 / PER_ROW, c = t0 % PER_ROW;
+    float* at = t + row0 * HS + (VEC ? 4 * c : c);
+    const int nk = (VEC || c < F) ? gi.n : 0;          // rows below nk carry data in this thread's column, the rest are zero
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int e = t0 + j * MT, row = e / (KPAD / 4), c4 = e % (KPAD / 4);
-        if (row < nrows) *reinterpret_cast<float4*>(t + row * HS + 4 * c4) = row < gi.n ? v4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int e = t0 + j * MT, row = e / KPAD, k = e % KPAD;
-        if (row < nrows) t[row * HS + k] = (row < gi.n && k < F) ? v1[j] : 0.f;
+    for (int j = 0; j < NJ; ++j) {
+      const int row = row0 + j * RSTEP;
+      // nrows is a multiple of 32: for RSTEP <= 32 a slot is inside the tile for EVERY thread or for none (scalar branch)
+      const bool inside = RSTEP <= 32 ? j * RSTEP < nrows : row < nrows;
+      if (inside) {
+        if constexpr (VEC) *reinterpret_cast<float4*>(at + j * RSTEP * HS) = row < nk ? v4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        else at[j * RSTEP * HS] = row < nk ? v1[j] : 0.f;
       }
     }
   }
 };
+
+
+// Aggregation + epilogue of one unit of 16 rows by one wave: 16 lanes x float4 per row, 4 rows per pass (packed f32 math:
+// v_pk_add / v_pk_fma / v_pk_mul -- these kernels are bound by VALU issue).  The four passes' index words and dinv are read
+// up front in ONE LDS round trip; each pass then issues its five row reads together.
+//   slot route: nbr[row] = up to NSLOT source ids in the order the atomics ran, empty = `empty_id` (the zero row, larger
+//               than any id) -> sorted here in registers: the sum runs over ascending ids, bitwise run to run
+//   CSR route : rows already sorted in col; rows longer than NSLOT continue in a per-lane loop
+struct Quad { f32x2 lo, hi; };
+__device__ __forceinline__ Quad ldq(const char* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  Quad q;
+  q.lo = f32x2{v.x, v.y};
+  q.hi = f32x2{v.z, v.w};
+  return q;
+}
+
+template <bool CSR, bool POOL>
+__device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsigned empty_id, const Quad& bq, float slope_eff,
+                                             float* __restrict__ out_graph, int ldo, Quad& pmax, Quad& psum) {
+  const int lane = threadIdx.x & 63, q = lane & 15, r4 = lane >> 4;
+  const char* tq = reinterpret_cast<const char*>(L.t0 + 4 * q);
+  uint2 nb[4];
+  float di[4];
+  int kb[4], ke[4];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = u * 16 + pass * 4 + r4;
+    if constexpr (!CSR) {
+      nb[pass] = *reinterpret_cast<const uint2*>(L.nbr + row * NSLOT);
+    } else {
+      kb[pass] = L.rowptr[row];
+      ke[pass] = L.rowptr[row + 1];
+    }
+    di[pass] = L.dinv[row];
+  }
+  if (q == 0) {                                        // the rows' slots and counters are clean for the next graph
+    const unsigned e2 = empty_id | (empty_id << 16);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = u * 16 + pass * 4 + r4;
+      *reinterpret_cast<uint2*>(L.nbr + row * NSLOT) = make_uint2(e2, e2);
+      L.cursor[row] = 0;
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = u * 16 + pass * 4 + r4;
+    unsigned a0, a1, a2, a3;
+    if constexpr (!CSR) {
+      a0 = nb[pass].x & 0xffffu; a1 = nb[pass].x >> 16; a2 = nb[pass].y & 0xffffu; a3 = nb[pass].y >> 16;
+      unsigned t;                                      // ascending (empty sorts last)
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+    } else {
+      a0 = kb[pass] + 0 < ke[pass] ? L.col[kb[pass] + 0] : empty_id;
+      a1 = kb[pass] + 1 < ke[pass] ? L.col[kb[pass] + 1] : empty_id;
+      a2 = kb[pass] + 2 < ke[pass] ? L.col[kb[pass] + 2] : empty_id;
+      a3 = kb[pass] + 3 < ke[pass] ? L.col[kb[pass] + 3] : empty_id;
+    }
+    Quad acc = ldq(tq + __umul24((unsigned)row, HS * 4u));
+    const Quad n0 = ldq(tq + __umul24(a0, HS * 4u)), n1 = ldq(tq + __umul24(a1, HS * 4u));
+    const Quad n2 = ldq(tq + __umul24(a2, HS * 4u)), n3 = ldq(tq + __umul24(a3, HS * 4u));
+    acc.lo += n0.lo; acc.hi += n0.hi;
+    acc.lo += n1.lo; acc.hi += n1.hi;
+    acc.lo += n2.lo; acc.hi += n2.hi;
+    acc.lo += n3.lo; acc.hi += n3.hi;
+    if constexpr (CSR) {
+      for (int k = kb[pass] + NSLOT; __any(k < ke[pass]); ++k) {
+        if (k < ke[pass]) {
+          const Quad v = ldq(tq + __umul24((unsigned)L.col[k], HS * 4u));
+          acc.lo += v.lo; acc.hi += v.hi;
+        }
+      }
+    }
+    const f32x2 d2 = f32x2{di[pass], di[pass]}, s2 = f32x2{slope_eff, slope_eff};
+    Quad y;
+    y.lo = __builtin_elementwise_fma(d2, acc.lo, bq.lo);
+    y.hi = __builtin_elementwise_fma(d2, acc.hi, bq.hi);
+    y.lo = __builtin_elementwise_max(y.lo, s2 * y.lo);   // LeakyReLU as max(v, slope v): exact for 0 <= slope <= 1; none: slope 1
+    y.hi = __builtin_elementwise_max(y.hi, s2 * y.hi);
+    if (row < n) {
+      *reinterpret_cast<float4*>(out_graph + (size_t)row * ldo + 4 * q) = make_float4(y.lo.x, y.lo.y, y.hi.x, y.hi.y);
+      if (POOL) {
+        pmax.lo = __builtin_elementwise_max(pmax.lo, y.lo);
+        pmax.hi = __builtin_elementwise_max(pmax.hi, y.hi);
+        psum.lo += y.lo;
+        psum.hi += y.hi;
+      }
+    }
+  }
+}
 
 // =====================================================================================================
 // forward of one layer, one graph per workgroup iteration
 // =====================================================================================================
 // One launch produces 64 output columns [coff, coff + 64) of a layer `ldo` columns wide (ldo = 64: the whole layer; ldo =
 // 128: one of two independent column halves -- W / bias already point at the half's rows).  Inputs wider than 64
-// features are contracted in K-chunks of 64 through the same LDS tile (accumulators stay in registers: a wave owns ONE
-// 32-row block, the host guarantees nblk <= 8).
+// features are contracted in K-chunks of 64 through the same LDS tile (MULTIK: accumulators stay in registers, a wave owns
+// ONE 32-row block, the host guarantees nblk <= 8).
+//
+// A graph's iteration is a chain of dependent LDS / barrier round trips (tools/probe_mid.hip stamps them), so the kernel is
+// built to keep that chain short -- round 3, 18 600 -> ~? cycles per graph on the reference-sized batch:
+//   * neighbour SLOT TABLE instead of a CSR: one pass over the edges (slot = atomic in-degree counter; the first NSLOT
+//     sources of a target go to nbr[target][slot]) replaces count + scan + fill + sort and three of their four barriers;
+//     the slots' order depends on the atomics, so the reader SORTS the four ids in registers (summation stays "ascending
+//     neighbour id", bitwise run to run).  A graph with an in-degree above NSLOT (no molecule of the reference's data) takes
+//     the CSR route for that graph -- the counters already hold the in-degrees.
+//   * aggregation (mid_agg_unit): the index words of a unit's four passes are read in ONE round trip (the CSR went through
+//     rowptr -> col -> rows once per pass), empty slots name an all-zero row (no branches), packed f32 math.
+//   * the kernel is bound by VALU ISSUE, not by the length of the chain (two workgroups = four waves per SIMD; per graph and
+//     CU ~8 x the per-wave VALU count in cycles): index arithmetic is 24-bit multiply-adds on workgroup-uniform bases,
+//     LDS offsets are compile-time immediates, guards are scalar where the geometry allows it.
+//   * the next graph's edges and x rows are requested a graph ahead, its four scalars two graphs ahead.
 // VEC / NR: how the x rows are prefetched (XRows; unused by MULTIK, which stages chunk by chunk inside the iteration).
+// (launch bounds: four waves per SIMD = two workgroups per CU = at most 128 VGPRs -- the scheduler trades load batching for
+//  registers instead of silently dropping to one workgroup per CU; MULTIK needs more and runs one workgroup per CU)
 template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR>
-__global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
+__global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int64_t* __restrict__ ei,
                                                          int64_t E, const int32_t* __restrict__ graph_ptr,
                                                          const int32_t* __restrict__ edge_ptr, int B, int npad, int emax,
@@ -395,7 +529,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
   const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
   const MidLds L = carve(smem, npad, emax, DD * nkc, KPAD, false);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5, q = lane & 15, r4 = lane >> 4;
+  const int r = lane & 31, h = lane >> 5;
 
   // the weight image(s) are loop invariant: staged ONCE per workgroup, every K-chunk's image resident (MULTIK: two images,
   // 55 KB -- these kernels run one workgroup per CU anyway; re-staging a chunk's image per graph cost 8 global loads, 24
@@ -406,8 +540,18 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
   } else {
     for (int kc = 0; kc < nkc; ++kc) stage_weight_split<false, MT, DD, KPAD>(L.wl + kc * IMG, W, DD, F, kc * KPAD);
   }
-  const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+  Quad bq;
+  {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * (lane & 15));
+    bq.lo = f32x2{b4.x, b4.y};
+    bq.hi = f32x2{b4.z, b4.w};
+  }
+  const float slope_eff = apply_act ? slope : 1.0f;    // LeakyReLU as max(v, slope v): exact for 0 <= slope <= 1; none: slope 1
+  const unsigned empty_id = (unsigned)npad;            // an empty slot names the all-zero row behind the tile: no branches
   csr_counters_clear(L, npad, nullptr);
+  for (int i = tid; i < npad * NSLOT / 2; i += MT) reinterpret_cast<unsigned*>(L.nbr)[i] = empty_id | (empty_id << 16);
+  if (tid < HS) L.t0[npad * HS + tid] = 0.f;
+  if (tid == 0) L.flag[0] = 0;
   __syncthreads();
 
   // (the grid never exceeds B: every workgroup has a first graph; past its last graph a workgroup requests the batch's
@@ -423,33 +567,86 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
   (void)mstamp_it;
   for (int g = blockIdx.x; g < B; g += G) {
     MSTAMP(0);
-    if constexpr (MULTIK) stage_graph_rows<KPAD, true>(L.t0, x, F, 0, gi.nbase, gi.n, gi.nblk);
-    MSTAMP(1);
-    csr_count_scan_fill<false>(L, gi, er, status, nullptr, mstamp_it);
-    if constexpr (!MULTIK) xr.write(L.t0, F, gi);     // (requested at the end of the previous graph: ~3 500 cycles ago)
-    csr_sort_rows(L, gi);                               // (ends with a barrier: the x tile is complete too)
-    MSTAMP(5);
-
-    // ---- H' = dinv (.) (X W^T), in place, each wave on its own 32-row blocks
-    if constexpr (!MULTIK) {
-      for (int mb = wave; mb < gi.nblk; mb += MW) {
-        float* blk = L.t0 + mb * 32 * HS;
-        f32x16 acc0, acc1;
+    const GraphInfo gcur = gi;
+    const int nrows = gcur.nblk * 32;
+    // ---- the graph's edges (in registers since the previous graph) -> in-degree counters + slot table; its x rows -> tile
+    unsigned short es[EPT], ed[EPT];
+    {
+      bool bad = false, over = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * MT;
+        es[j] = 0xffff;
+        ed[j] = 0xffff;
+        if (e < gcur.ne) {
+          const long long sv = er.s[j], dv = er.d[j];
+          const unsigned sl = (unsigned)((int)sv - gcur.nbase), dl = (unsigned)((int)dv - gcur.nbase);
+          const bool ok = sl < (unsigned)gcur.n && dl < (unsigned)gcur.n && (sv >> 31) == 0 && (dv >> 31) == 0;
+          bad |= !ok;
+          if (ok && sl != dl) {          // an explicit (i, i) edge collapses into the unit self loop (PyG add_remaining_self_loops)
+            es[j] = (unsigned short)sl;
+            ed[j] = (unsigned short)dl;
+            const int slot = atomicAdd(&L.cursor[dl], 1);
+            if (slot < NSLOT) L.nbr[dl * NSLOT + slot] = (unsigned short)sl;
+            else over = true;
+          }
+        }
+      }
+      if (__ballot(bad) != 0ull && lane == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);   // edge leaves its graph: ignored
+      if (__ballot(over) != 0ull && lane == 0) L.flag[0] = 1;
+    }
+    if constexpr (MULTIK) stage_graph_rows<KPAD, true>(L.t0, x, F, 0, gcur.nbase, gcur.n, gcur.nblk);
+    else xr.write(L.t0, F, gcur);
+    MSTAMP(1);
+    __syncthreads();
+    MSTAMP(2);
+    const bool csr_route = __builtin_amdgcn_readfirstlane(L.flag[0]) != 0;
+    // dinv = (1 + in-degree)^-1/2 of a row block by the wave that owns the block in the GEMM below (its H' write reads them
+    // back: same wave, LDS runs in order -- no barrier in between)
+    if (wave < gcur.nblk && lane < 32) {
+      const int i = wave * 32 + lane;
+      L.dinv[i] = i < gcur.n ? 1.0f / sqrtf(1.0f + (float)L.cursor[i]) : 0.f;
+    }
+    if (csr_route) {        // some in-degree > NSLOT: CSR of the graph (the counters hold the row sizes), rows sorted by id
+      if (tid < 64) csr_scan_rows(L, nrows);
+      __syncthreads();      // (also: every dinv above has read its counter before the fill pass counts them down)
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        if (es[j] != 0xffff) {
+          const int left = atomicSub(&L.cursor[ed[j]], 1);          // counts the row back down to zero
+          L.col[L.rowptr[ed[j]] + left - 1] = es[j];
+        }
+      }
+      __syncthreads();
+      csr_sort_rows(L, gcur);
+    }
+    MSTAMP(3);
+
+    // ---- H' = dinv (.) (X W^T), in place: wave -> its own 32-row block, both column halves (eight waves on (row block,
+    //      column half) blocks were measured: every A fragment is then split twice, and the kernel is bound by VALU issue)
+    if (wave < gcur.nblk) {       // (nblk <= 7; MULTIK: the host guarantees nblk <= 8)
+      float* blk = L.t0 + wave * 32 * HS;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      if constexpr (!MULTIK) {
         tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
+      }
+      if constexpr (!MULTIK) {
         mfma_results_fence(acc0, acc1);
+        MSTAMP(4);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = krow(i, h);
-          const float dv = L.dinv[mb * 32 + row];
-          blk[row * HS + r] = acc0[i] * dv;
-          blk[row * HS + 32 + r] = acc1[i] * dv;
+          const float dv = L.dinv[wave * 32 + row];
+          const f32x2 hv = f32x2{acc0[i], acc1[i]} * f32x2{dv, dv};
+          blk[row * HS + r] = hv.x;
+          blk[row * HS + 32 + r] = hv.y;
         }
       }
-    } else {
-      // inputs wider than 64 features: K-chunk by K-chunk through the same tile; the accumulators stay in registers (a
-      // wave owns ONE block: the host guarantees nblk <= 8)
+    }
+    if constexpr (MULTIK) {
+      // inputs wider than 64 features: K-chunk by K-chunk through the same tile; the accumulators stay in registers
       const int mb = wave;
       float* blk = L.t0 + mb * 32 * HS;
       f32x16 acc0, acc1;
@@ -458,13 +655,14 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
       for (int kc = 0; kc < nkc; ++kc) {
         if (kc > 0) {
           __syncthreads();                                           // every wave is done with the previous chunk
-          stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gi.nbase, gi.n, gi.nblk);
+          stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gcur.nbase, gcur.n, gcur.nblk);
           __syncthreads();
         }
-        if (mb < gi.nblk) tile_gemm_split<KPAD>(blk, L.wl + kc * IMG, acc0, acc1, lane);
+        if (mb < gcur.nblk) tile_gemm_split<KPAD>(blk, L.wl + kc * IMG, acc0, acc1, lane);
       }
+      MSTAMP(4);
       __syncthreads();                                               // the last x chunk is dead: H' may overwrite it
-      if (mb < gi.nblk) {
+      if (mb < gcur.nblk) {
         mfma_results_fence(acc0, acc1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -478,66 +676,54 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_fwd(const float* __restrict
     MSTAMP(6);
     __syncthreads();
     MSTAMP(7);
+    if (tid == 0) L.flag[0] = 0;                         // (every thread read it before the barrier above)
 
-    // the NEXT graph's edges are requested here (its scalars were requested a graph ago): they land while this graph is
-    // aggregated and stored; the scalars of the graph after next follow.  Its x rows are requested BEHIND the aggregation
-    // (whose registers they would otherwise share: 150+ VGPRs = one workgroup per CU) and written to the tile between the
-    // next graph's fill and sort passes -- pooling, two barriers, count, scan and fill in between cover the HBM latency
-    const GraphInfo gcur = gi;
+    // the NEXT graph's edges and x rows are requested here (its scalars were requested a graph ago): they land while this
+    // graph is aggregated and stored; the scalars of the graph after next follow
     gi = graph_finish(raw_next, npad, emax, status);
     er.load(gi, ei, E);
+    if constexpr (!MULTIK) xr.load(x, F, gi);
     raw_next = graph_raw(min(g + 2 * G, B - 1), graph_ptr, edge_ptr);
     MSTAMP(8);
 
-    // ---- Y_i = H'_i + sum_k H'_{col k};  out = LeakyReLU(dinv_i Y_i + b).  16 lanes x float4 per row, 4 rows per pass.
-    float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- Y_i = H'_i + sum_k H'_{nbr k} (ascending ids);  out = LeakyReLU(dinv_i Y_i + b)
+    Quad pmax, psum;
+    pmax.lo = pmax.hi = f32x2{-INFINITY, -INFINITY};
+    psum.lo = psum.hi = f32x2{0.f, 0.f};
+    float* out_graph = out + (size_t)gcur.nbase * ldo + coff;
     for (int u = wave; u < gcur.nblk * 2; u += MW) {      // units of 16 rows
-#pragma unroll 2
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = u * 16 + pass * 4 + r4;
-        const bool valid = row < gcur.n;
-        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-        const float4 acc = mid_row_sum(L.t0, L.col, row, kb, ke, q);
-        const float di = L.dinv[row];
-        float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
-        if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
-        if (valid) {
-          *reinterpret_cast<float4*>(out + (size_t)(gcur.nbase + row) * ldo + coff + 4 * q) = y;
-          if (POOL) {
-            pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
-            psum.x += y.x; psum.y += y.y; psum.z += y.z; psum.w += y.w;
-          }
-        }
-      }
+      if (!csr_route) mid_agg_unit<false, POOL>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum);
+      else mid_agg_unit<true, POOL>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum);
     }
-    if constexpr (!MULTIK) xr.load(x, F, gi);
     MSTAMP(9);
     if (POOL) {   // rows of this lane's (r4, q) slot -> wave (xor 16, 32) -> workgroup (LDS, fixed order)
-      pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 16, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 16, 64)),
-                         fmaxf(pmax.z, __shfl_xor(pmax.z, 16, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 16, 64)));
-      pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 32, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 32, 64)),
-                         fmaxf(pmax.z, __shfl_xor(pmax.z, 32, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 32, 64)));
-      psum.x += __shfl_xor(psum.x, 16, 64); psum.y += __shfl_xor(psum.y, 16, 64); psum.z += __shfl_xor(psum.z, 16, 64); psum.w += __shfl_xor(psum.w, 16, 64);
-      psum.x += __shfl_xor(psum.x, 32, 64); psum.y += __shfl_xor(psum.y, 32, 64); psum.z += __shfl_xor(psum.z, 32, 64); psum.w += __shfl_xor(psum.w, 32, 64);
+      const int q = lane & 15, r4 = lane >> 4;
+      float4 pm = make_float4(pmax.lo.x, pmax.lo.y, pmax.hi.x, pmax.hi.y), sm = make_float4(psum.lo.x, psum.lo.y, psum.hi.x, psum.hi.y);
+      pm = make_float4(fmaxf(pm.x, __shfl_xor(pm.x, 16, 64)), fmaxf(pm.y, __shfl_xor(pm.y, 16, 64)),
+                       fmaxf(pm.z, __shfl_xor(pm.z, 16, 64)), fmaxf(pm.w, __shfl_xor(pm.w, 16, 64)));
+      pm = make_float4(fmaxf(pm.x, __shfl_xor(pm.x, 32, 64)), fmaxf(pm.y, __shfl_xor(pm.y, 32, 64)),
+                       fmaxf(pm.z, __shfl_xor(pm.z, 32, 64)), fmaxf(pm.w, __shfl_xor(pm.w, 32, 64)));
+      sm.x += __shfl_xor(sm.x, 16, 64); sm.y += __shfl_xor(sm.y, 16, 64); sm.z += __shfl_xor(sm.z, 16, 64); sm.w += __shfl_xor(sm.w, 16, 64);
+      sm.x += __shfl_xor(sm.x, 32, 64); sm.y += __shfl_xor(sm.y, 32, 64); sm.z += __shfl_xor(sm.z, 32, 64); sm.w += __shfl_xor(sm.w, 32, 64);
       if (r4 == 0) {
-        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + 4 * q) = pmax;
-        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + DD + 4 * q) = psum;
+        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + 4 * q) = pm;
+        *reinterpret_cast<float4*>(L.red + wave * 2 * DD + DD + 4 * q) = sm;
       }
       __syncthreads();
       if (tid < DD) {
-        float m = -INFINITY, s = 0.f;
+        float m = -INFINITY, sum = 0.f;
 #pragma unroll
         for (int w = 0; w < MW; ++w) {                    // fixed order over the waves
           m = fmaxf(m, L.red[w * 2 * DD + tid]);
-          s += L.red[w * 2 * DD + DD + tid];
+          sum += L.red[w * 2 * DD + DD + tid];
         }
         if (gcur.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * ldo + coff + tid] = m;                                   // [max | mean], each ldo wide
-        emb[(size_t)g * 2 * ldo + ldo + coff + tid] = s / (float)(gcur.n > 0 ? gcur.n : 1);
+        emb[(size_t)g * 2 * ldo + ldo + coff + tid] = sum / (float)(gcur.n > 0 ? gcur.n : 1);
       }
     }
     MSTAMP(10);
-    __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
+    __syncthreads();   // the tile, the slot table and the combine scratch are free for the next graph
     MSTAMP(11);
 #ifdef HCG_MID_STAMP
     ++mstamp_it;

@@ -51,12 +51,13 @@ int main(int argc, char** argv) {
 #ifdef HCG_MID_STAMP
   static unsigned long long st[MW][4][16];
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mid_stamp), sizeof(st)));
-  const char* nm[] = {"", "x rows -> LDS", "zero, count, barrier", "scan, dinv, cursor (3 barriers)", "fill + barrier", "sort + barrier", "GEMM + H' write",
-                      "barrier", "prefetch issue", "aggregate + store", "pool", "end barrier"};
+  const int idx[] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11};
+  const char* nm[] = {"", "count + slots + x write", "barrier", "dinv (+ CSR route)", "GEMM", "H' write", "barrier",
+                      "prefetch issue", "aggregate + store", "pool", "end barrier"};
   for (int w : {0, 2, 5, 7})
     for (int it = 0; it < 3; ++it) {
       printf("wave %d graph %d:", w, it);
-      for (int i = 1; i < 12; ++i) printf(" %s %llu |", nm[i], st[w][it][i] - st[w][it][i - 1]);
+      for (int i = 1; i < 11; ++i) printf(" %s %llu |", nm[i], st[w][it][idx[i]] - st[w][it][idx[i - 1]]);
       printf(" total %llu\n", st[w][it][11] - st[w][it][0]);
     }
 #endif
