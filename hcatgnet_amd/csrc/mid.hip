@@ -97,6 +97,17 @@ __device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_r
 
 struct GraphInfo { int nbase, n, ebase, ne, nblk; };
 
+// host metadata that does not fit the kernel's tile: the graph is refused (n = ne = 0) and reported.  The selects stay
+// OUTSIDE the branch of the reporting thread: assigned inside it, n and ne became per-lane registers and every address
+// derived from them a 64-bit vector computation.
+__device__ __forceinline__ void graph_validate(GraphInfo& gi, int npad, int emax, int32_t* status) {
+  const bool bad = gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax;
+  gi.n = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.n);
+  gi.ne = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.ne);
+  gi.nblk = (gi.n + 31) / 32;
+  if (bad && threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
+}
+
 __device__ __forceinline__ GraphInfo graph_info(int g, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
                                                 int npad, int emax, int32_t* status) {
   GraphInfo gi;
@@ -104,12 +115,7 @@ __device__ __forceinline__ GraphInfo graph_info(int g, const int32_t* __restrict
   gi.n = graph_ptr[g + 1] - gi.nbase;
   gi.ebase = edge_ptr[g];
   gi.ne = edge_ptr[g + 1] - gi.ebase;
-  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax) {     // host metadata was wrong: refuse the graph
-    if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
-    gi.n = 0;
-    gi.ne = 0;
-  }
-  gi.nblk = (gi.n + 31) / 32;
+  graph_validate(gi, npad, emax, status);
   return gi;
 }
 
@@ -128,12 +134,7 @@ __device__ __forceinline__ GraphInfo graph_finish(int raw, int npad, int emax, i
   gi.n = __builtin_amdgcn_readlane(raw, 1) - gi.nbase;
   gi.ebase = __builtin_amdgcn_readlane(raw, 2);
   gi.ne = __builtin_amdgcn_readlane(raw, 3) - gi.ebase;
-  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > emax) {     // host metadata was wrong: refuse the graph
-    if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
-    gi.n = 0;
-    gi.ne = 0;
-  }
-  gi.nblk = (gi.n + 31) / 32;
+  graph_validate(gi, npad, emax, status);
   return gi;
 }
 
@@ -406,6 +407,38 @@ struct XRows {
 //   slot route: nbr[row] = up to NSLOT source ids in the order the atomics ran, empty = `empty_id` (the zero row, larger
 //               than any id) -> sorted here in registers: the sum runs over ascending ids, bitwise run to run
 //   CSR route : rows already sorted in col; rows longer than NSLOT continue in a per-lane loop
+// Combine a value over the four 16-lane rows of a wave with gfx950's v_permlane16_swap / v_permlane32_swap (one VALU
+// instruction per exchange; __shfl_xor compiles to ds_bpermute: 16 dependent LDS round trips per graph in the pooling tail).
+// permlane16_swap(v, v) -> { rows (0, 0, 2, 2), rows (1, 1, 3, 3) };  permlane32_swap(v, v) -> { lower half twice, upper half twice }
+// (the results are copied to scalars before they are reinterpreted: __builtin_bit_cast applied to the vector ELEMENT p[1]
+//  reads element 0 with hipcc 7.2 -- it produced max(a, a) / a + a, measured as wrong pooled outputs)
+__device__ __forceinline__ void rows_pair(float v, float& even, float& odd) {
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned p0 = p[0], p1 = p[1];
+  even = __uint_as_float(p0);
+  odd = __uint_as_float(p1);
+}
+__device__ __forceinline__ void halves_pair(float v, float& lower, float& upper) {
+  const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const unsigned p0 = p[0], p1 = p[1];
+  lower = __uint_as_float(p0);
+  upper = __uint_as_float(p1);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  float a, b;
+  rows_pair(v, a, b);
+  v = fmaxf(a, b);
+  halves_pair(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {        // (row 0 + row 1) + (row 2 + row 3), the same in every lane
+  float a, b;
+  rows_pair(v, a, b);
+  v = a + b;
+  halves_pair(v, a, b);
+  return a + b;
+}
+
 struct Quad { f32x2 lo, hi; };
 __device__ __forceinline__ Quad ldq(const char* p) {
   const float4 v = *reinterpret_cast<const float4*>(p);
@@ -563,9 +596,9 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
   er.load(gi, ei, E);
   if constexpr (!MULTIK) xr.load(x, F, gi);
   int raw_next = graph_raw(min((int)blockIdx.x + G, B - 1), graph_ptr, edge_ptr);
-  int mstamp_it = 0;
+  int mstamp_it = 0, rot = 0;
   (void)mstamp_it;
-  for (int g = blockIdx.x; g < B; g += G) {
+  for (int g = blockIdx.x; g < B; g += G, rot += 3) {
     MSTAMP(0);
     const GraphInfo gcur = gi;
     const int nrows = gcur.nblk * 32;
@@ -603,8 +636,11 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
     const bool csr_route = __builtin_amdgcn_readfirstlane(L.flag[0]) != 0;
     // dinv = (1 + in-degree)^-1/2 of a row block by the wave that owns the block in the GEMM below (its H' write reads them
     // back: same wave, LDS runs in order -- no barrier in between)
-    if (wave < gcur.nblk && lane < 32) {
-      const int i = wave * 32 + lane;
+    // (row block -> wave rotates from graph to graph: the two or three GEMM waves of an 87-node graph would otherwise load
+    //  the same SIMDs every time, in both workgroups of the CU)
+    const int wblk = (wave + rot) & (MW - 1);
+    if (wblk < gcur.nblk && lane < 32) {
+      const int i = wblk * 32 + lane;
       L.dinv[i] = i < gcur.n ? 1.0f / sqrtf(1.0f + (float)L.cursor[i]) : 0.f;
     }
     if (csr_route) {        // some in-degree > NSLOT: CSR of the graph (the counters hold the row sizes), rows sorted by id
@@ -624,30 +660,31 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
 
     // ---- H' = dinv (.) (X W^T), in place: wave -> its own 32-row block, both column halves (eight waves on (row block,
     //      column half) blocks were measured: every A fragment is then split twice, and the kernel is bound by VALU issue)
-    if (wave < gcur.nblk) {       // (nblk <= 7; MULTIK: the host guarantees nblk <= 8)
-      float* blk = L.t0 + wave * 32 * HS;
+    if (wblk < gcur.nblk) {       // (nblk <= 7; MULTIK: the host guarantees nblk <= 8)
+      float* blk = L.t0 + wblk * 32 * HS;
       f32x16 acc0, acc1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
       if constexpr (!MULTIK) {
-        tile_gemm_split<KPAD>(blk, L.wl, acc0, acc1, lane);
-      }
-      if constexpr (!MULTIK) {
+        // transposed product: lane = tile row, register quads = 4 consecutive columns -> H' goes back as 8 x ds_write_b128
+        // with ONE dinv per lane (row-per-register it was 32 x ds_write_b32 + 16 dinv reads: 1 500 cycles per graph)
+        tile_gemm_split_t<KPAD>(blk, L.wl, acc0, acc1, lane);
         mfma_results_fence(acc0, acc1);
         MSTAMP(4);
+        const float dv = L.dinv[wblk * 32 + r];
+        float* hrow = blk + r * HS + 4 * h;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = krow(i, h);
-          const float dv = L.dinv[wave * 32 + row];
-          const f32x2 hv = f32x2{acc0[i], acc1[i]} * f32x2{dv, dv};
-          blk[row * HS + r] = hv.x;
-          blk[row * HS + 32 + r] = hv.y;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          *reinterpret_cast<float4*>(hrow + 8 * g4) =
+              make_float4(acc0[4 * g4] * dv, acc0[4 * g4 + 1] * dv, acc0[4 * g4 + 2] * dv, acc0[4 * g4 + 3] * dv);
+          *reinterpret_cast<float4*>(hrow + 32 + 8 * g4) =
+              make_float4(acc1[4 * g4] * dv, acc1[4 * g4 + 1] * dv, acc1[4 * g4 + 2] * dv, acc1[4 * g4 + 3] * dv);
         }
       }
     }
     if constexpr (MULTIK) {
       // inputs wider than 64 features: K-chunk by K-chunk through the same tile; the accumulators stay in registers
-      const int mb = wave;
+      const int mb = wblk;
       float* blk = L.t0 + mb * 32 * HS;
       f32x16 acc0, acc1;
 #pragma unroll
@@ -658,18 +695,20 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
           stage_graph_rows<KPAD, true>(L.t0, x, F, kc * KPAD, gcur.nbase, gcur.n, gcur.nblk);
           __syncthreads();
         }
-        if (mb < gcur.nblk) tile_gemm_split<KPAD>(blk, L.wl + kc * IMG, acc0, acc1, lane);
+        if (mb < gcur.nblk) tile_gemm_split_t<KPAD>(blk, L.wl + kc * IMG, acc0, acc1, lane);
       }
       MSTAMP(4);
       __syncthreads();                                               // the last x chunk is dead: H' may overwrite it
       if (mb < gcur.nblk) {
         mfma_results_fence(acc0, acc1);
+        const float dv = L.dinv[mb * 32 + r];
+        float* hrow = blk + r * HS + 4 * h;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = krow(i, h);
-          const float dv = L.dinv[mb * 32 + row];
-          blk[row * HS + r] = acc0[i] * dv;
-          blk[row * HS + 32 + r] = acc1[i] * dv;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          *reinterpret_cast<float4*>(hrow + 8 * g4) =
+              make_float4(acc0[4 * g4] * dv, acc0[4 * g4 + 1] * dv, acc0[4 * g4 + 2] * dv, acc0[4 * g4 + 3] * dv);
+          *reinterpret_cast<float4*>(hrow + 32 + 8 * g4) =
+              make_float4(acc1[4 * g4] * dv, acc1[4 * g4 + 1] * dv, acc1[4 * g4 + 2] * dv, acc1[4 * g4 + 3] * dv);
         }
       }
     }
@@ -696,15 +735,10 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
       else mid_agg_unit<true, POOL>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum);
     }
     MSTAMP(9);
-    if (POOL) {   // rows of this lane's (r4, q) slot -> wave (xor 16, 32) -> workgroup (LDS, fixed order)
+    if (POOL) {   // rows of this lane's (r4, q) slot -> wave (the four 16-lane rows) -> workgroup (LDS, fixed order)
       const int q = lane & 15, r4 = lane >> 4;
-      float4 pm = make_float4(pmax.lo.x, pmax.lo.y, pmax.hi.x, pmax.hi.y), sm = make_float4(psum.lo.x, psum.lo.y, psum.hi.x, psum.hi.y);
-      pm = make_float4(fmaxf(pm.x, __shfl_xor(pm.x, 16, 64)), fmaxf(pm.y, __shfl_xor(pm.y, 16, 64)),
-                       fmaxf(pm.z, __shfl_xor(pm.z, 16, 64)), fmaxf(pm.w, __shfl_xor(pm.w, 16, 64)));
-      pm = make_float4(fmaxf(pm.x, __shfl_xor(pm.x, 32, 64)), fmaxf(pm.y, __shfl_xor(pm.y, 32, 64)),
-                       fmaxf(pm.z, __shfl_xor(pm.z, 32, 64)), fmaxf(pm.w, __shfl_xor(pm.w, 32, 64)));
-      sm.x += __shfl_xor(sm.x, 16, 64); sm.y += __shfl_xor(sm.y, 16, 64); sm.z += __shfl_xor(sm.z, 16, 64); sm.w += __shfl_xor(sm.w, 16, 64);
-      sm.x += __shfl_xor(sm.x, 32, 64); sm.y += __shfl_xor(sm.y, 32, 64); sm.z += __shfl_xor(sm.z, 32, 64); sm.w += __shfl_xor(sm.w, 32, 64);
+      const float4 pm = make_float4(rows_max(pmax.lo.x), rows_max(pmax.lo.y), rows_max(pmax.hi.x), rows_max(pmax.hi.y));
+      const float4 sm = make_float4(rows_sum(psum.lo.x), rows_sum(psum.lo.y), rows_sum(psum.hi.x), rows_sum(psum.hi.y));
       if (r4 == 0) {
         *reinterpret_cast<float4*>(L.red + wave * 2 * DD + 4 * q) = pm;
         *reinterpret_cast<float4*>(L.red + wave * 2 * DD + DD + 4 * q) = sm;

@@ -192,5 +192,39 @@ __device__ __forceinline__ void tile_gemm_split(const float* buf, const short* w
   }
 }
 
+// The same product TRANSPOSED: the weight image is the MFMA's A operand, the tile rows its B operand, so that
+// acc{0,1} = H^T blocks -- lane (r, h) holds ROW r of the tile, registers 4g .. 4g+3 its columns 8g + 4h + 0..3 (+ 32 for
+// acc1): four consecutive columns of one row per register quad.  A row-major write-back is then 4 x ds_write_b128 per
+// accumulator (lane-contiguous, conflict free with the HS row stride) instead of 16 x ds_write_b32, and a per-row scale is
+// ONE value per lane.  Same six cross terms in the same order as tile_gemm_split.
+template <int K>
+__device__ __forceinline__ void tile_gemm_split_t(const float* buf, const short* wl, f32x16& acc0, f32x16& acc1, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int ld = K + WPAD, plane = DD * ld;
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    const float4 a0 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h);
+    const float4 a1 = *reinterpret_cast<const float4*>(buf + r * HS + 16 * s + 8 * h + 4);
+    const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const Split3 X = split3(xa);
+    const short* w0 = wl + r * ld + 16 * s + 8 * h;
+    const short* w1 = w0 + 32 * ld;
+#define HCG_SPLIT_T(ACC, W)                                                        \
+    do {                                                                           \
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(W);                       \
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>((W) + plane);             \
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>((W) + 2 * plane);         \
+      ACC = HCG_MFMA(b1, X.p3, ACC);                                               \
+      ACC = HCG_MFMA(b3, X.p1, ACC);                                               \
+      ACC = HCG_MFMA(b2, X.p2, ACC);                                               \
+      ACC = HCG_MFMA(b1, X.p2, ACC);                                               \
+      ACC = HCG_MFMA(b2, X.p1, ACC);                                               \
+      ACC = HCG_MFMA(b1, X.p1, ACC);                                               \
+    } while (0)
+    HCG_SPLIT_T(acc0, w0);
+    HCG_SPLIT_T(acc1, w1);
+#undef HCG_SPLIT_T
+  }
+}
 
 }  // namespace

@@ -27,3 +27,9 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# development only: run the GPU tests against a library variant (tools/build_variants.sh, A/B bisects on one box)
+if os.environ.get("HCG_LIB"):
+    from hcatgnet_amd import _lib as _hcg_lib
+    _hcg_lib.LIB_PATH = os.path.abspath(os.environ["HCG_LIB"])
