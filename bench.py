@@ -442,6 +442,9 @@ def main():
     F, D = cfg["feat"], cfg["hidden"]
     opt = H.default_options(embedding_dim=D)
     model = H.make_network("GCN", opt, F).to(dev)
+    if os.environ.get("HCG_FAMILY_MID") == "1":       # development A/B: keep every layer on the one-graph-per-workgroup kernels
+        for cv in [model.conv1] + list(model.conv_layers):
+            cv.family = "mid"
 
     class Resident:
         """One synthetic batch in HBM (its own seed stream: base + 1000 * (rank + world * i))."""

@@ -27,8 +27,28 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_
 
 struct Split3 { bf16x8 p1, p2, p3; };
 // 8 f32 -> three bf16 fragments with x = p1 + p2 + p3 (each residual is exact in f32)
+// (the residuals are PAIR subtractions, v_pk_add_f32: same IEEE results, one instruction per two values -- the split is most
+//  of the VALU work of every MFMA kernel here, and those kernels are bound by VALU issue.  HCG_SPLIT_SCALAR: the one-value
+//  form, for A/B measurements with tools/build_variants.sh)
 __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
   u32x4 a, b, c;
+#ifndef HCG_SPLIT_SCALAR
+  f32x2 r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = pk_bf16(x[2 * j], x[2 * j + 1]);
+    a[j] = u;
+    r[j] = f32x2{x[2 * j], x[2 * j + 1]} - f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = pk_bf16(r[j].x, r[j].y);
+    b[j] = u;
+    r[j] -= f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = pk_bf16(r[j].x, r[j].y);
+#else
   float r[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -46,6 +66,7 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) c[j] = pk_bf16(r[2 * j], r[2 * j + 1]);
+#endif
   Split3 s;
   s.p1 = __builtin_bit_cast(bf16x8, a);
   s.p2 = __builtin_bit_cast(bf16x8, b);
