@@ -404,8 +404,8 @@ struct XRows {
 // Aggregation + epilogue of one unit of 16 rows by one wave: 16 lanes x float4 per row, 4 rows per pass (packed f32 math:
 // v_pk_add / v_pk_fma / v_pk_mul -- these kernels are bound by VALU issue).  The four passes' index words and dinv are read
 // up front in ONE LDS round trip; each pass then issues its five row reads together.
-//   slot route: nbr[row] = up to NSLOT source ids in the order the atomics ran, empty = `empty_id` (the zero row, larger
-//               than any id) -> sorted here in registers: the sum runs over ascending ids, bitwise run to run
+//   slot route: nbr[row] = up to NSLOT source ids, ascending (sorted by the lane that computed the row's dinv), empty =
+//               `empty_id` (the zero row, larger than any id): the sum runs over ascending ids, bitwise run to run
 //   CSR route : rows already sorted in col; rows longer than NSLOT continue in a per-lane loop
 // Combine a value over the four 16-lane rows of a wave with gfx950's v_permlane16_swap / v_permlane32_swap (one VALU
 // instruction per exchange; __shfl_xor compiles to ds_bpermute: 16 dependent LDS round trips per graph in the pooling tail).
@@ -481,13 +481,7 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
     const int row = u * 16 + pass * 4 + r4;
     unsigned a0, a1, a2, a3;
     if constexpr (!CSR) {
-      a0 = nb[pass].x & 0xffffu; a1 = nb[pass].x >> 16; a2 = nb[pass].y & 0xffffu; a3 = nb[pass].y >> 16;
-      unsigned t;                                      // ascending (empty sorts last)
-      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
-      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
-      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
-      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
-      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      a0 = nb[pass].x & 0xffffu; a1 = nb[pass].x >> 16; a2 = nb[pass].y & 0xffffu; a3 = nb[pass].y >> 16;   // (sorted by the row's dinv lane)
     } else {
       a0 = kb[pass] + 0 < ke[pass] ? L.col[kb[pass] + 0] : empty_id;
       a1 = kb[pass] + 1 < ke[pass] ? L.col[kb[pass] + 1] : empty_id;
@@ -539,8 +533,8 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
 // built to keep that chain short -- round 3, 18 600 -> ~? cycles per graph on the reference-sized batch:
 //   * neighbour SLOT TABLE instead of a CSR: one pass over the edges (slot = atomic in-degree counter; the first NSLOT
 //     sources of a target go to nbr[target][slot]) replaces count + scan + fill + sort and three of their four barriers;
-//     the slots' order depends on the atomics, so the reader SORTS the four ids in registers (summation stays "ascending
-//     neighbour id", bitwise run to run).  A graph with an in-degree above NSLOT (no molecule of the reference's data) takes
+//     the slots' order depends on the atomics, so the lane that computes a row's dinv SORTS its four ids in registers
+//     (summation stays "ascending neighbour id", bitwise run to run).  A graph with an in-degree above NSLOT (no molecule of the reference's data) takes
 //     the CSR route for that graph -- the counters already hold the in-degrees.
 //   * aggregation (mid_agg_unit): the index words of a unit's four passes are read in ONE round trip (the CSR went through
 //     rowptr -> col -> rows once per pass), empty slots name an all-zero row (no branches), packed f32 math.
@@ -642,6 +636,16 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
     if (wblk < gcur.nblk && lane < 32) {
       const int i = wblk * 32 + lane;
       L.dinv[i] = i < gcur.n ? 1.0f / sqrtf(1.0f + (float)L.cursor[i]) : 0.f;
+      // the row's slots, filled in the order the atomics ran, sorted ONCE here by the row's own lane (in the aggregation the
+      // 16 lanes of a row would each repeat the network: 10 VALU per pass): ascending ids, empty (= npad) last
+      const uint2 nb = *reinterpret_cast<const uint2*>(L.nbr + i * NSLOT);
+      unsigned a0 = nb.x & 0xffffu, a1 = nb.x >> 16, a2 = nb.y & 0xffffu, a3 = nb.y >> 16, t;
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      *reinterpret_cast<uint2*>(L.nbr + i * NSLOT) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
     }
     if (csr_route) {        // some in-degree > NSLOT: CSR of the graph (the counters hold the row sizes), rows sorted by id
       if (tid < 64) csr_scan_rows(L, nrows);

@@ -356,11 +356,13 @@ __device__ __forceinline__ SegGraph seg_graph(int g, const int32_t* __restrict__
   gi.n = graph_ptr[g + 1] - gi.nbase;
   gi.ebase = edge_ptr[g];
   gi.ne = edge_ptr[g + 1] - gi.ebase;
-  if (gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > SEG_MAX_EDGES) {     // host metadata was wrong: refuse the graph
-    if (threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
-    gi.n = 0;
-    gi.ne = 0;
-  }
+  // host metadata that does not fit: the graph is refused and reported.  The selects stay OUTSIDE the reporting thread's
+  // branch (assigned inside it, n and ne became per-lane registers and every address derived from them a 64-bit vector
+  // computation -- mid.hip, round 3)
+  const bool bad = gi.n < 0 || gi.n > npad || gi.ne < 0 || gi.ne > SEG_MAX_EDGES;
+  gi.n = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.n);
+  gi.ne = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.ne);
+  if (bad && threadIdx.x == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
   gi.nld = gi.n > 0 ? gi.nbase : 0;     // base of clamped loads (an empty graph at the end of the batch has nbase == N)
   return gi;
 }
@@ -368,11 +370,16 @@ __device__ __forceinline__ SegGraph seg_graph(int g, const int32_t* __restrict__
 struct SegEdge {       // this thread's edge of the graph (loads only: unconditional, clamped)
   long long s, d;
   __device__ __forceinline__ void load(const SegGraph& gi, const int64_t* __restrict__ ei, int64_t E) {
+    // (workgroup-uniform bases + one unsigned 32-bit byte offset: the scalar-base form of global_load; clamps are scalar work)
+    long long eb = gi.ebase;
+    eb = eb < 0 ? 0 : (eb > E - 1 ? E - 1 : eb);
+    const long long room = E - eb;
+    const int nec = (long long)gi.ne < room ? gi.ne : (int)room;
+    const int last = nec > 0 ? nec - 1 : 0;
     const int e = threadIdx.x;
-    int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
-    if (k > E - 1) k = E - 1;
-    s = ei[k];
-    d = ei[E + k];
+    const unsigned off = 8u * (unsigned)(e < last ? e : last);
+    s = *reinterpret_cast<const long long*>(reinterpret_cast<const char*>(ei + eb) + off);
+    d = *reinterpret_cast<const long long*>(reinterpret_cast<const char*>(ei + E + eb) + off);
   }
 };
 
@@ -382,12 +389,13 @@ struct SegRowsF {
   float4 v[SEG_RPT];
   __device__ __forceinline__ void load(const float* __restrict__ src, int F, const SegGraph& gi) {
     const int rg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
-    const float* base = src + (size_t)gi.nld * F + (4 * c4 < F ? 4 * c4 : F - 4);
+    const char* base = reinterpret_cast<const char*>(src + (size_t)gi.nld * F);     // (uniform base + 32-bit byte offsets)
+    const unsigned F4 = 4u * (unsigned)F, coff = 4u * (unsigned)(4 * c4 < F ? 4 * c4 : F - 4);
 #pragma unroll
     for (int j = 0; j < SEG_RPT; ++j) {
       if (j * 32 < gi.n) {
         const int row = rg + 32 * j;
-        v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * F);
+        v[j] = *reinterpret_cast<const float4*>(base + __umul24((unsigned)(row < gi.n ? row : gi.n - 1), F4) + coff);
       }
     }
   }
@@ -738,13 +746,19 @@ struct GS {
   struct Edges {       // this thread's edges of the graph (loads only: unconditional, clamped)
     long long s[EPT], d[EPT];
     __device__ __forceinline__ void load(const SegGraph& gi, const int64_t* __restrict__ ei, int64_t E) {
+      long long eb = gi.ebase;
+      eb = eb < 0 ? 0 : (eb > E - 1 ? E - 1 : eb);
+      const long long room = E - eb;
+      const int nec = (long long)gi.ne < room ? gi.ne : (int)room;
+      const int last = nec > 0 ? nec - 1 : 0;
+      const char* sb = reinterpret_cast<const char*>(ei + eb);
+      const char* db = reinterpret_cast<const char*>(ei + E + eb);
 #pragma unroll
       for (int j = 0; j < EPT; ++j) {
         const int e = threadIdx.x + j * NT;
-        int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
-        if (k > E - 1) k = E - 1;
-        s[j] = ei[k];
-        d[j] = ei[E + k];
+        const unsigned off = 8u * (unsigned)(e < last ? e : last);
+        s[j] = *reinterpret_cast<const long long*>(sb + off);
+        d[j] = *reinterpret_cast<const long long*>(db + off);
       }
     }
   };
@@ -753,12 +767,13 @@ struct GS {
     float4 v[RPT];
     __device__ __forceinline__ void load(const float* __restrict__ src, const SegGraph& gi, int ld) {
       const int rg = threadIdx.x / LPR, c4 = threadIdx.x % LPR;
-      const float* base = src + (size_t)gi.nld * ld + 4 * c4;
+      const char* base = reinterpret_cast<const char*>(src + (size_t)gi.nld * ld);     // (uniform base + 32-bit byte offsets)
+      const unsigned ld4 = 4u * (unsigned)ld;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
         if (j * RPP < gi.n) {                     // block-uniform guard, clamped address: no per-lane branch around the load
           const int row = rg + RPP * j;
-          v[j] = *reinterpret_cast<const float4*>(base + (size_t)(row < gi.n ? row : gi.n - 1) * ld);
+          v[j] = *reinterpret_cast<const float4*>(base + __umul24((unsigned)(row < gi.n ? row : gi.n - 1), ld4) + 16u * (unsigned)c4);
         }
       }
     }
