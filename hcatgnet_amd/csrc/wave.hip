@@ -68,11 +68,12 @@ __device__ __forceinline__ WGraph w_graph(int g, int B, const int32_t* __restric
   gi.n = graph_ptr[g + 1] - gi.nbase;
   gi.ebase = edge_ptr[g];
   gi.ne = edge_ptr[g + 1] - gi.ebase;
-  if (gi.n < 0 || gi.n > WN || gi.ne < 0 || gi.ne > WE) {     // host metadata was wrong: refuse the graph
-    if (lane == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
-    gi.n = 0;
-    gi.ne = 0;
-  }
+  // host metadata was wrong: the graph is refused and reported.  (The selects stay OUTSIDE the reporting lane's branch:
+  // assigned inside it, n and ne became per-lane registers and every address derived from them a 64-bit vector computation.)
+  const bool bad = gi.n < 0 || gi.n > WN || gi.ne < 0 || gi.ne > WE;
+  gi.n = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.n);
+  gi.ne = __builtin_amdgcn_readfirstlane(bad ? 0 : gi.ne);
+  if (bad && lane == 0) atomicOr(status, HCG_STATUS_SHAPE_LIMIT);
   gi.nblk = (gi.n + 31) / 32;
   gi.nld = gi.n > 0 ? gi.nbase : 0;
   return gi;
@@ -95,13 +96,20 @@ __device__ __forceinline__ WGraph w_uniform(const WGraph& a) {
 struct WEdges {   // loads only (unconditional, clamped): consumed one graph later
   long long s[WEPT], d[WEPT];
   __device__ __forceinline__ void load(const WGraph& gi, const int64_t* __restrict__ ei, int64_t E, int lane) {
+    // (wave-uniform bases + one unsigned 32-bit byte offset per slot: the scalar-base form of global_load; clamps are scalar)
+    long long eb = gi.ebase;
+    eb = eb < 0 ? 0 : (eb > E - 1 ? E - 1 : eb);
+    const long long room = E - eb;
+    const int nec = (long long)gi.ne < room ? gi.ne : (int)room;
+    const int last = nec > 0 ? nec - 1 : 0;
+    const char* sb = reinterpret_cast<const char*>(ei + eb);
+    const char* db = reinterpret_cast<const char*>(ei + E + eb);
 #pragma unroll
     for (int j = 0; j < WEPT; ++j) {
       const int e = lane + 64 * j;
-      int64_t k = (int64_t)gi.ebase + (e < gi.ne ? e : (gi.ne > 0 ? gi.ne - 1 : 0));
-      if (k > E - 1) k = E - 1;
-      s[j] = ei[k];
-      d[j] = ei[E + k];
+      const unsigned off = 8u * (unsigned)(e < last ? e : last);
+      s[j] = *reinterpret_cast<const long long*>(sb + off);
+      d[j] = *reinterpret_cast<const long long*>(db + off);
     }
   }
 };
@@ -219,12 +227,15 @@ __device__ __forceinline__ void w_stage_rows(float* t, const float* __restrict__
     constexpr int PER_ROW = KPAD / 4;                 // float4 per row: 16 (8)
     constexpr int RPP = 64 / PER_ROW;                 // rows per pass: 4 (8)
     const int c4 = lane % PER_ROW, r0 = lane / PER_ROW;
+    const char* gb = reinterpret_cast<const char*>(g + (size_t)(n > 0 ? nbase : 0) * F);   // (wave-uniform base + 32-bit byte offsets)
+    const unsigned F4 = 4u * (unsigned)F;
+    const int nlast = n > 0 ? n - 1 : 0;
     for (int base = 0; base < rows; base += 8 * RPP) {     // 32 (64) rows per batch of 8 loads
       float4 v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int row = base + j * RPP + r0;
-        v[j] = *reinterpret_cast<const float4*>(g + (size_t)(nbase + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + 4 * c4);
+        v[j] = *reinterpret_cast<const float4*>(gb + __umul24((unsigned)(row < nlast ? row : nlast), F4) + 16u * (unsigned)c4);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -248,10 +259,13 @@ struct WRowsAhead {
   float4 v[8];
   __device__ __forceinline__ void load(const float* __restrict__ g, int F, int nbase, int n, int base, int lane) {
     const int c4 = lane % PER_ROW, r0 = lane / PER_ROW;
+    const char* gb = reinterpret_cast<const char*>(g + (size_t)(n > 0 ? nbase : 0) * F);   // (wave-uniform base + 32-bit byte offsets)
+    const unsigned F4 = 4u * (unsigned)F;
+    const int nlast = n > 0 ? n - 1 : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = base + j * RPP + r0;
-      v[j] = *reinterpret_cast<const float4*>(g + (size_t)(nbase + (row < n ? row : (n > 0 ? n - 1 : 0))) * F + 4 * c4);
+      v[j] = *reinterpret_cast<const float4*>(gb + __umul24((unsigned)(row < nlast ? row : nlast), F4) + 16u * (unsigned)c4);
     }
   }
   __device__ __forceinline__ void write(float* t, int n, int rows, int base, int lane) const {
