@@ -401,6 +401,66 @@ struct XRows {
 };
 
 
+// The backward's x rows, requested while the transpose sum runs (its own iteration: the x tile shares t0 with dY', so the
+// rows wait in registers) -- float4 slots for every width: F == KPAD and 16-byte aligned rows: one float4 load per slot,
+// otherwise four dword loads (clamped columns, zeroed on the way into the tile).  Loads only, unconditional, on a
+// workgroup-uniform base; the scalar staging loop it replaces for F = 25 was eight dependent HBM round trips per graph (5 of
+// the layer-1 backward's 9.5 us at the reference's batch size 40).
+template <int KPAD, int NR>
+struct XRows4 {
+  static constexpr int PER_ROW = KPAD / 4, RSTEP = MT / PER_ROW, NJ = (NR + RSTEP - 1) / RSTEP;
+  float4 v[NJ];
+  __device__ __forceinline__ void load(const float* __restrict__ g, int F, bool vec, const GraphInfo& gi) {
+    const int nlast = gi.n > 0 ? gi.n - 1 : 0;
+    const char* base = reinterpret_cast<const char*>(g + (size_t)(gi.n > 0 ? gi.nbase : 0) * F);
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));
+    const int row0 = t0 / PER_ROW, c = t0 % PER_ROW;
+    const unsigned F4 = 4u * (unsigned)F;
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = row0 + j * RSTEP;
+        if (j * RSTEP < gi.nblk * 32)
+          v[j] = *reinterpret_cast<const float4*>(base + __umul24((unsigned)(row < nlast ? row : nlast), F4) + 16u * (unsigned)c);
+      }
+    } else {
+      unsigned co[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) co[i] = 4u * (unsigned)(4 * c + i < F ? 4 * c + i : F - 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = row0 + j * RSTEP;
+        if (j * RSTEP < gi.nblk * 32) {            // (workgroup-uniform: no per-lane branch around the loads)
+          const char* rp = base + __umul24((unsigned)(row < nlast ? row : nlast), F4);
+          v[j].x = *reinterpret_cast<const float*>(rp + co[0]);
+          v[j].y = *reinterpret_cast<const float*>(rp + co[1]);
+          v[j].z = *reinterpret_cast<const float*>(rp + co[2]);
+          v[j].w = *reinterpret_cast<const float*>(rp + co[3]);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void write(float* t, int F, const GraphInfo& gi) const {
+    const int nrows = gi.nblk * 32;
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));
+    const int row0 = t0 / PER_ROW, c = t0 % PER_ROW;
+    float* at = t + row0 * HS + 4 * c;
+    const bool k0 = 4 * c < F, k1 = 4 * c + 1 < F, k2 = 4 * c + 2 < F, k3 = 4 * c + 3 < F;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = row0 + j * RSTEP;
+      const bool inside = RSTEP <= 32 ? j * RSTEP < nrows : row < nrows;
+      if (inside) {
+        const bool live = row < gi.n;
+        *reinterpret_cast<float4*>(at + j * RSTEP * HS) = make_float4(live && k0 ? v[j].x : 0.f, live && k1 ? v[j].y : 0.f,
+                                                                      live && k2 ? v[j].z : 0.f, live && k3 ? v[j].w : 0.f);
+      }
+    }
+  }
+};
+
 // Aggregation + epilogue of one unit of 16 rows by one wave: 16 lanes x float4 per row, 4 rows per pass (packed f32 math:
 // v_pk_add / v_pk_fma / v_pk_mul -- these kernels are bound by VALU issue).  The four passes' index words and dinv are read
 // up front in ONE LDS round trip; each pass then issues its five row reads together.
@@ -558,6 +618,19 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  // the FIRST graph's scalars, edges and x rows are requested before anything else: they are in flight while the weight
+  // image is staged (at the reference's batch size 40 a launch is one graph long: serialised, weights -> scalars -> rows
+  // were three exposed round trips in front of the first instruction of the graph)
+  // (the grid never exceeds B: every workgroup has a first graph; past its last graph a workgroup requests the batch's
+  //  last graph again and drops it -- the prefetches are unconditional)
+  const int G = (int)gridDim.x;
+  GraphInfo gi = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
+  EdgeRegs er;
+  XRows<KPAD, VEC, MULTIK ? 32 : NR> xr;
+  er.load(gi, ei, E);
+  if constexpr (!MULTIK) xr.load(x, F, gi);
+  int raw_next = graph_raw(min((int)blockIdx.x + G, B - 1), graph_ptr, edge_ptr);
+
   // the weight image(s) are loop invariant: staged ONCE per workgroup, every K-chunk's image resident (MULTIK: two images,
   // 55 KB -- these kernels run one workgroup per CU anyway; re-staging a chunk's image per graph cost 8 global loads, 24
   // splits and 24 ds_write_b16 per thread and graph)
@@ -581,15 +654,6 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
   if (tid == 0) L.flag[0] = 0;
   __syncthreads();
 
-  // (the grid never exceeds B: every workgroup has a first graph; past its last graph a workgroup requests the batch's
-  //  last graph again and drops it -- the prefetches are unconditional)
-  const int G = (int)gridDim.x;
-  GraphInfo gi = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
-  EdgeRegs er;
-  XRows<KPAD, VEC, MULTIK ? 32 : NR> xr;
-  er.load(gi, ei, E);
-  if constexpr (!MULTIK) xr.load(x, F, gi);
-  int raw_next = graph_raw(min((int)blockIdx.x + G, B - 1), graph_ptr, edge_ptr);
   int mstamp_it = 0, rot = 0;
   (void)mstamp_it;
   for (int g = blockIdx.x; g < B; g += G, rot += 3) {
@@ -799,7 +863,17 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   const bool act_here = apply_act & 1, premask = NEEDS_DX && (apply_act & 2);
   const bool need_a = POOLG || act_here;
 
+  // the first graph's scalars and edges are requested before the weight image is staged (one exposed round trip less at the
+  // reference's batch size, where a launch is one graph long)
+  GraphInfo gnext;
+  EdgeRegs er;
+  if ((int)blockIdx.x < B) {
+    gnext = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
+    er.load(gnext, ei, E);
+  }
   if (NEEDS_DX && NFC == 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F);   // image row f, column d <- W[d][f]
+  const bool xvec = F == KPAD && ((uintptr_t)x % 16 == 0);
+  csr_counters_clear(L, npad, reinterpret_cast<int*>(L.red));
   __syncthreads();
 
   // dW: per f-chunk 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every
@@ -814,43 +888,46 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
     for (int i = 0; i < 16; ++i) dw[fc][i] = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  csr_counters_clear(L, npad, reinterpret_cast<int*>(L.red));
-  __syncthreads();
-  GraphInfo gnext;
-  EdgeRegs er;
-  if ((int)blockIdx.x < B) {
-    gnext = graph_info(blockIdx.x, graph_ptr, edge_ptr, npad, emax, status);
-    er.load(gnext, ei, E);
-  }
+  XRows4<KPAD, MID_MAX_NODES> xr;
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const GraphInfo gi = gnext;
+    const int rows = gi.nblk * 32;
+    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
+    //         this thread's rows (row group rg, float4 column group c4): every global load of the graph is requested HERE, in
+    //         front of the CSR build (they depend on the graph's scalars only; behind the build they were an exposed round trip
+    //         per graph), workgroup-uniform base + 32-bit byte offsets
+    constexpr int NR = MID_MAX_NODES / (MT / 16);
+    float4 av[NR] = {}, dv[NR];
+    {
+      const size_t gbase = (size_t)(gi.n > 0 ? gi.nbase : 0) * ldo + coff;
+      const char* ab = reinterpret_cast<const char*>(a_out + gbase);
+      const char* db = reinterpret_cast<const char*>(dout + gbase);
+      const unsigned ld4 = 4u * (unsigned)ldo;
+      const int nlast = gi.n > 0 ? gi.n - 1 : 0;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int row = rg + j * (MT / 16);
+        if (j * (MT / 16) < rows) {                          // block-uniform
+          const unsigned at = __umul24((unsigned)(row < nlast ? row : nlast), ld4) + 16u * (unsigned)c4;
+          if (need_a) av[j] = *reinterpret_cast<const float4*>(ab + at);   // (kernel-uniform)
+          if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(db + at);
+        }
+      }
+    }
+    float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx, dmx = gmx;
+    if (POOLG) {
+      const size_t eb = (size_t)g * 2 * ldo + coff + 4 * c4;       // [max | mean], each ldo wide
+      gmx = *reinterpret_cast<const float4*>(emb + eb);
+      dmx = *reinterpret_cast<const float4*>(demb + eb);
+      dmean = *reinterpret_cast<const float4*>(demb + eb + ldo);
+    }
     csr_count_scan_fill<true>(L, gi, er, status, reinterpret_cast<int*>(L.red));
     csr_sort_rows(L, gi);
-    const int rows = gi.nblk * 32;
     if (g + (int)gridDim.x < B) {                          // the NEXT graph's scalars and edges: in flight for the whole graph
       gnext = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
       er.load(gnext, ei, E);
     }
-
-    // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
-    //         this thread's rows (row group rg, float4 column group c4): all global loads first, used by both passes
-    constexpr int NR = MID_MAX_NODES / (MT / 16);
-    float4 av[NR] = {}, dv[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int row = rg + j * (MT / 16);
-      if (j * (MT / 16) < rows) {                          // block-uniform
-        const size_t at = (size_t)((gi.n > 0 ? gi.nbase : 0) + (row < gi.n ? row : (gi.n > 0 ? gi.n - 1 : 0))) * ldo + coff + 4 * c4;
-        if (need_a) av[j] = *reinterpret_cast<const float4*>(a_out + at);   // (kernel-uniform)
-        if (!POOLG) dv[j] = *reinterpret_cast<const float4*>(dout + at);
-      }
-    }
-    float4 gmx = make_float4(0.f, 0.f, 0.f, 0.f), share = gmx, dmean = gmx;
     if (POOLG) {
-      const size_t eb = (size_t)g * 2 * ldo + coff + 4 * c4;       // [max | mean], each ldo wide
-      gmx = *reinterpret_cast<const float4*>(emb + eb);
-      const float4 dmx = *reinterpret_cast<const float4*>(demb + eb);
-      dmean = *reinterpret_cast<const float4*>(demb + eb + ldo);
       const float cntf = (float)(gi.n > 0 ? gi.n : 1);
       dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -899,6 +976,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       }
     }
     __syncthreads();
+    if constexpr (NFC == 1) xr.load(x, F, xvec, gi);      // the x rows (step 3) land while the transpose sum runs
 
     // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1
     for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
@@ -917,7 +995,8 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
 #pragma unroll
     for (int fc = 0; fc < NFC; ++fc) {
       // ---- 3. x chunk -> t0 (and, chunked, the matching rows of the dx operand image)
-      stage_graph_rows<KPAD, true>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
+      if constexpr (NFC == 1) xr.write(L.t0, F, gi);
+      else stage_graph_rows<KPAD, true>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
       if (NEEDS_DX && NFC > 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F, fc * KPAD);
       __syncthreads();
 
