@@ -56,7 +56,7 @@ struct MidLds {   // carved out of dynamic shared memory by carve()
 
 __host__ __device__ inline size_t mid_lds_bytes(int npad, int emax, int wl_rows, int wl_k, bool two_tiles) {
   size_t b = (size_t)npad * HS * 4 * (two_tiles ? 2 : 1);
-  if (!two_tiles) b += (size_t)HS * 4;         // the zero row
+  b += (size_t)HS * 4;                         // the all-zero row behind the tile(s)
   b += (size_t)3 * wl_rows * (wl_k + WPAD) * 2;
   b = (b + 15) / 16 * 16;
   b += (size_t)(npad + 1 + 3) / 4 * 16;       // rowptr
@@ -75,7 +75,7 @@ __device__ __forceinline__ MidLds carve(char* base, int npad, int emax, int wl_r
   L.t0 = reinterpret_cast<float*>(base);
   off += (unsigned)npad * HS * 4;
   L.t1 = two_tiles ? reinterpret_cast<float*>(base + off) : nullptr;
-  off += two_tiles ? (unsigned)npad * HS * 4 : (unsigned)HS * 4;      // (one tile: row npad of t0 = the zero row)
+  off += (two_tiles ? (unsigned)npad * HS * 4 : 0u) + (unsigned)HS * 4;   // + the zero row: row npad (one tile) / 2 npad (two) of t0
   L.wl = reinterpret_cast<short*>(base + off);
   off += 3u * wl_rows * (wl_k + WPAD) * 2;
   off = (off + 15u) / 16u * 16u;
@@ -508,7 +508,9 @@ __device__ __forceinline__ Quad ldq(const char* p) {
   return q;
 }
 
-template <bool CSR, bool POOL>
+// TO_TILE (the backward's transpose sum): dH_row = dinv_row * sum goes to the second tile `t1` for EVERY row of the unit
+// (rows past the graph are zero), no epilogue.
+template <bool CSR, bool POOL, bool TO_TILE = false>
 __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsigned empty_id, const Quad& bq, float slope_eff,
                                              float* __restrict__ out_graph, int ldo, Quad& pmax, Quad& psum) {
   const int lane = threadIdx.x & 63, q = lane & 15, r4 = lane >> 4;
@@ -564,6 +566,11 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
       }
     }
     const f32x2 d2 = f32x2{di[pass], di[pass]}, s2 = f32x2{slope_eff, slope_eff};
+    if constexpr (TO_TILE) {
+      const f32x2 lo = d2 * acc.lo, hi = d2 * acc.hi;
+      *reinterpret_cast<float4*>(L.t1 + row * HS + 4 * q) = make_float4(lo.x, lo.y, hi.x, hi.y);
+      continue;
+    }
     Quad y;
     y.lo = __builtin_elementwise_fma(d2, acc.lo, bq.lo);
     y.hi = __builtin_elementwise_fma(d2, acc.hi, bq.hi);
@@ -873,7 +880,11 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   }
   if (NEEDS_DX && NFC == 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F);   // image row f, column d <- W[d][f]
   const bool xvec = F == KPAD && ((uintptr_t)x % 16 == 0);
+  const unsigned empty_id = 2u * (unsigned)npad;       // an empty slot names the all-zero row behind the two tiles
   csr_counters_clear(L, npad, reinterpret_cast<int*>(L.red));
+  for (int i = tid; i < npad * NSLOT / 2; i += MT) reinterpret_cast<unsigned*>(L.nbr)[i] = empty_id | (empty_id << 16);
+  if (tid < HS) L.t0[2 * npad * HS + tid] = 0.f;
+  if (tid == 0) L.flag[0] = 0;
   __syncthreads();
 
   // dW: per f-chunk 2 x NBF output blocks (d-block mbw x f-block nbw), each shared by NPART waves that take every
@@ -889,7 +900,10 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   XRows4<KPAD, MID_MAX_NODES> xr;
+  int mstamp_it = 0;
+  (void)mstamp_it;
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    MSTAMP(0);
     const GraphInfo gi = gnext;
     const int rows = gi.nblk * 32;
     // ---- 1. dY' = dinv (.) dA (.) leaky'(A) -> t0 (rows >= n zero)
@@ -921,15 +935,40 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       dmx = *reinterpret_cast<const float4*>(demb + eb);
       dmean = *reinterpret_cast<const float4*>(demb + eb + ldo);
     }
-    csr_count_scan_fill<true>(L, gi, er, status, reinterpret_cast<int*>(L.red));
-    csr_sort_rows(L, gi);
-    if (g + (int)gridDim.x < B) {                          // the NEXT graph's scalars and edges: in flight for the whole graph
-      gnext = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
-      er.load(gnext, ei, E);
+    MSTAMP(1);
+    // ---- the graph's edges -> out-degree counters + slot table of the TRANSPOSE (row = source, slots = its targets) and
+    //      in-degree counters (dinv); one pass, as in the forward.  A graph with an out-degree above NSLOT takes the CSR route.
+    int* degin = reinterpret_cast<int*>(L.red);
+    unsigned short es[EPT], ed[EPT];
+    {
+      bool bad = false, over = false;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * MT;
+        es[j] = 0xffff;
+        ed[j] = 0xffff;
+        if (e < gi.ne) {
+          const long long sv = er.s[j], dv2 = er.d[j];
+          const unsigned sl = (unsigned)((int)sv - gi.nbase), dl = (unsigned)((int)dv2 - gi.nbase);
+          const bool ok = sl < (unsigned)gi.n && dl < (unsigned)gi.n && (sv >> 31) == 0 && (dv2 >> 31) == 0;
+          bad |= !ok;
+          if (ok && sl != dl) {
+            es[j] = (unsigned short)sl;
+            ed[j] = (unsigned short)dl;
+            const int slot = atomicAdd(&L.cursor[sl], 1);
+            if (slot < NSLOT) L.nbr[sl * NSLOT + slot] = (unsigned short)dl;
+            else over = true;
+            atomicAdd(&degin[dl], 1);
+          }
+        }
+      }
+      if (__ballot(bad) != 0ull && lane == 0) atomicOr(status, HCG_STATUS_EDGE_UNGROUPED);
+      if (__ballot(over) != 0ull && lane == 0) L.flag[0] = 1;
     }
+    // (POOLG) this thread's tie counts over its rows -> the wave's four row groups -> one partial per wave (the column maxima
+    // and the rows were requested above: they have been in flight for the whole pass over the edges)
+    float* tiesc = L.red + 256;                           // [MW][64] behind the in-degree counters
     if (POOLG) {
-      const float cntf = (float)(gi.n > 0 ? gi.n : 1);
-      dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
       float4 ties = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -939,18 +978,59 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
           ties.x += (a.x == gmx.x); ties.y += (a.y == gmx.y); ties.z += (a.z == gmx.z); ties.w += (a.w == gmx.w);
         }
       }
-      float* sc = L.t1;                                  // [MT / 16 row groups][64] scratch (t1 is free here)
-      *reinterpret_cast<float4*>(sc + rg * DD + 4 * c4) = ties;
+      ties = make_float4(rows_sum(ties.x), rows_sum(ties.y), rows_sum(ties.z), rows_sum(ties.w));   // (counts: exact in any order)
+      if (r4 == 0) *reinterpret_cast<float4*>(tiesc + wave * DD + 4 * q) = ties;
+    }
+    __syncthreads();
+    MSTAMP(2);
+    const bool csr_route = __builtin_amdgcn_readfirstlane(L.flag[0]) != 0;
+    // one thread per row (waves 1..: wave 0 is the scan wave of the CSR route): dinv, the counter back to zero, slots sorted
+    if (tid >= 64 && tid - 64 < rows) {
+      const int i = tid - 64;
+      L.dinv[i] = i < gi.n ? 1.0f / sqrtf(1.0f + (float)degin[i]) : 0.f;
+      degin[i] = 0;
+      const uint2 nb = *reinterpret_cast<const uint2*>(L.nbr + i * NSLOT);
+      unsigned a0 = nb.x & 0xffffu, a1 = nb.x >> 16, a2 = nb.y & 0xffffu, a3 = nb.y >> 16, t;
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      *reinterpret_cast<uint2*>(L.nbr + i * NSLOT) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+    }
+    if (csr_route) {
+      if (tid < 64) csr_scan_rows(L, rows);
       __syncthreads();
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        if (es[j] != 0xffff) {
+          const int left = atomicSub(&L.cursor[es[j]], 1);           // counts the row back down to zero
+          L.col[L.rowptr[es[j]] + left - 1] = ed[j];
+        }
+      }
+      __syncthreads();
+      csr_sort_rows(L, gi);                                          // (ends with a barrier)
+    } else {
+      __syncthreads();                                               // dinv and the wave partials of the tie counts are visible
+    }
+    MSTAMP(3);
+    if (tid == 0) L.flag[0] = 0;                           // (every thread read it before the barrier above)
+    if (g + (int)gridDim.x < B) {                          // the NEXT graph's scalars and edges: in flight for the whole graph
+      gnext = graph_info(g + gridDim.x, graph_ptr, edge_ptr, npad, emax, status);
+      er.load(gnext, ei, E);
+    }
+    if (POOLG) {
+      const float cntf = (float)(gi.n > 0 ? gi.n : 1);
+      dmean = make_float4(dmean.x / cntf, dmean.y / cntf, dmean.z / cntf, dmean.w / cntf);
       float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int k = 0; k < MT / 16; ++k) {
-        const float4 t = *reinterpret_cast<const float4*>(sc + k * DD + 4 * c4);
+      for (int w = 0; w < MW; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(tiesc + w * DD + 4 * c4);
         tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
       }
       share = make_float4(dmx.x / fmaxf(tot.x, 1.f), dmx.y / fmaxf(tot.y, 1.f), dmx.z / fmaxf(tot.z, 1.f), dmx.w / fmaxf(tot.w, 1.f));
-      __syncthreads();                                   // scratch reads done before step 2 writes t1
     }
+    MSTAMP(4);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int row = rg + j * (MT / 16);
@@ -976,21 +1056,22 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       }
     }
     __syncthreads();
+    MSTAMP(5);
     if constexpr (NFC == 1) xr.load(x, F, xvec, gi);      // the x rows (step 3) land while the transpose sum runs
 
-    // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1
-    for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
-#pragma unroll 2
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = u * 16 + pass * 4 + r4;
-        const bool valid = row < gi.n;
-        const int kb = valid ? L.rowptr[row] : 0, ke = valid ? L.rowptr[row + 1] : 0;
-        const float4 acc = mid_row_sum(L.t0, L.col, row, kb, ke, q);
-        const float di = L.dinv[row];
-        *reinterpret_cast<float4*>(L.t1 + row * HS + 4 * q) = make_float4(di * acc.x, di * acc.y, di * acc.z, di * acc.w);
+    // ---- 2. dH_j = dinv_j (dY'_j + sum_{k in row j of the transpose} dY'_{col k}) -> t1 (mid_agg_unit: slot table / CSR route;
+    //         its lanes also reset the rows' slots and counters for the next graph)
+    {
+      Quad z0, z1, z2;
+      z0.lo = z0.hi = z1.lo = z1.hi = z2.lo = z2.hi = f32x2{0.f, 0.f};
+      for (int u = wave; u < gi.nblk * 2; u += MW) {      // units of 16 rows
+        if (!csr_route) mid_agg_unit<false, false, true>(L, u, gi.n, empty_id, z0, 1.0f, nullptr, 0, z1, z2);
+        else mid_agg_unit<true, false, true>(L, u, gi.n, empty_id, z0, 1.0f, nullptr, 0, z1, z2);
       }
     }
+    MSTAMP(6);
     __syncthreads();
+    MSTAMP(7);
 
 #pragma unroll
     for (int fc = 0; fc < NFC; ++fc) {
@@ -999,6 +1080,7 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
       else stage_graph_rows<KPAD, true>(L.t0, x, F, fc * KPAD, gi.nbase, gi.n, gi.nblk);
       if (NEEDS_DX && NFC > 1) stage_weight_split<true, MT, KPAD, DD>(L.wl, W, DD, F, fc * KPAD);
       __syncthreads();
+      MSTAMP(8);
 
       // ---- 4. dW[mbw][fc, nbw] += dH^T x over the graph's nodes (K = nodes, 16 per step); both operands read down columns
       for (int ks = part; ks < gi.nblk * 2; ks += NPART) {
@@ -1013,8 +1095,85 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
         mfma_split(dw[fc], A, Bx.p1, Bx.p2, Bx.p3);
       }
 
-      // ---- 5. dx[:, chunk] (+)= dH W[:, chunk], each wave on its own row blocks
-      if (NEEDS_DX) {
+      MSTAMP(9);
+      // ---- 5. dx[:, chunk] (+)= dH W[:, chunk], each wave on its own row blocks.  TRANSPOSED product (the operand image is
+      //         the MFMA's A operand, the dH rows its B operand): a lane holds one ROW of the block and a register quad four
+      //         consecutive columns, so premask reads, read-back and stores are 128-bit per quad (row-per-register they were 32
+      //         guarded dword stores with 64-bit addresses per block: 8 000 of the layer-2 backward's 25 000 cycles per graph)
+      if (NEEDS_DX && NFC == 1) {
+        const bool f4ok = (F & 3) == 0 && ((uintptr_t)dx % 16 == 0);
+        const int nlast = gi.n > 0 ? gi.n - 1 : 0;
+        // one 32 x 32 output block (row block mb, column block nb) per wave and round: all eight waves busy on a graph of up
+        // to 128 nodes (one wave per ROW block left five of eight idle for 5 900 cycles; the dH fragment is then split once per
+        // column block -- this kernel runs one workgroup per CU and has VALU slots to spare)
+        for (int b8 = wave; b8 < gi.nblk * NBF; b8 += MW) {
+          const int mb = b8 / NBF, nb = b8 % NBF;
+          const float* blk = L.t1 + mb * 32 * HS;
+          f32x16 v;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = 0.f;
+#pragma unroll
+          for (int s = 0; s < DD / 16; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h);
+            const float4 a1 = *reinterpret_cast<const float4*>(blk + r * HS + 16 * s + 8 * h + 4);
+            const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const Split3 X = split3(xa);
+            const short* w0 = L.wl + (nb * 32 + r) * ld + 16 * s + 8 * h;
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(w0), b2 = *reinterpret_cast<const bf16x8*>(w0 + plane),
+                         b3 = *reinterpret_cast<const bf16x8*>(w0 + 2 * plane);
+            v = HCG_MFMA(b1, X.p3, v);       // the six cross terms of mfma_split, operands swapped
+            v = HCG_MFMA(b3, X.p1, v);
+            v = HCG_MFMA(b2, X.p2, v);
+            v = HCG_MFMA(b1, X.p2, v);
+            v = HCG_MFMA(b2, X.p1, v);
+            v = HCG_MFMA(b1, X.p1, v);
+          }
+          mfma_results_fence(v);
+          const int row = mb * 32 + r;                      // this lane's row; quad g4: columns f0 .. f0 + 3
+          const bool live = row < gi.n;
+          float* drow = dx + (size_t)((gi.n > 0 ? gi.nbase : 0) + (row < nlast ? row : nlast)) * F;
+          if (premask) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 xv = *reinterpret_cast<const float4*>(L.t0 + row * HS + nb * 32 + 8 * g4 + 4 * h);
+              v[4 * g4] *= hcg_leaky_grad(xv.x, slope); v[4 * g4 + 1] *= hcg_leaky_grad(xv.y, slope);
+              v[4 * g4 + 2] *= hcg_leaky_grad(xv.z, slope); v[4 * g4 + 3] *= hcg_leaky_grad(xv.w, slope);
+            }
+          }
+          // second column half of a 128-wide layer (acc_dx): the first half's dx is read back -- the block's four quads
+          // requested TOGETHER, unconditionally (clamped row and columns), behind one kernel-uniform branch
+          if (acc_dx) {
+            float4 old[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const int f0 = nb * 32 + 8 * g4 + 4 * h;
+              if (f4ok) {
+                old[g4] = *reinterpret_cast<const float4*>(drow + (f0 + 3 < F ? f0 : F - 4));
+              } else {
+                old[g4] = make_float4(drow[f0 < F ? f0 : F - 1], drow[f0 + 1 < F ? f0 + 1 : F - 1], drow[f0 + 2 < F ? f0 + 2 : F - 1],
+                                      drow[f0 + 3 < F ? f0 + 3 : F - 1]);
+              }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) { v[4 * g4] += old[g4].x; v[4 * g4 + 1] += old[g4].y; v[4 * g4 + 2] += old[g4].z; v[4 * g4 + 3] += old[g4].w; }
+          }
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int f0 = nb * 32 + 8 * g4 + 4 * h;
+            if (live) {
+              if (f4ok) {
+                if (f0 + 3 < F) *reinterpret_cast<float4*>(drow + f0) = make_float4(v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]);
+              } else {
+                if (f0 < F) drow[f0] = v[4 * g4];
+                if (f0 + 1 < F) drow[f0 + 1] = v[4 * g4 + 1];
+                if (f0 + 2 < F) drow[f0 + 2] = v[4 * g4 + 2];
+                if (f0 + 3 < F) drow[f0 + 3] = v[4 * g4 + 3];
+              }
+            }
+          }
+        }
+      }
+      if (NEEDS_DX && NFC > 1) {   // (wide inputs, f-chunked: row-per-register form -- the transposed one spills 150+ registers beside two dW chunks)
         for (int mb = wave; mb < gi.nblk; mb += MW) {
           const float* blk = L.t1 + mb * 32 * HS;
           f32x16 dxa[NBF];
@@ -1068,8 +1227,13 @@ __global__ __launch_bounds__(MT, 2) void k_mid_layer_bwd(
           }
         }
       }
+      MSTAMP(10);
       __syncthreads();   // t0 / the operand image are free for the next chunk (or the next graph)
+      MSTAMP(11);
     }
+#ifdef HCG_MID_STAMP
+    ++mstamp_it;
+#endif
   }
 
   // ---- publish this workgroup's slab: dW [64][FPAD] | db [64]

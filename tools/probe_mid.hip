@@ -39,27 +39,50 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(db, bias.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dei, ei.data(), ei.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(dgp, gp.data(), (B + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dep, ep.data(), (B + 1) * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dstatus, 0, 16));
+  const bool bwd = argc > 2 && argv[2][0] == 'b';
+  float *da = nullptr, *ddx = nullptr, *dws = nullptr, *ddemb = nullptr;
+  size_t wsb = 0;
+  if (bwd) {   // pooled form for F = 64 (layer 2: demb / emb / a_out -> dx), dout form otherwise (layer 1: no dx)
+    wsb = hcg_mid_workspace_bytes(B, F, D, 117, 300);
+    CK(hipMalloc(&da, (size_t)N * D * 4)); CK(hipMalloc(&ddx, (size_t)N * F * 4)); CK(hipMalloc(&dws, wsb)); CK(hipMalloc(&ddemb, (size_t)B * 2 * D * 4));
+    CK(hipMemset(da, 0, (size_t)N * D * 4)); CK(hipMemset(ddemb, 0, (size_t)B * 2 * D * 4)); CK(hipMemset(demb, 0, (size_t)B * 2 * D * 4));
+    CK(hipMemset(dout, 0, (size_t)N * D * 4));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < 25; ++it) {
     if (it == 5) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
-    int rc = hcg_mid_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 1, dout, F == 64 ? demb : nullptr, dstatus, 0);
+    int rc;
+    if (!bwd) rc = hcg_mid_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 1, dout, F == 64 ? demb : nullptr, dstatus, 0);
+    else if (F == 64) rc = hcg_mid_layer_bwd(nullptr, ddemb, demb, da, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 3, ddx, dstatus, dws, wsb, 0);
+    else rc = hcg_mid_layer_bwd(dout, nullptr, nullptr, nullptr, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 0, nullptr, dstatus, dws, wsb, 0);
     if (rc) { printf("rc %d\n", rc); return 1; }
   }
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("mid forward (F = %d): %.2f us per launch\n", F, ms * 1000.f / 20);
+  printf("mid %s (F = %d): %.2f us per launch\n", bwd ? "backward" : "forward", F, ms * 1000.f / 20);
 #ifdef HCG_MID_STAMP
   static unsigned long long st[MW][4][16];
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mid_stamp), sizeof(st)));
-  const int idx[] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11};
-  const char* nm[] = {"", "count + slots + x write", "barrier", "dinv (+ CSR route)", "GEMM", "H' write", "barrier",
-                      "prefetch issue", "aggregate + store", "pool", "end barrier"};
-  for (int w : {0, 2, 5, 7})
-    for (int it = 0; it < 3; ++it) {
-      printf("wave %d graph %d:", w, it);
-      for (int i = 1; i < 11; ++i) printf(" %s %llu |", nm[i], st[w][it][idx[i]] - st[w][it][idx[i - 1]]);
-      printf(" total %llu\n", st[w][it][11] - st[w][it][0]);
-    }
+  if (!bwd) {
+    const int idx[] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11};
+    const char* nm[] = {"", "count + slots + x write", "barrier", "dinv (+ CSR route)", "GEMM", "H' write", "barrier",
+                        "prefetch issue", "aggregate + store", "pool", "end barrier"};
+    for (int w : {0, 2, 5, 7})
+      for (int it = 0; it < 3; ++it) {
+        printf("wave %d graph %d:", w, it);
+        for (int i = 1; i < 11; ++i) printf(" %s %llu |", nm[i], st[w][it][idx[i]] - st[w][it][idx[i - 1]]);
+        printf(" total %llu\n", st[w][it][11] - st[w][it][0]);
+      }
+  } else {
+    const char* nm[] = {"", "row loads issued", "count / scan / fill", "sort", "pool ties", "dY' tile + barrier", "transpose sum", "barrier",
+                        "x write + barrier", "dW k-loop", "dx GEMM + stores", "end barrier"};
+    for (int w : {0, 2, 5, 7})
+      for (int it = 0; it < 3; ++it) {
+        printf("wave %d graph %d:", w, it);
+        for (int i = 1; i < 12; ++i) printf(" %s %llu |", nm[i], st[w][it][i] - st[w][it][i - 1]);
+        printf(" total %llu\n", st[w][it][11] - st[w][it][0]);
+      }
+  }
 #endif
   return 0;
 }
