@@ -1315,7 +1315,10 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   if (B == 0 || N == 0) return HCG_OK;
   if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no graph has edges
-  if (hcg_w64_applicable(F, D, max_nodes, max_edges))   // graphs up to 64 nodes: one graph per WAVE (wave.hip)
+  // graphs up to 64 nodes: one graph per WAVE (wave.hip).  (Round 3 measured this kernel's rebuilt forward on them instead:
+  // equal at 4096 graphs of 37-63 atoms -- 49.5 / 47.2 against 49.5 / 48.0 us -- and 18.1 / 17.6 against 19.2 / 19.2 us on the
+  // 1 270 graphs of 33-36 atoms of the ragged batch, whose launches are one graph chain long either way.)
+  if (hcg_w64_applicable(F, D, max_nodes, max_edges))
     return hcg_w64_fwd_launch(x, W, b, edge_index, E, graph_ptr, edge_ptr, B, F, slope, apply_act, out, emb, status, stream);
   const int npad = pad32(max_nodes), emax = pad8(max_edges);
   const int kpad = F <= 32 ? 32 : 64;

@@ -32,6 +32,8 @@ CONFIGS = {
 # the reference's own regime (SURVEY 8 "Real data"): 56-184 atoms (mean 87), F = 25 (diene) -- not a BASELINE config
 CONFIGS["REAL"] = dict(num_graphs=4096, nodes=87, nodes_jitter=30, extra_bonds=4, max_degree=4, feat=25, hidden=64)
 CONFIGS["REAL40"] = dict(CONFIGS["REAL"], num_graphs=40)      # the reference's batch_size (options/base_options.py:269-274)
+# development: every graph in the one-graph-per-wave size class (37-63 atoms), the C3 widths -- not a BASELINE config
+CONFIGS["W50"] = dict(num_graphs=4096, nodes=50, nodes_jitter=13, extra_bonds=3, max_degree=4, feat=64, hidden=64)
 CONFIGS["C3"] = CONFIGS["C2"]
 CONFIGS["C4"] = CONFIGS["C2"]
 
