@@ -791,8 +791,11 @@ class StepWindow:
         for i, st in enumerate(steps): st.capture(batch_fn[i], next_plan=plans[(i + 1) % n])
         window = StepWindow(steps, batch_fn);  losses = window.replay()      # one launch = n steps"""
 
-    def __init__(self, steps, batches, forward_only: bool = False):
-        """`forward_only`: the steps' `evaluate` form (plan, conv stack, head: loss only, nothing reduced or updated)."""
+    def __init__(self, steps, batches, forward_only: bool = False, counts64=None):
+        """`forward_only`: the steps' `evaluate` form (plan, conv stack, head: loss only, nothing reduced or updated).
+        `counts64` (float64 [len(steps)], graphs per batch): the epoch sum dot(losses, counts) -- `_weighted_loss_sum`, the same
+        three operations -- and its copy into a pinned host scalar are recorded behind the last step, so reading an epoch's
+        value is one stream synchronisation (`value()`), not four launches and a blocking copy."""
         steps, batches = list(steps), list(batches)
         if not steps or len(steps) != len(batches):
             raise ValueError("StepWindow needs as many batches as steps (at least one)")
@@ -819,9 +822,23 @@ class StepWindow:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        self.value_host = None
+        if counts64 is not None:
+            self.value_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+            _weighted_loss_dev([counts64.new_zeros((), dtype=torch.float32) for _ in steps], counts64)   # (its kernels loaded before the capture)
+            self.value_host.copy_(counts64[:1], non_blocking=True)
+            torch.cuda.synchronize()
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.losses = [st(get(b), _forward_only=self.forward_only) for st, b in zip(steps, batches)]
+            if counts64 is not None:
+                self.value_dev = _weighted_loss_dev(self.losses, counts64)
+                self.value_host.copy_(self.value_dev.reshape(1), non_blocking=True)
         self._fp = [st._graph_fingerprint() for st in steps]
+
+    def value(self) -> float:
+        """dot(losses, counts64) of the last replay (needs `counts64`): waits for the current stream, reads the pinned scalar."""
+        torch.cuda.current_stream().synchronize()
+        return float(self.value_host[0])
 
     def replay(self):
         """-> the steps' loss tensors (device scalars, overwritten by the next replay)."""
@@ -934,7 +951,7 @@ class EpochWindow:
                 fl = opt._rebase(0, opt.param_groups[0])
         opt._make_dev_state(fl, opt.param_groups[0])
         saved = [fl["p"].clone(), fl["m"].clone(), fl["v"].clone(), fl["step_dev"].clone()]
-        self.window = StepWindow(self.steps, fns)
+        self.window = StepWindow(self.steps, fns, counts64=self.counts)
         fl2 = opt._flat.get(0)
         if fl2 is not fl:
             raise _lib.HcgError("EpochWindow: the optimiser re-based its state during the capture")
@@ -962,13 +979,20 @@ class EpochWindow:
         ld = self.loader
         return ld.rng.permutation(self.G) if ld.shuffle else np.arange(self.G)
 
-    def run_epoch(self, order=None) -> float:
-        """-> sum(loss_i * num_graphs_i) / len(dataset), the reference's `train_network` return value."""
+    def launch_epoch(self, order=None):
+        """Issue the epoch on the current stream (index upload + ONE graph launch), no synchronisation; `finish_epoch` reads
+        its value.  One epoch in flight per window (the pinned index buffer is rewritten by the next launch)."""
         if order is None:
             order = self.draw_order()
         self._layout(order)
-        losses = self.window.replay()
-        return _weighted_loss_sum(losses, self.counts) / self.G   # (the sync also keeps the pinned buffer from being rewritten too early)
+        return self.window.replay()
+
+    def finish_epoch(self, losses) -> float:
+        """-> sum(loss_i * num_graphs_i) / len(dataset), the reference's `train_network` return value (synchronises)."""
+        return self.window.value() / self.G        # (the sync also keeps the pinned index buffer from being rewritten too early)
+
+    def run_epoch(self, order=None) -> float:
+        return self.finish_epoch(self.launch_epoch(order))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -998,9 +1022,13 @@ class _EpochSum:
         return _weighted_loss_sum(self.vals, torch.tensor(self.ns, dtype=torch.float64, device=self.vals[0].device)) / denom
 
 
+def _weighted_loss_dev(losses, counts64):
+    return torch.dot(torch.stack([v.reshape(()) for v in losses]).double(), counts64)
+
+
 def _weighted_loss_sum(losses, counts64) -> float:
     """One synchronising read: dot(losses, counts) in float64."""
-    return float(torch.dot(torch.stack([v.reshape(()) for v in losses]).double(), counts64).item())
+    return float(_weighted_loss_dev(losses, counts64).item())
 
 
 def train_network(model, train_loader, device):
@@ -1035,9 +1063,10 @@ def train_network(model, train_loader, device):
 EPOCH_WINDOW = True      # train_network over a DeviceLoader: whole epochs as one hipGraph (EpochWindow); False = per-batch loop
 
 
-def _epoch_window(model, loader):
-    """-> the epoch's value through the loader's cached `EpochWindow` (built on first use; rebuilt when the model or the
-    optimiser's storages changed), or None when that form does not apply."""
+def _epoch_window_launch(model, loader):
+    """Issue one epoch through the loader's cached `EpochWindow` (built on first use; rebuilt when the model or the
+    optimiser's storages changed) on the current stream -> (window, losses) for `window.finish_epoch(losses)`, or None
+    when that form does not apply."""
     from .store import DeviceLoader
     if not (EPOCH_WINDOW and isinstance(loader, DeviceLoader) and hasattr(model.optimizer, "enable_capturable")):
         return None
@@ -1059,13 +1088,19 @@ def _epoch_window(model, loader):
         try:
             if order is None:
                 order = cache[1].draw_order()            # (drawn once: a rebuild must not skip a permutation)
-            return cache[1].run_epoch(order)
+            return cache[1], cache[1].launch_epoch(order)
         except _lib.HcgError:                 # parameters / optimiser re-based since the capture: build again
             try:
                 loader._hcg_epoch_window = None
             except Exception:
                 return None
     return None
+
+
+def _epoch_window(model, loader):
+    """-> the epoch's value through `_epoch_window_launch`, or None when that form does not apply."""
+    got = _epoch_window_launch(model, loader)
+    return None if got is None else got[0].finish_epoch(got[1])
 
 
 def dist_initialized_multi() -> bool:
@@ -1075,8 +1110,9 @@ def dist_initialized_multi() -> bool:
 EVAL_WINDOW_MAX_BATCHES = 64
 
 
-def _eval_window(model, loader, fused):
-    """A `store.DeviceLoader` that does not shuffle yields the same batches every epoch (the reference's validation / test
+def _eval_window(model, loader, fused, launch_only: bool = False):
+    """(`launch_only`: issue the graph on the current stream and return its window without synchronising: `window.value()`.)
+    A `store.DeviceLoader` that does not shuffle yields the same batches every epoch (the reference's validation / test
     loaders, call_methods.py:41-46): they are collated once, their `evaluate` steps captured as ONE hipGraph
     (`StepWindow(forward_only=True)`) and an `eval_network` call is one graph launch + one reduction instead of
     (collate + 3 launches) per batch.  -> the epoch's value, or None when this path does not apply (the caller loops)."""
@@ -1092,10 +1128,10 @@ def _eval_window(model, loader, fused):
                 return None
             try:
                 steps = [FusedTrainStep(model, optimizer_step=False) for _ in batches]
-                win = StepWindow(steps, batches, forward_only=True)
+                counts = torch.tensor([float(b.num_graphs) for b in batches], dtype=torch.float64, device=batches[0].x.device)
+                win = StepWindow(steps, batches, forward_only=True, counts64=counts)
             except (_lib.HcgError, RuntimeError):        # capture failed (memory, an unsupported launch): the per-batch loop runs
                 return None
-            counts = torch.tensor([float(b.num_graphs) for b in batches], dtype=torch.float64, device=batches[0].x.device)
             cache = {"model": model, "key": key, "window": win, "batches": batches, "counts": counts}
             try:
                 loader._hcg_eval_window = cache
@@ -1106,7 +1142,9 @@ def _eval_window(model, loader, fused):
         except _lib.HcgError:                 # parameters re-based since the capture (load_state_dict on new storages ...)
             cache = None
             continue
-        return _weighted_loss_sum(losses, cache["counts"]) / len(loader.dataset)
+        if launch_only:
+            return cache["window"]
+        return cache["window"].value() / len(loader.dataset)
     return None
 
 
@@ -1133,6 +1171,96 @@ def eval_network(model, loader, device):
                 loss = _rmse_autograd(model, batch)
             total.add(loss, batch.num_graphs)
     return total.value(len(loader.dataset))
+
+
+def _fused_of(model):
+    fused = getattr(model, "_hcg_train_step", None)
+    if fused is None:
+        fused = FusedTrainStep(model)
+        try:
+            model._hcg_train_step = fused
+        except Exception:
+            pass
+    return fused
+
+
+def _run_stream(model, device):
+    """The HIP stream of an independent run (one per model, made on first use)."""
+    st = getattr(model, "_hcg_run_stream", None)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        try:
+            model._hcg_run_stream = st
+        except Exception:
+            pass
+    return st
+
+
+def train_networks(models, train_loaders, device, active=None):
+    """One epoch of SEVERAL independent runs at once -> [train_network(model_k, loader_k, device) for every k] (None where
+    `active[k]` is false: a run that has stopped early).
+
+    The reference's nested cross-validation trains folds * (folds - 1) = 90 models one after another
+    (scripts_experiments/train_GNN.py:48-50), each on ~535 graphs in batches of 40 (options/base_options.py:269-274): a
+    batch of 40 graphs occupies 40 of the 256 CUs, so one run cannot fill the GPU whatever its kernels do.  The runs share
+    nothing (own model, own optimiser, own loaders), so here every run issues its epoch -- ONE hipGraph (`EpochWindow`) --
+    on its own HIP stream and the GPU overlaps them; the host synchronises once per run and epoch, after all of them are in
+    flight.  Each run's arithmetic is untouched: bitwise what `train_network` gives that run alone
+    (tests/test_gpu_train_step.py::test_concurrent_runs_equal_the_runs_one_by_one).  A run whose epoch does not fit the
+    one-graph form (a host loader, a layer on the dense row-streaming kernels) is trained by `train_network` in turn."""
+    K = len(models)
+    if len(train_loaders) != K or (active is not None and len(active) != K):
+        raise ValueError("train_networks: one loader (and one `active` flag) per model")
+    on = [bool(a) for a in active] if active is not None else [True] * K
+    out, flying = [None] * K, []
+    cur = torch.cuda.current_stream(device)
+    for k, (m, ld) in enumerate(zip(models, train_loaders)):
+        if not on[k]:
+            continue
+        m.train()
+        _fused_of(m)
+        st = _run_stream(m, device)
+        st.wait_stream(cur)                         # (whatever the caller did to this run's model on its own stream)
+        with torch.cuda.stream(st):
+            got = _epoch_window_launch(m, ld)
+        if got is None:
+            out[k] = train_network(m, ld, device)
+        else:
+            flying.append((k, st, got))
+    for k, st, (win, losses) in flying:
+        with torch.cuda.stream(st):
+            out[k] = win.finish_epoch(losses)
+        cur.wait_stream(st)
+    return out
+
+
+def eval_networks(models, loaders, device, active=None):
+    """`eval_network` of several independent runs at once (see `train_networks`): every run's evaluation epoch -- one
+    forward-only hipGraph over its fixed loader -- on the run's own stream.  -> [eval_network(model_k, loader_k, device)]."""
+    K = len(models)
+    if len(loaders) != K or (active is not None and len(active) != K):
+        raise ValueError("eval_networks: one loader (and one `active` flag) per model")
+    on = [bool(a) for a in active] if active is not None else [True] * K
+    out, flying = [None] * K, []
+    cur = torch.cuda.current_stream(device)
+    for k, (m, ld) in enumerate(zip(models, loaders)):
+        if not on[k]:
+            continue
+        m.eval()
+        fused = _fused_of(m)
+        st = _run_stream(m, device)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            got = _eval_window(m, ld, fused, launch_only=True)
+        if got is None:
+            out[k] = eval_network(m, ld, device)
+        else:
+            flying.append((k, st, got, len(ld.dataset)))
+    for k, st, win, n in flying:
+        with torch.cuda.stream(st):
+            out[k] = win.value() / n
+        cur.wait_stream(st)
+    return out
 
 
 def predict_network(model, loader, return_emb: bool = False, device=None):

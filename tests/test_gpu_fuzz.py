@@ -1,5 +1,6 @@
 """Random shapes around the kernels' own boundaries through whichever kernel family the host picks (tools/fuzz_families.py),
-one training step each, against the any-shape GPU path: fixed seeds, so the cases are the same on every run."""
+one training step each, against the any-shape GPU path AND the CPU oracle (outputs / pooled embedding <= 1e-5, every gradient
+<= 1e-4 of its fp64 value): fixed seeds, so the cases are the same on every run."""
 import importlib.util
 import os
 
@@ -16,11 +17,19 @@ def _tool():
     return mod
 
 
+def _oracle_step(params, sb):
+    import torch
+    from oracle import gcn_oracle as O
+    _, out, emb, g = O.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, sb.num_graphs, dtype=torch.float64)
+    return out, emb, g
+
+
 @pytest.mark.parametrize("small,seed", [(False, 3), (True, 5)])
-def test_random_shapes_match_the_any_shape_path(small, seed):
+def test_random_shapes_match_the_any_shape_path_and_the_oracle(small, seed):
     """`small`: 64-wide layers over 1..130-node graphs (fused.hip / wave.hip / mid.hip); else 65..224-node graphs, 64- and
     128-wide (tall.hip).  Batches the screens throw out (near-ties, activations at the LeakyReLU kink) do not count."""
     lines = []
-    ran, skipped, failed = _tool().run(cases=60, seed=seed, small=small, log=lambda *a: lines.append(" ".join(map(str, a))))
+    ran, skipped, failed = _tool().run(cases=60, seed=seed, small=small, log=lambda *a: lines.append(" ".join(map(str, a))),
+                                       oracle_step=_oracle_step)
     assert not failed, "\n".join(l for l in lines if l.startswith("FAIL"))
     assert ran >= 25, (ran, skipped)

@@ -275,6 +275,49 @@ def test_epoch_window_equals_the_per_batch_loop_on_the_same_permutations(H, cfg,
     assert va2 == vb2
 
 
+def test_concurrent_runs_equal_the_runs_one_by_one(H):
+    """`train_networks` / `eval_networks`: several independent runs (the reference's nested cross-validation trains 90, one
+    after another: scripts_experiments/train_GNN.py:48-50) advance together, every run's epoch ONE hipGraph on the run's own
+    HIP stream.  Each run is BITWISE what `train_network` / `eval_network` give it alone: epoch values, evaluation values and
+    weights after three epochs -- with different datasets, sizes and seeds per run, one run switched off for an epoch (early
+    stopping) and one run over a host loader (no window: trained in turn)."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import eval_network, eval_networks, train_network, train_networks
+    K = 4
+    sizes = [135, 100, 121, 90]
+
+    def make(k):
+        sb = synth.make_config("REAL", num_graphs=sizes[k], seed=synth.BASE_SEED + 7 * k)
+        graphs = sb.as_graph_list()
+        store = H.DeviceGraphStore(graphs, device="cuda")
+        torch.manual_seed(100 + k)
+        m = H.make_network("GCN", H.default_options(), 25).cuda()
+        if k == 3:                                           # a host loader: the per-batch loop, in turn
+            trn = H.DataLoader(graphs, batch_size=40, shuffle=False)
+        else:
+            trn = H.DeviceLoader(store, batch_size=40, shuffle=True, seed=20 + k)
+        return m, trn, H.DeviceLoader(store, batch_size=40)
+    together, alone = [make(k) for k in range(K)], [make(k) for k in range(K)]
+    for (ma, _, _), (mb, _, _) in zip(together, alone):
+        mb.load_state_dict(ma.state_dict())
+    masks = [[True] * K, [True, False, True, True], [True] * K]
+    for active in masks:
+        tv = train_networks([r[0] for r in together], [r[1] for r in together], "cuda", active=active)
+        ev = eval_networks([r[0] for r in together], [r[2] for r in together], "cuda", active=active)
+        for k, (m, trn, val) in enumerate(alone):
+            if not active[k]:
+                assert tv[k] is None and ev[k] is None
+                continue
+            assert tv[k] == train_network(m, trn, "cuda"), k
+            assert ev[k] == eval_network(m, val, "cuda"), k
+    for (ma, _, _), (mb, _, _) in zip(together, alone):
+        for q, r in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(q, r)
+    assert getattr(together[0][1], "_hcg_epoch_window", (None, None))[1] is not None     # the one-graph form did run
+    with pytest.raises(ValueError):
+        train_networks([together[0][0]], [], "cuda")
+
+
 def test_train_network_mirror_runs_an_epoch_and_learns(H):
     """hcatgnet_amd.train.train_network / eval_network / predict_network: the reference's loop signatures
     (utils/utils_model.py:55-111) over a DeviceLoader; fused step for 30-atom graphs, autograd fallback for graphs

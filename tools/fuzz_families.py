@@ -17,18 +17,19 @@ from tests.test_gpu_parity import _model_from_params, _rand_params, _step_grads,
 from tests.test_gpu_mid import _near_ties
 from hcatgnet_amd.train import FusedTrainStep
 
-def run(cases=60, seed=0, small=False, log=print):
-    """-> (cases run, cases skipped, tags of the failed ones)."""
+def run(cases=60, seed=0, small=False, log=print, oracle_step=None):
+    """-> (cases run, cases skipped, tags of the failed ones).  `oracle_step(params, sb)` -> (out, emb, {name: grad}) of the
+    CPU oracle (given by tests/test_gpu_fuzz.py only: tools never import oracle/): every case is then ALSO compared with it."""
     rng = np.random.default_rng(seed)
     failed = []
     tall_min = HF.TALL_MIN_NODES_D64
     try:
-        return _run(cases, rng, small, log, failed)
+        return _run(cases, rng, small, log, failed, oracle_step)
     finally:
         HF.TALL_MIN_NODES_D64 = tall_min
 
 
-def _run(cases, rng, small, log, failed):
+def _run(cases, rng, small, log, failed, oracle_step=None):
     if not small:
         HF.TALL_MIN_NODES_D64 = 0
     edges = [1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 100, 130] if small else [65, 66, 96, 127, 128, 129, 130, 160, 199, 200, 223, 224]
@@ -75,6 +76,11 @@ def _run(cases, rng, small, log, failed):
         errs.update({k: rel_inf(g_t[k], g_g[k]) for k in g_t})
         ok = st == 0 and errs["emb"] <= 2e-6 and errs["out"] <= 2e-6 and all(errs[k] <= TOL_DW for k in g_t)
         ok = ok and all(torch.isfinite(v).all() for v in g_t.values())
+        if oracle_step is not None:                            # the CPU oracle (fp64 gradients), not only the any-shape GPU path
+            o_out, o_emb, o_g = oracle_step(params, sb)
+            errs["oracle:emb"], errs["oracle:out"] = rel_inf(emb_t, o_emb), rel_inf(out_t, o_out, floor=1.0)
+            errs.update({"oracle:" + k: rel_inf(g_t[k], o_g[k]) for k in g_t})
+            ok = ok and errs["oracle:emb"] <= 1e-5 and errs["oracle:out"] <= 1e-5 and all(errs["oracle:" + k] <= TOL_DW for k in g_t)
         # the same batch through the no-autograd training step (train.FusedTrainStep: its own dispatch, workspaces, jobs)
         step = FusedTrainStep(m, optimizer_step=False)
         if step.unsupported_reason(m, batch) is None:
