@@ -19,7 +19,7 @@ HCG_LOSS_MSE, HCG_LOSS_RMSE, HCG_LOSS_SSE = 0, 1, 2      # loss modes of hcg_ste
 HCG_HEAD_FORWARD_ONLY = 1
 HCG_WS_PLAN, HCG_WS_LINEAR, HCG_WS_GCN_LAYER_BWD, HCG_WS_READOUT2 = 0, 1, 2, 3        # hcg_general_workspace_bytes kinds
 HCG_FUSED_POOLBITS, HCG_FUSED_HEAD_WS = 0, 1                                          # hcg_fused_aux_bytes kinds
-HCG_STRUCT_REDUCE_JOB, HCG_STRUCT_TAIL_ARGS, HCG_STRUCT_FUSED_FWD_ARGS = 0, 1, 2     # hcg_struct_bytes
+HCG_STRUCT_REDUCE_JOB, HCG_STRUCT_TAIL_ARGS, HCG_STRUCT_FUSED_FWD_ARGS, HCG_STRUCT_COLLATE_ARGS, HCG_STRUCT_COLLATE_SLOT = 0, 1, 2, 3, 4   # hcg_struct_bytes
 HCG_REDUCE_MAX_JOBS, HCG_REDUCE_MAX_SEGS = 8, 4
 HCG_XCHG_MEAN, HCG_XCHG_SSE, HCG_XCHG_ERR_TIMEOUT, HCG_XCHG_MAX_WORLD = 0, 1, 1, 8
 STATUS_BITS = {1: "edge_index entry outside [0, N)", 2: "batch vector not sorted (non-decreasing)",
@@ -60,6 +60,19 @@ class FusedFwdArgs(ctypes.Structure):
                 ("demb", P), ("head_workspace", P), ("head_workspace_bytes", SZ), ("step_counter", P)]
 
 
+class CollateSlot(ctypes.Structure):
+    """hcg_collate_slot: one batch of a collate launch."""
+    _fields_ = [("ids", P), ("graph_ptr", P), ("edge_ptr", P), ("x_out", P), ("edge_index_out", P), ("batch_out", P),
+                ("y_out", P), ("idx_out", P), ("B", I64), ("N_out", I64), ("E_out", I64)]
+
+
+class CollateArgs(ctypes.Structure):
+    """hcg_collate_args: the dataset + one slot (host values) or a device array of slots."""
+    _fields_ = [("x_all", P), ("src_all", P), ("dst_all", P), ("node_ptr_all", P), ("edge_ptr_all", P), ("y_all", P),
+                ("idx_all", P), ("F", I64), ("nslots", I32), ("reserved", I32), ("slot", CollateSlot), ("slots_dev", P),
+                ("max_B", I64)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/hcatgnet_hip.h
 SIGNATURES = {
     "hcg_version": (INT, []),
@@ -96,7 +109,7 @@ SIGNATURES = {
     "hcg_reduce_job_append": (INT, [P, P]),
     "hcg_step_tail": (INT, [P, P]),
     "hcg_loss_finalize": (INT, [P, F32, INT, P, P, P]),
-    "hcg_collate": (INT, [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P]),
+    "hcg_collate": (INT, [P, P]),
     "hcg_adam_step": (INT, [P, P, P, P, I64, F32, F32, F32, F32, I64, P]),
     "hcg_mse_fwd": (INT, [P, P, I64, P, P]),
     "hcg_mse_bwd": (INT, [P, P, P, I64, P, P, P]),

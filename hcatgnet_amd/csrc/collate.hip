@@ -9,60 +9,75 @@
 //   y / idx    per-graph scalars
 // The batch's graph_ptr / edge_ptr (= the whole plan of the fused path) are prefix sums of per-graph sizes
 // the host already knows, so they are uploaded, not recomputed.
+// Every batch of an epoch in ONE launch (round 3): a shuffled epoch's batches are known once its permutation is drawn, and at
+// the reference's batch size 40 a per-batch collate launch is a tenth of the step it feeds (40 workgroups, one dependent
+// hop): train.EpochWindow hands the launch a device array of slot descriptors, grid = (largest batch, slots).
 #include "common.h"
 
 namespace {
 
-// one 256-thread workgroup per selected graph
-__global__ __launch_bounds__(256) void k_collate(const float* __restrict__ x_all, const int32_t* __restrict__ src_all,
-                                                 const int32_t* __restrict__ dst_all, const int64_t* __restrict__ node_ptr_all,
-                                                 const int64_t* __restrict__ edge_ptr_all, const float* __restrict__ y_all,
-                                                 const int64_t* __restrict__ idx_all, const int64_t* __restrict__ ids,
-                                                 const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr,
-                                                 int F, int64_t E_out, float* __restrict__ x_out,
-                                                 int64_t* __restrict__ ei_out, int64_t* __restrict__ batch_out,
-                                                 float* __restrict__ y_out, int64_t* __restrict__ idx_out) {
+struct Dataset {
+  const float* x_all;
+  const int32_t* src_all;
+  const int32_t* dst_all;
+  const int64_t* node_ptr_all;
+  const int64_t* edge_ptr_all;
+  const float* y_all;
+  const int64_t* idx_all;
+  int F;
+};
+
+// one 256-thread workgroup per selected graph (blockIdx.x) of a slot (MULTI: blockIdx.y, descriptor read from the device
+// array -- a uniform address, scalar loads)
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_collate(Dataset ds, hcg_collate_slot one, const hcg_collate_slot* __restrict__ slots) {
+  const hcg_collate_slot s = MULTI ? slots[blockIdx.y] : one;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int64_t g = ids[b];
-  const int64_t nin = node_ptr_all[g], ein = edge_ptr_all[g];
-  const int nout = graph_ptr[b], n = graph_ptr[b + 1] - nout;
-  const int eout = edge_ptr[b], ne = edge_ptr[b + 1] - eout;
+  if (MULTI && b >= (int)s.B) return;
+  const int F = ds.F;
+  const int64_t g = s.ids[b];
+  const int64_t nin = ds.node_ptr_all[g], ein = ds.edge_ptr_all[g];
+  const int nout = s.graph_ptr[b], n = s.graph_ptr[b + 1] - nout;
+  const int eout = s.edge_ptr[b], ne = s.edge_ptr[b + 1] - eout;
   // features: the graph's rows are one contiguous block of n*F floats on both sides
-  const float* xs = x_all + (size_t)nin * F;
-  float* xd = x_out + (size_t)nout * F;
+  const float* xs = ds.x_all + (size_t)nin * F;
+  float* xd = s.x_out + (size_t)nout * F;
   const int total = n * F;
   if ((F & 3) == 0 && (((uintptr_t)xs | (uintptr_t)xd) & 15) == 0) {
     for (int i = tid; i < total / 4; i += 256) reinterpret_cast<float4*>(xd)[i] = reinterpret_cast<const float4*>(xs)[i];
   } else {
     for (int i = tid; i < total; i += 256) xd[i] = xs[i];
   }
-  for (int i = tid; i < n; i += 256) batch_out[nout + i] = b;
+  for (int i = tid; i < n; i += 256) s.batch_out[nout + i] = b;
   for (int k = tid; k < ne; k += 256) {
-    ei_out[eout + k] = (int64_t)src_all[ein + k] + nout;
-    ei_out[E_out + eout + k] = (int64_t)dst_all[ein + k] + nout;
+    s.edge_index_out[eout + k] = (int64_t)ds.src_all[ein + k] + nout;
+    s.edge_index_out[s.E_out + eout + k] = (int64_t)ds.dst_all[ein + k] + nout;
   }
   if (tid == 0) {
-    if (y_out) y_out[b] = y_all[g];
-    if (idx_out) idx_out[b] = idx_all[g];
+    if (s.y_out) s.y_out[b] = ds.y_all[g];
+    if (s.idx_out) s.idx_out[b] = ds.idx_all[g];
   }
 }
 
 }  // namespace
 
-extern "C" int hcg_collate(const float* x_all, const int32_t* src_all, const int32_t* dst_all, const int64_t* node_ptr_all,
-                           const int64_t* edge_ptr_all, const float* y_all, const int64_t* idx_all, const int64_t* ids,
-                           const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t B, int64_t F, int64_t N_out,
-                           int64_t E_out, float* x_out, int64_t* edge_index_out, int64_t* batch_out, float* y_out,
-                           int64_t* idx_out, hcg_stream_t stream) {
-  if (B < 0 || F <= 0 || N_out < 0 || E_out < 0 || F >= (1 << 20)) return HCG_ERR_INVALID_ARG;
-  if (B == 0) return HCG_OK;
-  if (!x_all || !node_ptr_all || !edge_ptr_all || !ids || !graph_ptr || !edge_ptr || !x_out || !batch_out)
-    return HCG_ERR_INVALID_ARG;
-  if (E_out > 0 && (!src_all || !dst_all || !edge_index_out)) return HCG_ERR_INVALID_ARG;
-  if ((y_out && !y_all) || (idx_out && !idx_all)) return HCG_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(k_collate, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x_all, src_all, dst_all, node_ptr_all,
-                     edge_ptr_all, y_all, idx_all, ids, graph_ptr, edge_ptr, (int)F, E_out, x_out, edge_index_out, batch_out,
-                     y_out, idx_out);
+extern "C" int hcg_collate(const hcg_collate_args* a, hcg_stream_t stream) {
+  if (!a || a->nslots < 1 || a->F <= 0 || a->F >= (1 << 20)) return HCG_ERR_INVALID_ARG;
+  if (!a->x_all || !a->node_ptr_all || !a->edge_ptr_all) return HCG_ERR_INVALID_ARG;
+  const Dataset ds{a->x_all, a->src_all, a->dst_all, a->node_ptr_all, a->edge_ptr_all, a->y_all, a->idx_all, (int)a->F};
+  if (a->nslots == 1) {
+    const hcg_collate_slot& s = a->slot;
+    if (s.B < 0 || s.N_out < 0 || s.E_out < 0) return HCG_ERR_INVALID_ARG;
+    if (s.B == 0) return HCG_OK;
+    if (!s.ids || !s.graph_ptr || !s.edge_ptr || !s.x_out || !s.batch_out) return HCG_ERR_INVALID_ARG;
+    if (s.E_out > 0 && (!a->src_all || !a->dst_all || !s.edge_index_out)) return HCG_ERR_INVALID_ARG;
+    if ((s.y_out && !a->y_all) || (s.idx_out && !a->idx_all)) return HCG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_collate<false>, dim3((unsigned)s.B), dim3(256), 0, (hipStream_t)stream, ds, s, nullptr);
+  } else {
+    if (!a->slots_dev || a->max_B < 1 || a->nslots > 65535 || !a->src_all || !a->dst_all) return HCG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_collate<true>, dim3((unsigned)a->max_B, (unsigned)a->nslots), dim3(256), 0, (hipStream_t)stream, ds,
+                       hcg_collate_slot{}, a->slots_dev);
+  }
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }

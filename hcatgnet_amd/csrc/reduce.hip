@@ -297,6 +297,8 @@ extern "C" size_t hcg_struct_bytes(int which) {
     case HCG_STRUCT_REDUCE_JOB: return sizeof(hcg_reduce_job);
     case HCG_STRUCT_TAIL_ARGS: return sizeof(hcg_tail_args);
     case HCG_STRUCT_FUSED_FWD_ARGS: return sizeof(hcg_fused_fwd_args);
+    case HCG_STRUCT_COLLATE_ARGS: return sizeof(hcg_collate_args);
+    case HCG_STRUCT_COLLATE_SLOT: return sizeof(hcg_collate_slot);
     default: return 0;
   }
 }

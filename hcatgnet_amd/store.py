@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Iterable, Optional, Sequence
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -48,6 +50,18 @@ class DeviceGraphStore:
     def __len__(self):
         return self.num_graphs
 
+    def collate_args(self) -> "_lib.CollateArgs":
+        """The dataset half of `hcg_collate`'s argument struct (made once; callers fill the slot half)."""
+        a = getattr(self, "_collate_args", None)
+        if a is None:
+            p = _lib.ptr
+            a = _lib.CollateArgs()
+            a.x_all, a.src_all, a.dst_all, a.node_ptr_all, a.edge_ptr_all = (p(self.x_all), p(self.src_all), p(self.dst_all),
+                                                                            p(self.node_ptr_all), p(self.edge_ptr_all))
+            a.y_all, a.idx_all, a.F, a.nslots = p(self.y_all), p(self.idx_all), self.F, 1
+            self._collate_args = a
+        return a
+
     def collate(self, graph_ids: Iterable[int], _uploaded=None) -> Batch:
         """Batch of the given graphs (host list / array of indices), gathered on the device.
         `_uploaded` (DeviceLoader): device views (ids, graph_ptr, edge_ptr) of this batch inside ONE upload for the whole
@@ -76,10 +90,11 @@ class DeviceGraphStore:
         y = torch.empty(B, dtype=torch.float32, device=dev) if self.y_all is not None else None
         idx = torch.empty(B, dtype=torch.int64, device=dev) if self.idx_all is not None else None
         p = _lib.ptr
-        rc = lib.hcg_collate(p(self.x_all), p(self.src_all), p(self.dst_all), p(self.node_ptr_all), p(self.edge_ptr_all),
-                             p(self.y_all), p(self.idx_all), p(ids_d), p(gp_d), p(ep_d), B, self.F, N, E, p(x), p(ei), p(bvec),
-                             p(y), p(idx), _lib.stream_ptr())
-        _lib.check(rc, "hcg_collate")
+        a = self.collate_args()
+        sl = a.slot
+        sl.ids, sl.graph_ptr, sl.edge_ptr, sl.x_out, sl.edge_index_out, sl.batch_out = p(ids_d), p(gp_d), p(ep_d), p(x), p(ei), p(bvec)
+        sl.y_out, sl.idx_out, sl.B, sl.N_out, sl.E_out = p(y), p(idx), B, N, E
+        _lib.check(lib.hcg_collate(ctypes.byref(a), _lib.stream_ptr()), "hcg_collate")
         batch = Batch(x, ei, bvec, B, y=y, idx=idx, max_nodes=int(n.max()), max_edges=int(e.max()), edges_grouped=True)
         # the plan of the fused path is exactly (graph_ptr, edge_ptr): attach it, nothing left to launch
         plan = BatchPlan()

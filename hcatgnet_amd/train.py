@@ -898,7 +898,7 @@ class EpochWindow:
         self.dbuf = torch.zeros(G + 2 * tot, dtype=torch.int64, device=dev)
         d32 = self.dbuf[G:].view(torch.int32)
         lib, p = _lib.load(), _lib.ptr
-        self.batches, self.spans, fns, off = [], [], [], 0
+        self.batches, self.spans, slots, off = [], [], [], 0
         for i, B in zip(starts, self.Bs):
             Ncap, Ecap = int(n_desc[:B].sum()), max(int(e_desc[:B].sum()), 1)
             x = torch.zeros(Ncap, F, dtype=torch.float32, device=dev)
@@ -923,14 +923,25 @@ class EpochWindow:
             self.batches.append(batch)
             self.spans.append((i, B, off))
 
-            def collate_slot(batch=batch, ids_d=ids_d, gp_d=gp_d, ep_d=ep_d, B=B, Ncap=Ncap, Ecap=Ecap):
-                rc = lib.hcg_collate(p(st.x_all), p(st.src_all), p(st.dst_all), p(st.node_ptr_all), p(st.edge_ptr_all), p(st.y_all),
-                                     p(st.idx_all), p(ids_d), p(gp_d), p(ep_d), B, F, Ncap, Ecap, p(batch.x), p(batch.edge_index),
-                                     p(batch.batch), p(batch.y), p(batch.idx), _lib.stream_ptr())
-                _lib.check(rc, "hcg_collate")
-                return batch
-            fns.append(collate_slot)
+            sl = _lib.CollateSlot()
+            sl.ids, sl.graph_ptr, sl.edge_ptr, sl.x_out, sl.edge_index_out, sl.batch_out = p(ids_d), p(gp_d), p(ep_d), p(x), p(ei), p(bvec)
+            sl.y_out, sl.idx_out, sl.B, sl.N_out, sl.E_out = p(y), p(idx), B, Ncap, Ecap
+            slots.append(sl)
             off += 2 * words(B)
+        # ONE collate launch for the whole epoch, in front of its first step (every slot owns its buffers; the launch reads the
+        # slot descriptors from a device array): a collate per batch was 14 launches of 40 workgroups, a tenth of the epoch
+        arr = (_lib.CollateSlot * len(slots))(*slots)
+        self.slots_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        src = st.collate_args()
+        self.cargs = _lib.CollateArgs.from_buffer_copy(src)
+        self.cargs.nslots, self.cargs.slots_dev, self.cargs.max_B = len(slots), p(self.slots_dev), max(self.Bs)
+        if len(slots) == 1:
+            self.cargs.slot = slots[0]
+
+        def first_batch():
+            _lib.check(lib.hcg_collate(ctypes.byref(self.cargs), _lib.stream_ptr()), "hcg_collate")
+            return self.batches[0]
+        fns = [first_batch] + [(lambda b=b: b) for b in self.batches[1:]]
         self.steps = [FusedTrainStep(model) for _ in self.Bs]
         why = self.steps[0].reason(self.batches[0])
         if why is not None:

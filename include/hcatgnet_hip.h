@@ -353,6 +353,8 @@ typedef struct hcg_reduce_job {
 #define HCG_STRUCT_REDUCE_JOB 0
 #define HCG_STRUCT_TAIL_ARGS 1
 #define HCG_STRUCT_FUSED_FWD_ARGS 2
+#define HCG_STRUCT_COLLATE_ARGS 3
+#define HCG_STRUCT_COLLATE_SLOT 4
 size_t hcg_struct_bytes(int which);
 int hcg_fused_reduce_job(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F,
                          int64_t D, int graphs_per_tile, float* dW, float* db, hcg_reduce_job* job_host);
@@ -469,18 +471,43 @@ int hcg_xchg_ipc_export(void* ptr, void* handle64);
 int hcg_xchg_ipc_open(const void* handle64, void** ptr);
 int hcg_xchg_ipc_close(void* ptr);
 
-/* ---- on-device collation (f1): gather B graphs of an HBM-resident dataset into one PyG-style batch.
+/* ---- on-device collation (f1): gather the graphs of an HBM-resident dataset into PyG-style batches, ONE launch for one
+ * batch or for every batch of an epoch.
  * Dataset side: x_all [N_all, F], local edge lists src_all / dst_all (int32 ids inside their graph),
- * node_ptr_all / edge_ptr_all [G+1] (int64), y_all [G], idx_all [G].  `ids` [B] selects graphs (device).
- * graph_ptr / edge_ptr [B+1] (int32) are the batch's prefix sums (the host knows the sizes; they double
- * as the fused path's plan).  Writes x_out [N_out, F], edge_index_out [2, E_out] (global ids), batch_out
- * [N_out], y_out / idx_out [B] (nullable).  Replaces reference data/datasets.py:74-78 + PyG collate. */
-int hcg_collate(const float* x_all, const int32_t* src_all, const int32_t* dst_all,
-                const int64_t* node_ptr_all, const int64_t* edge_ptr_all, const float* y_all,
-                const int64_t* idx_all, const int64_t* ids, const int32_t* graph_ptr, const int32_t* edge_ptr,
-                int64_t B, int64_t F, int64_t N_out, int64_t E_out,
-                float* x_out, int64_t* edge_index_out, int64_t* batch_out, float* y_out /*nullable*/,
-                int64_t* idx_out /*nullable*/, hcg_stream_t stream);
+ * node_ptr_all / edge_ptr_all [G+1] (int64), y_all [G], idx_all [G].
+ * A slot = one batch: `ids` [B] selects its graphs (device); graph_ptr / edge_ptr [B+1] (int32) are the batch's prefix sums
+ * (the host knows the sizes; they double as the fused path's plan).  Writes x_out [N_out, F], edge_index_out [2, E_out]
+ * (batch-local ids), batch_out [N_out], y_out / idx_out [B] (nullable).
+ * nslots == 1: the batch is `slot` (host values).  nslots > 1: `slots_dev` is a DEVICE array of nslots descriptors (every
+ * batch of a shuffled epoch: train.EpochWindow collates an epoch in one launch in front of its steps), max_B the largest
+ * slot.B; the caller has validated them.  Replaces reference data/datasets.py:74-78 + PyG collate (call_methods.py:41-46). */
+typedef struct hcg_collate_slot {
+  const int64_t* ids;
+  const int32_t* graph_ptr;
+  const int32_t* edge_ptr;
+  float* x_out;
+  int64_t* edge_index_out;
+  int64_t* batch_out;
+  float* y_out;               /* nullable */
+  int64_t* idx_out;           /* nullable */
+  int64_t B, N_out, E_out;
+} hcg_collate_slot;
+typedef struct hcg_collate_args {
+  const float* x_all;
+  const int32_t* src_all;
+  const int32_t* dst_all;
+  const int64_t* node_ptr_all;
+  const int64_t* edge_ptr_all;
+  const float* y_all;         /* nullable when no slot has y_out */
+  const int64_t* idx_all;     /* nullable when no slot has idx_out */
+  int64_t F;
+  int32_t nslots;
+  int32_t reserved;
+  hcg_collate_slot slot;                 /* nslots == 1 */
+  const hcg_collate_slot* slots_dev;     /* nslots > 1 */
+  int64_t max_B;                         /* nslots > 1 */
+} hcg_collate_args;
+int hcg_collate(const hcg_collate_args* args_host, hcg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,8 @@ def test_host_structs_match_the_library():
     assert ctypes.sizeof(_lib.ReduceJob) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_REDUCE_JOB)
     assert ctypes.sizeof(_lib.TailArgs) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_TAIL_ARGS)
     assert ctypes.sizeof(_lib.FusedFwdArgs) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_FUSED_FWD_ARGS)
+    assert ctypes.sizeof(_lib.CollateArgs) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_COLLATE_ARGS)
+    assert ctypes.sizeof(_lib.CollateSlot) == lib.hcg_struct_bytes(_lib.HCG_STRUCT_COLLATE_SLOT)
     assert lib.hcg_step_tail(None, None) == -1 and lib.hcg_fused_forward(None, None) == -1
     a = _lib.TailArgs()
     assert lib.hcg_step_tail(ctypes.addressof(a), None) == 0            # no jobs, nothing else: nothing to do
