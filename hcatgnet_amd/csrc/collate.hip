@@ -34,28 +34,42 @@ __global__ __launch_bounds__(256) void k_collate(Dataset ds, hcg_collate_slot on
   const hcg_collate_slot s = MULTI ? slots[blockIdx.y] : one;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (MULTI && b >= (int)s.B) return;
+  // (pointers that arrive through memory are generic to the compiler: without the address-space casts every access of the
+  //  multi-slot form is a flat_* instruction -- tools/isa_lint.py)
+#define GLOBAL_PTR(T, p) reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p))
+  auto* ids = GLOBAL_PTR(const int64_t, s.ids);
+  auto* gp = GLOBAL_PTR(const int32_t, s.graph_ptr);
+  auto* ep = GLOBAL_PTR(const int32_t, s.edge_ptr);
+  auto* x_out = GLOBAL_PTR(float, s.x_out);
+  auto* ei_out = GLOBAL_PTR(int64_t, s.edge_index_out);
+  auto* batch_out = GLOBAL_PTR(int64_t, s.batch_out);
+  auto* y_out = GLOBAL_PTR(float, s.y_out);
+  auto* idx_out = GLOBAL_PTR(int64_t, s.idx_out);
+#undef GLOBAL_PTR
   const int F = ds.F;
-  const int64_t g = s.ids[b];
+  const int64_t g = ids[b];
   const int64_t nin = ds.node_ptr_all[g], ein = ds.edge_ptr_all[g];
-  const int nout = s.graph_ptr[b], n = s.graph_ptr[b + 1] - nout;
-  const int eout = s.edge_ptr[b], ne = s.edge_ptr[b + 1] - eout;
+  const int nout = gp[b], n = gp[b + 1] - nout;
+  const int eout = ep[b], ne = ep[b + 1] - eout;
   // features: the graph's rows are one contiguous block of n*F floats on both sides
   const float* xs = ds.x_all + (size_t)nin * F;
-  float* xd = s.x_out + (size_t)nout * F;
+  auto* xd = x_out + (size_t)nout * F;
   const int total = n * F;
   if ((F & 3) == 0 && (((uintptr_t)xs | (uintptr_t)xd) & 15) == 0) {
-    for (int i = tid; i < total / 4; i += 256) reinterpret_cast<float4*>(xd)[i] = reinterpret_cast<const float4*>(xs)[i];
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    auto* xd4 = reinterpret_cast<__attribute__((address_space(1))) vec4*>(xd);
+    for (int i = tid; i < total / 4; i += 256) xd4[i] = reinterpret_cast<const vec4*>(xs)[i];
   } else {
     for (int i = tid; i < total; i += 256) xd[i] = xs[i];
   }
-  for (int i = tid; i < n; i += 256) s.batch_out[nout + i] = b;
+  for (int i = tid; i < n; i += 256) batch_out[nout + i] = b;
   for (int k = tid; k < ne; k += 256) {
-    s.edge_index_out[eout + k] = (int64_t)ds.src_all[ein + k] + nout;
-    s.edge_index_out[s.E_out + eout + k] = (int64_t)ds.dst_all[ein + k] + nout;
+    ei_out[eout + k] = (int64_t)ds.src_all[ein + k] + nout;
+    ei_out[s.E_out + eout + k] = (int64_t)ds.dst_all[ein + k] + nout;
   }
   if (tid == 0) {
-    if (s.y_out) s.y_out[b] = ds.y_all[g];
-    if (s.idx_out) s.idx_out[b] = ds.idx_all[g];
+    if (s.y_out) y_out[b] = ds.y_all[g];
+    if (s.idx_out) idx_out[b] = ds.idx_all[g];
   }
 }
 

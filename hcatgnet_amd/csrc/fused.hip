@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   __shared__ WaveLdsF lds[WAVES];
   static_assert(HEAD == 0 || sizeof(hcg_head16::Lds) <= sizeof(WaveLdsF) * WAVES, "the head's LDS aliases the tile buffers");
   __shared__ float semb[HEAD != 0 ? SEMB_ROWS * hcg_head16::ES : 4];   // this workgroup's pooled rows, for its head tail
-  if (HEAD != 0 && HA.step_counter && blockIdx.x == 0 && threadIdx.x == 0) HA.step_counter[0] += 1;   // this step's number
+  if (HEAD != 0 && HA.step_counter && blockIdx.x == 0 && threadIdx.x == 0) { HA.step_counter[0] += 1; HA.step_counter[1] += 1; }   // this step's number | the exchange stamp (never re-based)
   __shared__ __attribute__((aligned(16))) short w1l[3 * DD * (KPAD + WPAD)];
   __shared__ __attribute__((aligned(16))) short w2l[STACK2 ? 3 * DD * (DD + WPAD) : 8];
   STAMP_DECL

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(HC<RD>::NT, 1) void k_head(const float* __restrict_
   __shared__ HeadLds<RD> L;
   HeadState<RD, RC> S;
   const int tiles = (B + RT - 1) / RT;
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;   // this training step's number, for the update launched later
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) { step_counter[0] += 1; step_counter[1] += 1; }   // this training step's number, for the update launched later | exchange stamp
   head_begin<RD, RC>(L, S, W0, b0, W1, b1, C);
   for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int g0 = t * RT, n = B - g0 < RT ? B - g0 : RT;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(hcg_head16::NT, 1) void k_head16(const float* __res
                                                              int* __restrict__ step_counter) {
   namespace h16 = hcg_head16;
   __shared__ h16::Lds L;
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) { step_counter[0] += 1; step_counter[1] += 1; }
   h16::Prefetch<RC> P;
   h16::prefetch<RC>(P, W0, b0, W1, C);
   h16::State<RC> S;

@@ -41,7 +41,7 @@ struct AdamArgs {
   float* m;
   float* v;
   const float* lr_dev;
-  const int* step_dev;      // [0] = 1-based number of this update
+  const int* step_dev;      // [0] = 1-based number of this update, [1] = exchange stamp (monotonic)
   float b1, b2, eps;
 };
 
@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void k_step_tail(Jobs jobs, AdamArgs A, PlanAr
   // [0] lr / bias-correction-1, [1] sqrt(bias-correction-2), [2] scale applied to this rank's sum (before an exchange),
   // [3] scale applied to the exchanged total
   __shared__ float adam_c[4];
-  const unsigned xstep = XCHG ? (unsigned)A.step_dev[0] : 0u;
+  // the exchange stamp is step_dev[1]: advanced with step_dev[0] by the step's first launch, but owned by no optimiser state --
+  // reloading a checkpoint re-bases the Adam step count, never the stamp (a stamp an inbox has already seen would let a stale
+  // granule pass as this step's)
+  const unsigned xstep = XCHG ? (unsigned)A.step_dev[1] : 0u;
   const int parity = (int)(xstep & 1u);
   const bool first = blockIdx.x == 0;
   if (ADAM && threadIdx.x == 0) {                    // bias corrections in double like torch's host computation

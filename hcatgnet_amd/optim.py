@@ -35,9 +35,13 @@ class FusedAdam(torch.optim.Optimizer):
                 self._make_dev_state(fl, group)
 
     def _make_dev_state(self, fl, group):
+        """step_dev = [Adam step count, exchange stamp].  Word 1 counts the steps this optimiser OBJECT has started and is
+        carried over every re-base / `load_state_dict` (`_keep_stamp`): the one-shot exchange (xgmi.py) stamps its granules
+        with it, and a stamp must never repeat although the Adam step count may go back to a checkpoint's."""
         if "step_dev" not in fl:
             dev = fl["p"].device
-            fl["step_dev"] = torch.tensor([fl["step"], 0], dtype=torch.int32, device=dev)
+            stamps = getattr(self, "_stamps", {})
+            fl["step_dev"] = torch.tensor([fl["step"], stamps.get(fl.get("gi", 0), 0)], dtype=torch.int32, device=dev)
             fl["lr_dev"] = torch.tensor([float(group["lr"])], dtype=torch.float32, device=dev)
             fl["lr_host"] = float(group["lr"])
 
@@ -61,6 +65,8 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """Restored moments / step counts are copied into fresh flat buffers right away (torch's `load_state_dict` may
         alias the tensors of the dict it is given: a source optimizer that keeps stepping must not leak into this one)."""
+        for gi in list(self._flat):
+            self._keep_stamp(gi)
         super().load_state_dict(state_dict)
         self._flat = {}
         with torch.no_grad():
@@ -81,8 +87,17 @@ class FusedAdam(torch.optim.Optimizer):
                     self.state[p]["step"] = torch.tensor(float(n))
         return super().state_dict()
 
+    def _keep_stamp(self, gi):
+        """Remember the exchange stamp of a flat state that is about to be replaced (synchronises; re-bases are rare)."""
+        old = self._flat.get(gi)
+        if old is not None and "step_dev" in old:
+            if not hasattr(self, "_stamps"):
+                self._stamps = {}
+            self._stamps[gi] = max(self._stamps.get(gi, 0), int(old["step_dev"][1].item()))
+
     def _rebase(self, gi, group):
         """Move the group's parameters and moments onto flat buffers (in parameter order)."""
+        self._keep_stamp(gi)
         ps = [p for p in group["params"] if p.requires_grad]
         dev = ps[0].device
         n = sum(p.numel() for p in ps)
@@ -105,7 +120,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = flat_v[off:off + k].view(p.shape)
                 st.setdefault("step", torch.tensor(0.0))
                 off += k
-        self._flat[gi] = dict(params=ps, p=flat_p, m=flat_m, v=flat_v, n=n, step=int(ps and self.state[ps[0]]["step"]) if ps else 0)
+        self._flat[gi] = dict(params=ps, p=flat_p, m=flat_m, v=flat_v, n=n, gi=gi, step=int(ps and self.state[ps[0]]["step"]) if ps else 0)
         return self._flat[gi]
 
     def fused_update_ready(self, flat_grad: torch.Tensor):

@@ -968,7 +968,7 @@ class EpochWindow:
             raise _lib.HcgError("EpochWindow: the optimiser re-based its state during the capture")
         torch.cuda.synchronize()
         with torch.no_grad():
-            fl["p"].copy_(saved[0]); fl["m"].copy_(saved[1]); fl["v"].copy_(saved[2]); fl["step_dev"].copy_(saved[3])
+            fl["p"].copy_(saved[0]); fl["m"].copy_(saved[1]); fl["v"].copy_(saved[2]); fl["step_dev"][:1].copy_(saved[3][:1])
 
     def _layout(self, order):
         """The epoch's index arrays [ids of every batch | graph_ptr of every batch | edge_ptr of every batch] -> device."""

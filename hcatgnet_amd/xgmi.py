@@ -157,7 +157,7 @@ class OneShotExchange:
                     slab.copy_(data)
                     flat_ext[n] = float(self.rank + 1) * (r + 1)        # "SSE"
                     flat_ext[n + 1] = 10.0 * (self.rank + 1)            # "count"
-                    fl["step_dev"][0] += 1                              # what the head kernel does in a real step
+                    fl["step_dev"] += 1                                 # what the head kernel does in a real step (count + stamp)
                     ref = torch.cat([data, flat_ext[n:].clone()])
                     self.launch(ctypes.addressof(job), 1, flat_ext, fl, 0.9, 0.999, 1e-9, "sse", loss)
                     torch.cuda.synchronize()
@@ -181,7 +181,8 @@ class OneShotExchange:
         return self.ok
 
     def reset(self):
-        """Zero this rank's inbox (between optimisers: stamps are step numbers).  Collective: all ranks call it."""
+        """Zero this rank's inbox (between optimiser OBJECTS: a stamp counts the steps one FusedAdam has started -- `step_dev[1]`,
+        carried over its re-bases and `load_state_dict`, so reloading a checkpoint mid-run needs no reset).  Collective: all ranks call it."""
         torch.cuda.synchronize()
         dist.barrier(group=self.group)
         if self.inbox:

@@ -384,11 +384,27 @@ def _rank_main_xchg(rank, world, port, q):
             l1, l2 = float(step(mine)), float(ref(mine))
             res["loss"], res["loss_ref"] = l1, l2
             res["grads"] = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+            import copy
+            ckpt = (copy.deepcopy(m.state_dict()), copy.deepcopy(m.optimizer.state_dict()))
+            ckpt_ref = (copy.deepcopy(twin.state_dict()), copy.deepcopy(twin.optimizer.state_dict()))
             for _ in range(5):                                                # five more steps (both step parities, Adam state)
                 l1, l2 = float(step(mine)), float(ref(mine))
             res["loss3"], res["loss3_ref"] = l1, l2
             res["w"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy().copy()
             res["w_ref"] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu().numpy().copy()
+            xchg.check()
+            # a checkpoint taken after step 1 is reloaded mid-run: the Adam step count goes BACK to 1 (numbers the inbox has
+            # already seen), the exchange stamp does not -- three more steps still follow the collective path
+            for mm, ck in ((m, ckpt), (twin, ckpt_ref)):
+                mm.load_state_dict(ck[0])
+                mm.optimizer.load_state_dict(ck[1])
+            assert m.optimizer.steps_done() == 1
+            for _ in range(3):
+                l1, l2 = float(step(mine)), float(ref(mine))
+            res["loss_rl"], res["loss_rl_ref"] = l1, l2
+            res["stamp"] = int(m.optimizer._flat[0]["step_dev"][1].item())
+            res["w_rl"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy().copy()
+            res["w_rl_ref"] = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu().numpy().copy()
             xchg.check()
         res["w0"] = w0
         q.put(res)
@@ -431,6 +447,11 @@ def test_one_shot_exchange_two_ranks_equals_the_collective_path(H, oracle):
             assert rel_inf(torch.from_numpy(r["grads"][k]), g_ref[k]) <= tol, k
         assert float(np.abs(r["w"] - r["w_ref"]).max()) <= 2e-3 * float(np.abs(r["w_ref"]).max())   # (Adam, eps 1e-9: loose)
     assert np.array_equal(r0["w"], r1["w"])                                    # replicas bitwise in sync
+    for r in (r0, r1):                                                         # after the mid-run checkpoint reload
+        assert abs(r["loss_rl"] - r["loss_rl_ref"]) <= 1e-4 * abs(r["loss_rl_ref"])
+        assert float(np.abs(r["w_rl"] - r["w_rl_ref"]).max()) <= 2e-3 * float(np.abs(r["w_rl_ref"]).max())
+        assert r["stamp"] >= 9                                                  # 6 + 3 steps (+ nothing re-based it)
+    assert np.array_equal(r0["w_rl"], r1["w_rl"])
     for k in r0["grads"]:
         assert np.array_equal(r0["grads"][k], r1["grads"][k]), k
 
