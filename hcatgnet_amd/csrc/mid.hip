@@ -510,9 +510,16 @@ __device__ __forceinline__ Quad ldq(const char* p) {
 
 // TO_TILE (the backward's transpose sum): dH_row = dinv_row * sum goes to the second tile `t1` for EVERY row of the unit
 // (rows past the graph are zero), no epilogue.
-template <bool CSR, bool POOL, bool TO_TILE = false>
+// BITS (needs POOL; the pooled layer of a training step whose backward is csrc/tall.hip's): the unit's outputs are NOT
+// stored.  What the pooled backward needs of them -- is the value positive (LeakyReLU'), is it its graph's column maximum
+// (where the max pool's gradient goes, ties included) -- leaves as one byte per (row, 4 columns) once the graph's maxima are
+// known.  Until then a lane keeps two 32-bit masks for its <= 8 rows (nibble k = its k-th row, bit c = column 4 q + c):
+// `sgn`, and `mxb` = the rows that attain the lane's OWN running maximum `pmax` (reset when a larger value arrives, joined on
+// equality) -- a row is a maximum of the graph iff it is one of the lane's and the lane's maximum equals the graph's.
+template <bool CSR, bool POOL, bool TO_TILE = false, bool BITS = false>
 __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsigned empty_id, const Quad& bq, float slope_eff,
-                                             float* __restrict__ out_graph, int ldo, Quad& pmax, Quad& psum) {
+                                             float* __restrict__ out_graph, int ldo, Quad& pmax, Quad& psum,
+                                             unsigned* sgn = nullptr, unsigned* mxb = nullptr, int kbase = 0) {
   const int lane = threadIdx.x & 63, q = lane & 15, r4 = lane >> 4;
   const char* tq = reinterpret_cast<const char*>(L.t0 + 4 * q);
   uint2 nb[4];
@@ -577,7 +584,21 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
     y.lo = __builtin_elementwise_max(y.lo, s2 * y.lo);   // LeakyReLU as max(v, slope v): exact for 0 <= slope <= 1; none: slope 1
     y.hi = __builtin_elementwise_max(y.hi, s2 * y.hi);
     if (row < n) {
-      *reinterpret_cast<float4*>(out_graph + (size_t)row * ldo + 4 * q) = make_float4(y.lo.x, y.lo.y, y.hi.x, y.hi.y);
+      if constexpr (BITS) {
+        const unsigned k4 = 4u * (unsigned)(kbase + pass);
+        const float yv[4] = {y.lo.x, y.lo.y, y.hi.x, y.hi.y}, mv[4] = {pmax.lo.x, pmax.lo.y, pmax.hi.x, pmax.hi.y};
+        unsigned sn = 0, m = *mxb;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          sn |= (unsigned)(yv[cc] > 0.f) << cc;
+          const unsigned bit = 1u << (k4 + cc), colmask = 0x11111111u << cc;
+          m = yv[cc] > mv[cc] ? ((m & ~colmask) | bit) : (yv[cc] == mv[cc] ? (m | bit) : m);
+        }
+        *sgn |= sn << k4;
+        *mxb = m;
+      } else {
+        *reinterpret_cast<float4*>(out_graph + (size_t)row * ldo + 4 * q) = make_float4(y.lo.x, y.lo.y, y.hi.x, y.hi.y);
+      }
       if (POOL) {
         pmax.lo = __builtin_elementwise_max(pmax.lo, y.lo);
         pmax.hi = __builtin_elementwise_max(pmax.hi, y.hi);
@@ -612,13 +633,17 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
 // VEC / NR: how the x rows are prefetched (XRows; unused by MULTIK, which stages chunk by chunk inside the iteration).
 // (launch bounds: four waves per SIMD = two workgroups per CU = at most 128 VGPRs -- the scheduler trades load batching for
 //  registers instead of silently dropping to one workgroup per CU; MULTIK needs more and runs one workgroup per CU)
-template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR>
+// BITS (needs POOL): `out` is not written; `poolbits` [N][ldo / 4] bytes take its place for the pooled backward of
+// csrc/tall.hip (mid_agg_unit): 91 MB less written here and 91 MB less read there on a 356 k-node batch.
+template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR, bool BITS = false>
 __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int64_t* __restrict__ ei,
                                                          int64_t E, const int32_t* __restrict__ graph_ptr,
                                                          const int32_t* __restrict__ edge_ptr, int B, int npad, int emax,
                                                          float slope, int apply_act, float* __restrict__ out, int ldo, int coff,
-                                                         float* __restrict__ emb, int32_t* __restrict__ status) {
+                                                         float* __restrict__ emb, int32_t* __restrict__ status,
+                                                         unsigned char* __restrict__ poolbits = nullptr) {
+  static_assert(!BITS || (POOL && !MULTIK), "the bit form belongs to the pooled layer (F <= 64)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
   const MidLds L = carve(smem, npad, emax, DD * nkc, KPAD, false);
@@ -805,9 +830,11 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
     pmax.lo = pmax.hi = f32x2{-INFINITY, -INFINITY};
     psum.lo = psum.hi = f32x2{0.f, 0.f};
     float* out_graph = out + (size_t)gcur.nbase * ldo + coff;
-    for (int u = wave; u < gcur.nblk * 2; u += MW) {      // units of 16 rows
-      if (!csr_route) mid_agg_unit<false, POOL>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum);
-      else mid_agg_unit<true, POOL>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum);
+    unsigned sgn = 0, mxb = 0;                             // BITS: this lane's rows, see mid_agg_unit
+    int kb4 = 0;
+    for (int u = wave; u < gcur.nblk * 2; u += MW, kb4 += 4) {      // units of 16 rows (at most two per wave: nblk <= 7)
+      if (!csr_route) mid_agg_unit<false, POOL, false, BITS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4);
+      else mid_agg_unit<true, POOL, false, BITS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4);
     }
     MSTAMP(9);
     if (POOL) {   // rows of this lane's (r4, q) slot -> wave (the four 16-lane rows) -> workgroup (LDS, fixed order)
@@ -829,11 +856,30 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
         if (gcur.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * ldo + coff + tid] = m;                                   // [max | mean], each ldo wide
         emb[(size_t)g * 2 * ldo + ldo + coff + tid] = sum / (float)(gcur.n > 0 ? gcur.n : 1);
+        if (BITS) L.red[tid] = m;      // (wave 0's slot of this column: this thread was its only reader)
       }
     }
     MSTAMP(10);
     __syncthreads();   // the tile, the slot table and the combine scratch are free for the next graph
     MSTAMP(11);
+    if constexpr (BITS) {
+      // the graph's column maxima are known: a row attains one iff it attains the lane's own maximum and that IS the graph's
+      // (L.red is next written two barriers into the next graph)
+      const int q = lane & 15, r4 = lane >> 4;
+      const float4 gm = *reinterpret_cast<const float4*>(L.red + 4 * q);
+      const unsigned keep = (pmax.lo.x == gm.x ? 0x11111111u : 0u) | (pmax.lo.y == gm.y ? 0x22222222u : 0u) |
+                            (pmax.hi.x == gm.z ? 0x44444444u : 0u) | (pmax.hi.y == gm.w ? 0x88888888u : 0u);
+      mxb &= keep;
+      unsigned char* bits_graph = poolbits + (size_t)gcur.nbase * (ldo >> 2) + (coff >> 2) + q;
+      unsigned k4 = 0;
+      for (int u = wave; u < gcur.nblk * 2; u += MW) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass, k4 += 4) {
+          const int row = u * 16 + pass * 4 + r4;
+          if (row < gcur.n) bits_graph[(size_t)row * (ldo >> 2)] = (unsigned char)(((sgn >> k4) & 0xfu) | (((mxb >> k4) & 0xfu) << 4));
+        }
+      }
+    }
 #ifdef HCG_MID_STAMP
     ++mstamp_it;
 #endif
@@ -1307,13 +1353,15 @@ extern "C" int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_gra
 extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
                                  const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
                                  int64_t max_nodes, int64_t max_edges, float slope, int apply_act, float* out, float* emb,
-                                 int32_t* status, hcg_stream_t stream_) {
+                                 uint8_t* poolbits, int32_t* status, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
-  if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (!x || !W || !b || !graph_ptr || !edge_ptr || (!out && !poolbits) || !status || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  // the bit form (training, pooled layer: `out` is not written) exists for F <= 64 on graphs of more than 64 nodes
+  if (poolbits && (!emb || F > 64 || hcg_w64_applicable(F, D, max_nodes, max_edges))) return HCG_ERR_UNSUPPORTED;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy; no graph has edges
   // graphs up to 64 nodes: one graph per WAVE (wave.hip).  (Round 3 measured this kernel's rebuilt forward on them instead:
   // equal at 4096 graphs of 37-63 atoms -- 49.5 / 47.2 against 49.5 / 48.0 us -- and 18.1 / 17.6 against 19.2 / 19.2 us on the
@@ -1325,18 +1373,20 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   const int nimg = F > 64 ? (int)((F + 63) / 64) : 1;                 // K-chunk weight images kept resident (MULTIK)
   const size_t lds = mid_lds_bytes(npad, emax, DD * nimg, kpad, false);
   const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
-#define LAUNCH_MID_FWD(KP, PL, MK, VC, NRC)                                                                                \
+#define LAUNCH_MID_FWD(KP, PL, MK, VC, NRC, BT)                                                                            \
   do {                                                                                                                     \
-    auto kfn = k_mid_layer_fwd<KP, PL, MK, VC, NRC>;                                                                       \
-    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK, VC, NRC>>();                                                  \
+    auto kfn = k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT>;                                                                   \
+    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT>>();                                              \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
     hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, Wh, bh, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,    \
-                       emax, slope, apply_act, out, (int)D, coff, emb, status);                                            \
+                       emax, slope, apply_act, out, (int)D, coff, emb, status, poolbits);                                  \
   } while (0)
+#define LAUNCH_MID_FWD_V(KP, PL, NRC, BT)                                                                                  \
+  do { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, NRC, BT); else LAUNCH_MID_FWD(KP, PL, false, false, NRC, BT); } while (0)
 #define LAUNCH_MID_FWD_X(KP, PL)                                                                                           \
   do {                                                                                                                     \
-    if (npad <= 128) { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, 128); else LAUNCH_MID_FWD(KP, PL, false, false, 128); } \
-    else { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, MID_MAX_NODES); else LAUNCH_MID_FWD(KP, PL, false, false, MID_MAX_NODES); } \
+    if (PL && poolbits) { if (npad <= 128) LAUNCH_MID_FWD_V(KP, true, 128, true); else LAUNCH_MID_FWD_V(KP, true, MID_MAX_NODES, true); } \
+    else { if (npad <= 128) LAUNCH_MID_FWD_V(KP, PL, 128, false); else LAUNCH_MID_FWD_V(KP, PL, MID_MAX_NODES, false); }    \
   } while (0)
   const bool vec = F == kpad && ((uintptr_t)x % 16 == 0);     // whole float4 rows in the x prefetch
   for (int half = 0; half < (int)(D / DD); ++half) {     // 64 output columns per launch
@@ -1345,10 +1395,11 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
     const int coff = half * DD;
     if (kpad == 32)   { if (emb) LAUNCH_MID_FWD_X(32, true); else LAUNCH_MID_FWD_X(32, false); }
     else if (F <= 64) { if (emb) LAUNCH_MID_FWD_X(64, true); else LAUNCH_MID_FWD_X(64, false); }
-    else              { if (emb) LAUNCH_MID_FWD(64, true, true, false, 32); else LAUNCH_MID_FWD(64, false, true, false, 32); }
+    else              { if (emb) LAUNCH_MID_FWD(64, true, true, false, 32, false); else LAUNCH_MID_FWD(64, false, true, false, 32, false); }
     HCG_CHECK_LAUNCH();
   }
 #undef LAUNCH_MID_FWD_X
+#undef LAUNCH_MID_FWD_V
 #undef LAUNCH_MID_FWD
   return HCG_OK;
 }

@@ -550,12 +550,17 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // The chain barrier -> LDS turn-around of the next weight chunk -> dependent MFMA chains per k-step is what they share; a
 // resident weight image would remove it and does not fit beside the tile.  PMC (profiles/r02_e_traffic_C5.txt): ~300 MB
 // per launch for 210 MB of operands -- the 9-33 spilled registers of this kernel and weight chunks that miss L2.
-template <bool POOL>
+// BITS (needs POOL; the pooled layer of a training step): `out` is not written -- one byte per (row, 4 columns) leaves
+// instead (low nibble: the value is positive, high nibble: it is its graph's column maximum; mid.hip: mid_agg_unit has the
+// scheme), all the pooled backward (k_gseg_bwd<.., BITS>) needs of the layer's output.
+template <bool POOL, bool BITS = false>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,
                                                    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
                                                    const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int apply_act,
-                                                   float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status) {
+                                                   float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status,
+                                                   unsigned char* __restrict__ poolbits = nullptr) {
+  static_assert(!BITS || POOL, "the bit form belongs to the pooled layer");
   constexpr int D = SEG_D;
   __shared__ SegLdsT<false> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -669,6 +674,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
       xrows.load(src, F, gnext);                      // (requested before the MFMA loop instead: the same ~5 us of exposed load
     }                                                 //  time per graph moves into that phase -- measured equal, more spills)
     float4 pmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), psum = f4_zero();
+    unsigned sgn = 0, mxb = 0;                         // BITS: nibble j = this thread's row rg + 32 j, bit c = column 4 c4 + c
 #pragma unroll
     for (int j = 0; j < SEG_RPT; ++j) {
       if (j * 32 < gi.n) {                             // (block-uniform: the tail loop of seg_row_sum votes per wave)
@@ -681,7 +687,19 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
         float4 y = make_float4(fmaf(di, acc.x, bq.x), fmaf(di, acc.y, bq.y), fmaf(di, acc.z, bq.z), fmaf(di, acc.w, bq.w));
         if (apply_act) { y.x = fmaxf(y.x, slope * y.x); y.y = fmaxf(y.y, slope * y.y); y.z = fmaxf(y.z, slope * y.z); y.w = fmaxf(y.w, slope * y.w); }
         if (valid) {
-          *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * D + 4 * c4) = y;
+          if constexpr (BITS) {
+            const float yv[4] = {y.x, y.y, y.z, y.w}, mv[4] = {pmax.x, pmax.y, pmax.z, pmax.w};
+            unsigned sn = 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              sn |= (unsigned)(yv[cc] > 0.f) << cc;
+              const unsigned bit = 1u << (4 * j + cc), colmask = 0x11111111u << cc;
+              mxb = yv[cc] > mv[cc] ? ((mxb & ~colmask) | bit) : (yv[cc] == mv[cc] ? (mxb | bit) : mxb);
+            }
+            sgn |= sn << (4 * j);
+          } else {
+            *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * D + 4 * c4) = y;
+          }
           if (POOL) {
             pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
             f4_add(psum, y);
@@ -689,6 +707,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
         }
       }
     }
+    const float4 own_max = pmax;                       // (BITS: this thread's own maxima, before the combine)
     if (POOL) {      // the two row slots of a wave (xor 32) -> workgroup (LDS, fixed order over the waves)
       pmax = make_float4(fmaxf(pmax.x, __shfl_xor(pmax.x, 32, 64)), fmaxf(pmax.y, __shfl_xor(pmax.y, 32, 64)),
                          fmaxf(pmax.z, __shfl_xor(pmax.z, 32, 64)), fmaxf(pmax.w, __shfl_xor(pmax.w, 32, 64)));
@@ -709,11 +728,26 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
         if (gi.n <= 0) m = 0.f;
         emb[(size_t)g * 2 * D + tid] = m;
         emb[(size_t)g * 2 * D + D + tid] = s / (float)(gi.n > 0 ? gi.n : 1);
+        if (BITS) red[tid] = m;        // (wave 0's slot of this column: this thread was its only reader)
       }
     }
     SSTAMP(sit, 4);
     __syncthreads();   // the tile, the CSR and the combine scratch are free for the next graph
     SSTAMP(sit, 5);
+    if constexpr (BITS) {
+      // (`red` aliases the weight-chunk buffers: their next write sits behind the barriers of the next graph's CSR build)
+      const float4 gm = *reinterpret_cast<const float4*>(red + 4 * c4);
+      const unsigned keep = (own_max.x == gm.x ? 0x11111111u : 0u) | (own_max.y == gm.y ? 0x22222222u : 0u) |
+                            (own_max.z == gm.z ? 0x44444444u : 0u) | (own_max.w == gm.w ? 0x88888888u : 0u);
+      mxb &= keep;
+      unsigned char* bits_graph = poolbits + (size_t)gi.nbase * (D / 4) + c4;
+#pragma unroll
+      for (int j = 0; j < SEG_RPT; ++j) {
+        const int row = rg + 32 * j;
+        if (j * 32 < gi.n && row < gi.n)
+          bits_graph[(size_t)row * (D / 4)] = (unsigned char)(((sgn >> (4 * j)) & 0xfu) | (((mxb >> (4 * j)) & 0xfu) << 4));
+      }
+    }
   }
 }
 
@@ -892,17 +926,22 @@ struct GS {
   }
 };
 
-template <int D, int NT, int NMAX, bool POOLG, bool TWO>
+// BITS (needs POOLG): the pooled layer's output was never stored; one byte per (row, 4 columns) -- low nibble: the value is
+// positive, high nibble: it is its graph's column maximum -- written by the forward's bit form (mid.hip: mid_agg_unit,
+// k_seg_fwd<POOL, BITS>) stands in for `a_out` AND `emb`: a sixteenth of the bytes, and no equality tests against the maxima.
+template <int D, int NT, int NMAX, bool POOLG, bool TWO, bool BITS = false>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb, const float* __restrict__ a_out,
     const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ edge_ptr, int B,
-    int npad, float slope, int act_here, float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status, int ld) {
+    int npad, float slope, int act_here, float* __restrict__ Z, float* __restrict__ db_slabs, int32_t* __restrict__ status, int ld,
+    const unsigned char* __restrict__ poolbits = nullptr) {
+  static_assert(!BITS || (POOLG && !TWO), "the bit form is the pooled backward");
   // `ld` = row length of the tensors (a layer `ld` columns wide is handled as ld / D independent column groups, blockIdx.y:
   // the sums never mix columns, and D = 64 column groups of a 128-wide layer leave room for two workgroups per CU)
   const int coff = blockIdx.y * D;
   using G = GS<D, NT, NMAX>;
   constexpr int LPR = G::LPR, RPP = G::RPP, RPT = G::RPT, TS = G::TS, NW = G::NW;
-  constexpr bool NEED_A = POOLG || TWO;
+  constexpr bool NEED_A = (POOLG || TWO) && !BITS;
   __shared__ typename G::Lds L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);          // [npad][TS]
@@ -913,15 +952,27 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
   SegGraph gnext;
   typename G::Edges er;
   typename G::Rows drows, arows;
+  unsigned char brows[BITS ? RPT : 1];                 // BITS: this thread's byte of each of its rows
   float4 gmx = f4_zero(), dmx = f4_zero(), dmean = f4_zero();
   auto request = [&](int g) {                          // everything of graph g this thread will need: loads only
     gnext = seg_graph(g, graph_ptr, edge_ptr, npad, status);
     er.load(gnext, ei, E);
     if (!POOLG) drows.load(dout + coff, gnext, ld);
     if (NEED_A) arows.load(a_out + coff, gnext, ld);
+    if constexpr (BITS) {
+      const unsigned ldb = (unsigned)ld >> 2;
+      const unsigned char* base = poolbits + (size_t)gnext.nld * ldb + (coff >> 2) + c4;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        if (j * RPP < gnext.n) {
+          const int row = rg + RPP * j;
+          brows[j] = base[__umul24((unsigned)(row < gnext.n ? row : gnext.n - 1), ldb)];
+        }
+      }
+    }
     if (POOLG) {
       const size_t eb = (size_t)g * 2 * ld + coff + 4 * c4;      // [max | mean], each ld wide
-      gmx = *reinterpret_cast<const float4*>(emb + eb);
+      if (!BITS) gmx = *reinterpret_cast<const float4*>(emb + eb);
       dmx = *reinterpret_cast<const float4*>(demb + eb);
       dmean = *reinterpret_cast<const float4*>(demb + eb + ld);
     }
@@ -939,8 +990,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
         if (j * RPP < gi.n && rg + RPP * j < gi.n) {
-          const float4 a = arows.v[j];
-          ties.x += (a.x == gm.x); ties.y += (a.y == gm.y); ties.z += (a.z == gm.z); ties.w += (a.w == gm.w);
+          if constexpr (BITS) {
+            const unsigned bv = brows[j];
+            ties.x += (float)(bv >> 4 & 1u); ties.y += (float)(bv >> 5 & 1u); ties.z += (float)(bv >> 6 & 1u); ties.w += (float)(bv >> 7 & 1u);
+          } else {
+            const float4 a = arows.v[j];
+            ties.x += (a.x == gm.x); ties.y += (a.y == gm.y); ties.z += (a.z == gm.z); ties.w += (a.w == gm.w);
+          }
         }
       }
       ties = G::fold(ties);
@@ -957,7 +1013,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void k_gseg_bwd(
       if (j * RPP < gi.n && row < gi.n) {
         float4 a = f4_zero(), gq;
         if (NEED_A) a = arows.v[j];
-        if (POOLG) {
+        if constexpr (BITS) {
+          const unsigned bv = brows[j];
+          gq = make_float4(dmn.x + ((bv & 0x10u) ? share.x : 0.f), dmn.y + ((bv & 0x20u) ? share.y : 0.f),
+                           dmn.z + ((bv & 0x40u) ? share.z : 0.f), dmn.w + ((bv & 0x80u) ? share.w : 0.f));
+          if (act_here) {
+            gq.x *= (bv & 1u) ? 1.f : slope; gq.y *= (bv & 2u) ? 1.f : slope;
+            gq.z *= (bv & 4u) ? 1.f : slope; gq.w *= (bv & 8u) ? 1.f : slope;
+          }
+        } else if (POOLG) {
           gq = make_float4(dmn.x + (a.x == gm.x ? share.x : 0.f), dmn.y + (a.y == gm.y ? share.y : 0.f),
                            dmn.z + (a.z == gm.z ? share.z : 0.f), dmn.w + (a.w == gm.w ? share.w : 0.f));
         } else {
@@ -1077,16 +1141,18 @@ extern "C" size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int6
 extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
                                   int64_t max_nodes, int64_t max_edges, float slope, int apply_act, float* out, float* emb,
-                                  int32_t* status, void* workspace, size_t workspace_bytes, hcg_stream_t stream_) {
+                                  uint8_t* poolbits, int32_t* status, void* workspace, size_t workspace_bytes,
+                                  hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_tall_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
   if (D == 64)     // (64-wide layers: only the backward is cut this way)
     return hcg_mid_layer_fwd(x, W, b, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, max_nodes, max_edges, slope, apply_act, out, emb,
-                             status, stream_);
+                             poolbits, status, stream_);
+  if (poolbits && !emb) return HCG_ERR_INVALID_ARG;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
-  if (!x || !W || !b || !graph_ptr || !edge_ptr || !out || !status || !workspace || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
+  if (!x || !W || !b || !graph_ptr || !edge_ptr || (!out && !poolbits) || !status || !workspace || (E > 0 && !edge_index)) return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
   if (N > (int64_t)INT32_MAX / 2) return HCG_ERR_UNSUPPORTED;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
@@ -1103,9 +1169,13 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
     HCG_CHECK_LAUNCH();
     const size_t lds = slds + wbuf, lds_max = 160 * 1024 - 512 - sizeof(SegLdsT<false>);
     if (lds > lds_max) return HCG_ERR_UNSUPPORTED;
-    hipError_t e = emb ? allow_lds<k_seg_fwd<true>>(lds_max) : allow_lds<k_seg_fwd<false>>(lds_max);
+    hipError_t e = poolbits ? allow_lds<k_seg_fwd<true, true>>(lds_max)
+                            : (emb ? allow_lds<k_seg_fwd<true>>(lds_max) : allow_lds<k_seg_fwd<false>>(lds_max));
     if (e != hipSuccess) return hcg_hip_err(e);
-    if (emb)
+    if (poolbits)
+      hipLaunchKernelGGL((k_seg_fwd<true, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
+                         graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status, poolbits);
+    else if (emb)
       hipLaunchKernelGGL((k_seg_fwd<true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
                          graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status);
     else
@@ -1119,7 +1189,8 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
 // dout == NULL selects the pooled form (upstream gradient = demb [B, 2D], expanded on chip with `emb` and `out`).
 // apply_act: bit 0 = multiply the upstream gradient by leaky'(out); bit 1 = hand dx down already multiplied by leaky'(x).
 // Leaves dW / db slabs in `workspace`: describe them with hcg_tall_reduce_jobs (two jobs) and sum with hcg_step_tail.
-extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out, const float* x,
+extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
+                                  const uint8_t* poolbits, const float* x,
                                   const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                   const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
                                   int64_t max_edges, float slope, int apply_act, float* dx, int32_t* status, void* workspace,
@@ -1130,9 +1201,11 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
     return HCG_ERR_INVALID_ARG;
   if (N > (int64_t)INT32_MAX / 2) return HCG_ERR_UNSUPPORTED;
   const bool poolg = (dout == nullptr);
-  if (poolg && (!demb || !emb)) return HCG_ERR_INVALID_ARG;
+  const bool bits = poolbits != nullptr;      // the forward's bit form stands in for `out` and `emb`
+  if (bits && !poolg) return HCG_ERR_INVALID_ARG;
+  if (poolg && (!demb || (!emb && !bits))) return HCG_ERR_INVALID_ARG;
   if ((apply_act & ~3) || ((apply_act & 2) && !dx)) return HCG_ERR_INVALID_ARG;
-  if ((poolg || (apply_act & 1)) && !out) return HCG_ERR_INVALID_ARG;
+  if ((poolg || (apply_act & 1)) && !out && !bits) return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }
   const TallWs ws = tall_carve(workspace, N, B, F, D);
@@ -1141,19 +1214,20 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
     const int npad = seg_npad(max_nodes);
     const dim3 sgrid(seg_grid64(B), (unsigned)(D / 64));
     const size_t slds = (size_t)npad * (64 + 4) * sizeof(float);
-#define LAUNCH_GSEG(NTV, NMAXV, PG, TW2, AOUT)                                                                             \
+#define LAUNCH_GSEG(NTV, NMAXV, PG, TW2, AOUT, BT)                                                                         \
   do {                                                                                                                     \
-    hipError_t e = allow_lds<k_gseg_bwd<64, NTV, NMAXV, PG, TW2>>((size_t)NMAXV * 68 * sizeof(float));                    \
+    hipError_t e = allow_lds<k_gseg_bwd<64, NTV, NMAXV, PG, TW2, BT>>((size_t)NMAXV * 68 * sizeof(float));                \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
-    hipLaunchKernelGGL((k_gseg_bwd<64, NTV, NMAXV, PG, TW2>), sgrid, dim3(NTV), slds, stream, dout, demb, emb, AOUT,       \
+    hipLaunchKernelGGL((k_gseg_bwd<64, NTV, NMAXV, PG, TW2, BT>), sgrid, dim3(NTV), slds, stream, dout, demb, emb, AOUT,   \
                        edge_index, E, graph_ptr, edge_ptr, (int)B, npad, slope, act_here, ws.inter, ws.db_slabs, status,   \
-                       (int)D);                                                                                            \
+                       (int)D, poolbits);                                                                                  \
   } while (0)
 #define DISPATCH_GSEG(NTV, NMAXV)                                                                                          \
   do {                                                                                                                     \
-    if (poolg) LAUNCH_GSEG(NTV, NMAXV, true, false, out);                                                                  \
-    else if (act_here) LAUNCH_GSEG(NTV, NMAXV, false, true, out);                                                          \
-    else LAUNCH_GSEG(NTV, NMAXV, false, false, (const float*)nullptr);                                                     \
+    if (bits) LAUNCH_GSEG(NTV, NMAXV, true, false, (const float*)nullptr, true);                                           \
+    else if (poolg) LAUNCH_GSEG(NTV, NMAXV, true, false, out, false);                                                      \
+    else if (act_here) LAUNCH_GSEG(NTV, NMAXV, false, true, out, false);                                                   \
+    else LAUNCH_GSEG(NTV, NMAXV, false, false, (const float*)nullptr, false);                                              \
   } while (0)
     if (npad <= 128) DISPATCH_GSEG(256, 128); else DISPATCH_GSEG(512, 224);
 #undef DISPATCH_GSEG

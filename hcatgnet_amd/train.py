@@ -382,13 +382,18 @@ class FusedTrainStep:
                                    status=plan.status)
             elif c.tall[l]:
                 ws, wsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
+                bits = None
+                if pe is not None and self.POOLBITS and Fl <= (64 if D == 64 else 128):
+                    # the pooled layer's activations stay on chip: one byte per (row, 4 columns) -- sign, is-the-column-max --
+                    # is all its backward (csrc/tall.hip: k_gseg_bwd) needs of them
+                    bits = c.poolbits = self._ws(bufs, "poolbits_tall", N * (D // 4), c.dev)
                 rc = lib.hcg_tall_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                            p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe),
-                                            p(plan.status), p(ws), wsb, stream)
+                                            p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, None if bits is not None else p(acts[l]),
+                                            p(pe), p(bits), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_tall_layer_fwd")
             else:
                 rc = lib.hcg_mid_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe),
+                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe), None,
                                            p(plan.status), stream)
                 _lib.check(rc, "hcg_mid_layer_fwd")
             h = acts[l]
@@ -409,9 +414,9 @@ class FusedTrainStep:
         fork()
         _lib.fused_forward(**self._tiles_args(c, Bs, gpt, poolbits=c.poolbits))
         _lib.check(lib.hcg_mid_layer_fwd(p(c.x), p(c.W[0]), p(c.bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.F, c.D,
-                                         mxn, mxe, slope, 1, p(acts[0]), None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+                                         mxn, mxe, slope, 1, p(acts[0]), None, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
         _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(c.W[1]), p(c.bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.D,
-                                         c.D, mxn, mxe, slope, 1, p(acts[1]), emb_b, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+                                         c.D, mxn, mxe, slope, 1, p(acts[1]), emb_b, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
         join()
         return gpt
 
@@ -489,8 +494,11 @@ class FusedTrainStep:
                     #  4-byte strided loads in the dense kernel's epilogue for the same bytes)
                     premasked = False
                     tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
-                    rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if (act or last) else None, p(inp), p(c.W[l]), *geo, mxn, mxe,
-                                                slope, act, p(dx), p(plan.status), p(tws), twsb, stream)
+                    bits = c.poolbits if last else None          # (the forward's bit form stands in for the layer's output and emb)
+                    if bits is not None:
+                        up = (None, p(bufs["demb"]), None)
+                    rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if ((act or last) and bits is None) else None, p(bits), p(inp),
+                                                p(c.W[l]), *geo, mxn, mxe, slope, act, p(dx), p(plan.status), p(tws), twsb, stream)
                     _lib.check(rc, "hcg_tall_layer_bwd")
                     _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, g(cv.lin.weight), g(cv.bias),
                                                         self._job_slot(c)), "hcg_tall_reduce_jobs")

@@ -249,7 +249,8 @@ size_t hcg_mid_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t max_node
 int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
                       const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                       int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
-                      float slope, int apply_act, float* out, float* emb /*nullable*/, int32_t* status,
+                      float slope, int apply_act, float* out, float* emb /*nullable*/,
+                      uint8_t* poolbits /*nullable: see hcg_tall_layer_fwd*/, int32_t* status,
                       hcg_stream_t stream);
 int hcg_mid_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
                       const float* out, const float* x, const float* W,
@@ -271,10 +272,16 @@ size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int64_t D);
 int hcg_tall_layer_fwd(const float* x, const float* W, const float* b,
                        const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                        int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
-                       float slope, int apply_act, float* out, float* emb /*nullable*/, int32_t* status,
+                       float slope, int apply_act, float* out, float* emb /*nullable*/,
+                       uint8_t* poolbits /*nullable*/, int32_t* status,
                        void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+/* `poolbits` [N, D / 4] bytes (training form of the POOLED layer, needs emb; F <= 64 for D = 64): the layer's output is
+ * NOT written (`out` may be NULL) -- one byte per (row, 4 columns) leaves instead: bits 0-3 = the value is positive
+ * (LeakyReLU'), bits 4-7 = it is its graph's column maximum (where global_max_pool's gradient goes, ties included).  Given
+ * to hcg_tall_layer_bwd (pooled form: dout = NULL) they stand in for `out` AND `emb` (both may be NULL): a sixteenth of the
+ * bytes on both sides of the step. */
 int hcg_tall_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
-                       const float* out, const float* x, const float* W,
+                       const float* out, const uint8_t* poolbits /*nullable*/, const float* x, const float* W,
                        const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                        int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
                        float slope, int apply_act, float* dx /*nullable*/, int32_t* status,

@@ -121,7 +121,7 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
         dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
         dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
-        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                           p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
                                           st), "hcg_tall_layer_bwd")
         jb = _lib.job_bytes()
@@ -141,3 +141,34 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
     _, dW_d, db_d = bwd(dx_pm, None, x0, W0, 64, 0, want_dx=False)
     assert torch.equal(dW_c, dW_d) and torch.equal(db_c, db_d)
     assert plan.check_status() == 0
+
+
+@pytest.mark.parametrize("D,F,nodes,jitter,B", [(64, 25, 100, 17, 400), (64, 64, 160, 30, 260), (128, 64, 150, 20, 24), (128, 128, 200, 24, 12)])
+def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, D, F, nodes, jitter, B):
+    """Training form of the pooled layer on the wide-layer route (`poolbits` of hcg_tall_layer_fwd / hcg_tall_layer_bwd): its
+    activations never leave the chip -- one byte per (row, 4 columns) does (sign, is-the-column-max).  Loss, outputs, pooled
+    embedding and EVERY gradient are BITWISE those of the plain form (output + emb read back), with exact max-pool ties in the
+    batch (a graph of identical rows: its equal-degree nodes tie).  (Against the oracle: the full-size and fuzz tests run this
+    form, it is the default.)"""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_batch(num_graphs=B, nodes=nodes, nodes_jitter=jitter, feat=F, extra_bonds=4, max_degree=4, seed=77)
+    gp = torch.zeros(B + 1, dtype=torch.int64)
+    gp[1:] = torch.bincount(sb.batch, minlength=B).cumsum(0)
+    sb.x[gp[0]:gp[1]] = sb.x[0]                                # graph 0: identical rows -> equal-degree nodes tie exactly
+    params = _rand_params(F, D, seed=5)
+    res = []
+    for bits in (True, False):
+        m = _model_from_params(H, params)
+        step = FusedTrainStep(m, optimizer_step=False)
+        step.POOLBITS = bits
+        batch = sb.as_batch("cuda")
+        assert step.reason(batch) is None
+        loss = step(batch)
+        assert batch._hcg_plan.check_status() == 0
+        cap = step._bufs["cap"]
+        assert ("poolbits_tall" in cap["ws"]) == bits, "the wide-layer route / its bit form did not run"
+        res.append((loss.clone(), step._flat.clone(), cap["emb"][:B].clone(), step.last_out.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(res[0][1]).all()) and float(res[0][1].abs().max()) > 0
