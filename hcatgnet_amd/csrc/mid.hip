@@ -508,6 +508,74 @@ __device__ __forceinline__ Quad ldq(const char* p) {
   return q;
 }
 
+// Z = Ahat x of a unit of 16 rows, from the x tile BEFORE the GEMM overwrites it (training form of the FIRST layer: with Z
+// its weight gradient is the dense product G^T Z, G = dA (.) leaky'(A) -- no transpose sum, no dH round trip: csrc/tall.hip).
+// KPAD / 4 lanes per row.  The slots may not be sorted yet (the row's dinv lane sorts them concurrently: an 8-byte LDS read
+// sees one order or the other) and dinv may not be written yet: the lane sorts its copy and derives every dinv from the
+// in-degree counters with the expression the dinv lanes use (bitwise the same values); the CSR route reads both finished.
+template <int KPAD, bool CSR>
+__device__ __forceinline__ void mid_zagg_unit(const MidLds& L, int u, int n, int npad, unsigned empty_id, float* __restrict__ z_graph) {
+  constexpr int LPRQ = KPAD / 4, RPP = 64 / LPRQ, NP = 16 / RPP;
+  const int lane = threadIdx.x & 63, qq = lane % LPRQ, rr = lane / LPRQ;
+  const char* tq = reinterpret_cast<const char*>(L.t0 + 4 * qq);
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    const int row = u * 16 + pass * RPP + rr;
+    unsigned a0, a1, a2, a3;
+    int kb = 0, ke = 0;
+    float di;
+    if constexpr (!CSR) {
+      const uint2 nb = *reinterpret_cast<const uint2*>(L.nbr + row * NSLOT);
+      unsigned t;
+      a0 = nb.x & 0xffffu; a1 = nb.x >> 16; a2 = nb.y & 0xffffu; a3 = nb.y >> 16;
+      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
+      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
+      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
+      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
+      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
+      di = 1.0f / sqrtf(1.0f + (float)L.cursor[row]);
+    } else {
+      kb = L.rowptr[row];
+      ke = L.rowptr[row + 1];
+      a0 = kb + 0 < ke ? L.col[kb + 0] : empty_id;
+      a1 = kb + 1 < ke ? L.col[kb + 1] : empty_id;
+      a2 = kb + 2 < ke ? L.col[kb + 2] : empty_id;
+      a3 = kb + 3 < ke ? L.col[kb + 3] : empty_id;
+      di = L.dinv[row];
+    }
+    // an empty slot names the all-zero row; its factor only has to be finite: the last real row's
+    const unsigned last = (unsigned)npad - 1u;
+    auto dof = [&](unsigned a) -> float {
+      const unsigned i = a < last ? a : last;
+      if constexpr (!CSR) return 1.0f / sqrtf(1.0f + (float)L.cursor[i]);
+      else return L.dinv[i];
+    };
+    const float d0 = dof(a0), d1 = dof(a1), d2 = dof(a2), d3 = dof(a3);
+    Quad acc = ldq(tq + __umul24((unsigned)row, HS * 4u));
+    const Quad n0 = ldq(tq + __umul24(a0, HS * 4u)), n1 = ldq(tq + __umul24(a1, HS * 4u));
+    const Quad n2 = ldq(tq + __umul24(a2, HS * 4u)), n3 = ldq(tq + __umul24(a3, HS * 4u));
+    acc.lo = f32x2{di, di} * acc.lo; acc.hi = f32x2{di, di} * acc.hi;
+    acc.lo = __builtin_elementwise_fma(f32x2{d0, d0}, n0.lo, acc.lo); acc.hi = __builtin_elementwise_fma(f32x2{d0, d0}, n0.hi, acc.hi);
+    acc.lo = __builtin_elementwise_fma(f32x2{d1, d1}, n1.lo, acc.lo); acc.hi = __builtin_elementwise_fma(f32x2{d1, d1}, n1.hi, acc.hi);
+    acc.lo = __builtin_elementwise_fma(f32x2{d2, d2}, n2.lo, acc.lo); acc.hi = __builtin_elementwise_fma(f32x2{d2, d2}, n2.hi, acc.hi);
+    acc.lo = __builtin_elementwise_fma(f32x2{d3, d3}, n3.lo, acc.lo); acc.hi = __builtin_elementwise_fma(f32x2{d3, d3}, n3.hi, acc.hi);
+    if constexpr (CSR) {
+      for (int k = kb + NSLOT; __any(k < ke); ++k) {
+        if (k < ke) {
+          const unsigned c = L.col[k];
+          const float dc = L.dinv[c];
+          const Quad v = ldq(tq + __umul24(c, HS * 4u));
+          acc.lo = __builtin_elementwise_fma(f32x2{dc, dc}, v.lo, acc.lo); acc.hi = __builtin_elementwise_fma(f32x2{dc, dc}, v.hi, acc.hi);
+        }
+      }
+    }
+    if (row < n) {
+      const f32x2 lo = f32x2{di, di} * acc.lo, hi = f32x2{di, di} * acc.hi;
+      *reinterpret_cast<float4*>(z_graph + (size_t)row * KPAD + 4 * qq) = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
+}
+
 // TO_TILE (the backward's transpose sum): dH_row = dinv_row * sum goes to the second tile `t1` for EVERY row of the unit
 // (rows past the graph are zero), no epilogue.
 // BITS (needs POOL; the pooled layer of a training step whose backward is csrc/tall.hip's): the unit's outputs are NOT
@@ -516,10 +584,14 @@ __device__ __forceinline__ Quad ldq(const char* p) {
 // known.  Until then a lane keeps two 32-bit masks for its <= 8 rows (nibble k = its k-th row, bit c = column 4 q + c):
 // `sgn`, and `mxb` = the rows that attain the lane's OWN running maximum `pmax` (reset when a larger value arrives, joined on
 // equality) -- a row is a maximum of the graph iff it is one of the lane's and the lane's maximum equals the graph's.
-template <bool CSR, bool POOL, bool TO_TILE = false, bool BITS = false>
+// SIGNS (training form of the FIRST layer, 64 columns): besides its output a row leaves four 16-bit pieces, piece j bit q =
+// (column 4 q + j is positive) -- exactly what one v_cmp per register of the quad layout produces wave-wide -- for the
+// dense first-layer backward of csrc/tall.hip, which then never reads this output.
+template <bool CSR, bool POOL, bool TO_TILE = false, bool BITS = false, bool SIGNS = false>
 __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsigned empty_id, const Quad& bq, float slope_eff,
                                              float* __restrict__ out_graph, int ldo, Quad& pmax, Quad& psum,
-                                             unsigned* sgn = nullptr, unsigned* mxb = nullptr, int kbase = 0) {
+                                             unsigned* sgn = nullptr, unsigned* mxb = nullptr, int kbase = 0,
+                                             unsigned short* __restrict__ sign_graph = nullptr) {
   const int lane = threadIdx.x & 63, q = lane & 15, r4 = lane >> 4;
   const char* tq = reinterpret_cast<const char*>(L.t0 + 4 * q);
   uint2 nb[4];
@@ -599,6 +671,14 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
       } else {
         *reinterpret_cast<float4*>(out_graph + (size_t)row * ldo + 4 * q) = make_float4(y.lo.x, y.lo.y, y.hi.x, y.hi.y);
       }
+      if constexpr (SIGNS) {
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(y.lo.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(y.lo.y > 0.f);
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(y.hi.x > 0.f), b3 = __builtin_amdgcn_ballot_w64(y.hi.y > 0.f);
+        if (q < 4) {
+          const unsigned long long bsel = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+          sign_graph[row * 4 + q] = (unsigned short)(bsel >> (16 * r4));
+        }
+      }
       if (POOL) {
         pmax.lo = __builtin_elementwise_max(pmax.lo, y.lo);
         pmax.hi = __builtin_elementwise_max(pmax.hi, y.hi);
@@ -635,15 +715,21 @@ __device__ __forceinline__ void mid_agg_unit(const MidLds& L, int u, int n, unsi
 //  registers instead of silently dropping to one workgroup per CU; MULTIK needs more and runs one workgroup per CU)
 // BITS (needs POOL): `out` is not written; `poolbits` [N][ldo / 4] bytes take its place for the pooled backward of
 // csrc/tall.hip (mid_agg_unit): 91 MB less written here and 91 MB less read there on a 356 k-node batch.
-template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR, bool BITS = false>
+// ZS (training form of the FIRST layer; not POOL, F <= 64, 64 output columns): two more outputs -- `zagg` [N][KPAD] = Ahat x
+// (mid_zagg_unit) and `signs` [N][4] 16-bit sign pieces of the output (mid_agg_unit) -- for csrc/tall.hip's dense first-layer
+// backward.
+template <int KPAD, bool POOL, bool MULTIK, bool VEC, int NR, bool BITS = false, bool ZS = false>
 __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const float* __restrict__ x, int F, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int64_t* __restrict__ ei,
                                                          int64_t E, const int32_t* __restrict__ graph_ptr,
                                                          const int32_t* __restrict__ edge_ptr, int B, int npad, int emax,
                                                          float slope, int apply_act, float* __restrict__ out, int ldo, int coff,
                                                          float* __restrict__ emb, int32_t* __restrict__ status,
-                                                         unsigned char* __restrict__ poolbits = nullptr) {
+                                                         unsigned char* __restrict__ poolbits = nullptr,
+                                                         float* __restrict__ zagg = nullptr,
+                                                         unsigned short* __restrict__ signs = nullptr) {
   static_assert(!BITS || (POOL && !MULTIK), "the bit form belongs to the pooled layer (F <= 64)");
+  static_assert(!ZS || (!POOL && !MULTIK), "Ahat x / sign pieces: the first (not pooled) layer, F <= 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nkc = MULTIK ? (F + KPAD - 1) / KPAD : 1;  // K-chunks (MULTIK: F > 64; compiled apart, it costs registers)
   const MidLds L = carve(smem, npad, emax, DD * nkc, KPAD, false);
@@ -757,6 +843,15 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
       csr_sort_rows(L, gcur);
     }
     MSTAMP(3);
+    if constexpr (ZS) {
+      if (csr_route) __syncthreads();                    // the sorted CSR and every dinv are complete
+      float* z_graph = zagg + (size_t)gcur.nbase * KPAD;
+      for (int u = wave; u < gcur.nblk * 2; u += MW) {
+        if (!csr_route) mid_zagg_unit<KPAD, false>(L, u, gcur.n, npad, empty_id, z_graph);
+        else mid_zagg_unit<KPAD, true>(L, u, gcur.n, npad, empty_id, z_graph);
+      }
+      __syncthreads();                                   // every x row has been read: the GEMM may overwrite the tile
+    }
 
     // ---- H' = dinv (.) (X W^T), in place: wave -> its own 32-row block, both column halves (eight waves on (row block,
     //      column half) blocks were measured: every A fragment is then split twice, and the kernel is bound by VALU issue)
@@ -833,8 +928,9 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
     unsigned sgn = 0, mxb = 0;                             // BITS: this lane's rows, see mid_agg_unit
     int kb4 = 0;
     for (int u = wave; u < gcur.nblk * 2; u += MW, kb4 += 4) {      // units of 16 rows (at most two per wave: nblk <= 7)
-      if (!csr_route) mid_agg_unit<false, POOL, false, BITS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4);
-      else mid_agg_unit<true, POOL, false, BITS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4);
+      unsigned short* sign_graph = ZS ? signs + (size_t)gcur.nbase * 4 : nullptr;
+      if (!csr_route) mid_agg_unit<false, POOL, false, BITS, ZS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4, sign_graph);
+      else mid_agg_unit<true, POOL, false, BITS, ZS>(L, u, gcur.n, empty_id, bq, slope_eff, out_graph, ldo, pmax, psum, &sgn, &mxb, kb4, sign_graph);
     }
     MSTAMP(9);
     if (POOL) {   // rows of this lane's (r4, q) slot -> wave (the four 16-lane rows) -> workgroup (LDS, fixed order)
@@ -1353,9 +1449,12 @@ extern "C" int hcg_mid_supported(int64_t F, int64_t D, int64_t max_nodes_per_gra
 extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
                                  const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
                                  int64_t max_nodes, int64_t max_edges, float slope, int apply_act, float* out, float* emb,
-                                 uint8_t* poolbits, int32_t* status, hcg_stream_t stream_) {
+                                 uint8_t* poolbits, float* xagg, uint8_t* signbits, int32_t* status, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_mid_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
+  // Ahat x + sign pieces (training form of a first, not pooled, 64-wide layer over graphs of more than 64 nodes)
+  if ((xagg == nullptr) != (signbits == nullptr)) return HCG_ERR_INVALID_ARG;
+  if (xagg && (emb || poolbits || D != DD || F > 64 || !out || hcg_w64_applicable(F, D, max_nodes, max_edges))) return HCG_ERR_UNSUPPORTED;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
   if (B == 0 || N == 0) return HCG_OK;
@@ -1373,20 +1472,22 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
   const int nimg = F > 64 ? (int)((F + 63) / 64) : 1;                 // K-chunk weight images kept resident (MULTIK)
   const size_t lds = mid_lds_bytes(npad, emax, DD * nimg, kpad, false);
   const dim3 grid(mid_grid(B, wgs_per_cu(lds))), blk(MT);
-#define LAUNCH_MID_FWD(KP, PL, MK, VC, NRC, BT)                                                                            \
+#define LAUNCH_MID_FWD(KP, PL, MK, VC, NRC, BT, ZSV)                                                                       \
   do {                                                                                                                     \
-    auto kfn = k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT>;                                                                   \
-    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT>>();                                              \
+    auto kfn = k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT, ZSV>;                                                              \
+    hipError_t e = allow_big_lds<k_mid_layer_fwd<KP, PL, MK, VC, NRC, BT, ZSV>>();                                         \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                            \
     hipLaunchKernelGGL(kfn, grid, blk, lds, stream, x, (int)F, Wh, bh, edge_index, E, graph_ptr, edge_ptr, (int)B, npad,    \
-                       emax, slope, apply_act, out, (int)D, coff, emb, status, poolbits);                                  \
+                       emax, slope, apply_act, out, (int)D, coff, emb, status, poolbits, xagg,                             \
+                       reinterpret_cast<unsigned short*>(signbits));                                                       \
   } while (0)
-#define LAUNCH_MID_FWD_V(KP, PL, NRC, BT)                                                                                  \
-  do { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, NRC, BT); else LAUNCH_MID_FWD(KP, PL, false, false, NRC, BT); } while (0)
+#define LAUNCH_MID_FWD_V(KP, PL, NRC, BT, ZSV)                                                                             \
+  do { if (vec) LAUNCH_MID_FWD(KP, PL, false, true, NRC, BT, ZSV); else LAUNCH_MID_FWD(KP, PL, false, false, NRC, BT, ZSV); } while (0)
 #define LAUNCH_MID_FWD_X(KP, PL)                                                                                           \
   do {                                                                                                                     \
-    if (PL && poolbits) { if (npad <= 128) LAUNCH_MID_FWD_V(KP, true, 128, true); else LAUNCH_MID_FWD_V(KP, true, MID_MAX_NODES, true); } \
-    else { if (npad <= 128) LAUNCH_MID_FWD_V(KP, PL, 128, false); else LAUNCH_MID_FWD_V(KP, PL, MID_MAX_NODES, false); }    \
+    if (PL && poolbits) { if (npad <= 128) LAUNCH_MID_FWD_V(KP, true, 128, true, false); else LAUNCH_MID_FWD_V(KP, true, MID_MAX_NODES, true, false); } \
+    else if (!PL && xagg) { if (npad <= 128) LAUNCH_MID_FWD_V(KP, false, 128, false, true); else LAUNCH_MID_FWD_V(KP, false, MID_MAX_NODES, false, true); } \
+    else { if (npad <= 128) LAUNCH_MID_FWD_V(KP, PL, 128, false, false); else LAUNCH_MID_FWD_V(KP, PL, MID_MAX_NODES, false, false); } \
   } while (0)
   const bool vec = F == kpad && ((uintptr_t)x % 16 == 0);     // whole float4 rows in the x prefetch
   for (int half = 0; half < (int)(D / DD); ++half) {     // 64 output columns per launch
@@ -1395,7 +1496,7 @@ extern "C" int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
     const int coff = half * DD;
     if (kpad == 32)   { if (emb) LAUNCH_MID_FWD_X(32, true); else LAUNCH_MID_FWD_X(32, false); }
     else if (F <= 64) { if (emb) LAUNCH_MID_FWD_X(64, true); else LAUNCH_MID_FWD_X(64, false); }
-    else              { if (emb) LAUNCH_MID_FWD(64, true, true, false, 32, false); else LAUNCH_MID_FWD(64, false, true, false, 32, false); }
+    else              { if (emb) LAUNCH_MID_FWD(64, true, true, false, 32, false, false); else LAUNCH_MID_FWD(64, false, true, false, 32, false, false); }
     HCG_CHECK_LAUNCH();
   }
 #undef LAUNCH_MID_FWD_X

@@ -156,9 +156,17 @@ __device__ __forceinline__ constexpr int dw_oct(int c, int o) { return o ^ ((c >
 
 // XVEC = false: X rows are not 16-byte aligned (F no multiple of 4, e.g. the reference's 25 node features): its stagers use
 // dword loads.  D = 64 (DB = 2): 55 KB of images, two workgroups per CU.
-template <int DB, int NBF, bool XVEC = true>
+// FIRST (the first layer's whole backward as ONE dense launch; D = 64): Z = the upstream gradient dA, multiplied on the way
+// in by leaky'(A) from the forward's sign pieces (`signs` [N][4] x 16 bits: piece j bit q = column 4 q + j is positive);
+// X = Ahat x, written by the forward's training form.  dW = (dA (.) leaky')^T (Ahat x) is the same sum as (Ahat^T G)^T x
+// in another order, so the layer needs no transpose sum, no dH round trip and no second launch; the bias gradient -- the
+// column sums of G -- leaves in `db_slabs` [grid][D].
+template <int DB, int NBF, bool XVEC = true, bool FIRST = false>
 __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
-                                                                 float* __restrict__ slabs, int N) {
+                                                                 float* __restrict__ slabs, int N,
+                                                                 const unsigned short* __restrict__ signs = nullptr,
+                                                                 float slope = 1.f, float* __restrict__ db_slabs = nullptr) {
+  static_assert(!FIRST || (DB == 2 && XVEC), "first-layer form: 64 output columns, padded Ahat x rows");
   constexpr int D = DB * 32, FP = NBF * 32, TR = 64, LDT = TR + 8;
   constexpr int NTILE = DB * NBF, TPW = NTILE >= DWW ? NTILE / DWW : 1, KPARTS = NTILE >= DWW ? 1 : DWW / NTILE;
   static_assert(NTILE * KPARTS == DWW * TPW, "block -> wave map");
@@ -195,6 +203,8 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
   static_assert(XVEC || FP * 8 <= DWT, "one X item per thread");
   float4 sv[8];
   float xs[XVEC ? 1 : 8];
+  uint2 sg[FIRST ? 8 : 1];                             // FIRST: the sign pieces of this thread's eight nodes
+  float dbacc[FIRST ? 4 : 1] = {};                     // FIRST: column sums of G over this thread's nodes
   auto load_tile = [&](int t) {
     if (live) {
       const int row0 = t * TR + oct * 8;
@@ -207,6 +217,9 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
         int node = row0 + u;
         if (node > N - 1) node = N - 1;
         sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
+        if constexpr (FIRST) {
+          if (!is_x) sg[u] = *reinterpret_cast<const uint2*>(signs + (size_t)node * 4);
+        }
       }
     }
     if (x_item) {                                       // (wave-uniform: FP * 8 is a multiple of 64)
@@ -230,8 +243,17 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
+          float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
+          if constexpr (FIRST) {
+            if (!is_x) {                               // G = dA (.) leaky'(A): piece i of the node, bit cq
+              const unsigned w = i < 2 ? sg[u].x : sg[u].y;
+              e *= ((w >> (16 * (i & 1) + cq)) & 1u) ? 1.f : slope;
+            }
+          }
           v[u] = (row0 + u < N && c < lim) ? e : 0.f;
+        }
+        if constexpr (FIRST) {
+          if (!is_x) dbacc[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         const Split3 sp = split3(v);
         short* dst = planes + c * LDT + dw_oct(c, oct) * 8;
@@ -279,6 +301,20 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
     }
   }
 
+  if constexpr (FIRST) {
+    // bias gradient: the eight node octets of a column quad meet in LDS (the images are dead), fixed order
+    __syncthreads();
+    float* comb = reinterpret_cast<float*>(smem);
+    if (tid < ZTH) *reinterpret_cast<float4*>(comb + oct * D + 4 * cq) = make_float4(dbacc[0], dbacc[1], dbacc[2], dbacc[3]);
+    __syncthreads();
+    if (tid < D) {
+      float sum = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) sum += comb[o * D + tid];
+      db_slabs[(size_t)blockIdx.x * D + tid] = sum;
+    }
+    __syncthreads();                                   // (the combine below reuses the scratch)
+  }
   // ---- this workgroup's slab: dW [D][FP]
   float* slab = slabs + (size_t)blockIdx.x * (D * FP);
 #pragma unroll
@@ -1109,7 +1145,8 @@ TallWs tall_carve(void* ws, int64_t N, int64_t B, int64_t F, int64_t D) {
   TallWs t;
   const size_t o1 = hcg_align_up((size_t)N * D * sizeof(float), 256);
   const size_t o2 = o1 + hcg_align_up((size_t)dw_grid(N, D) * D * tall_fpad(F) * sizeof(float), 256);
-  const size_t o3 = o2 + hcg_align_up((size_t)seg_grid64(B) * D * sizeof(float), 256);
+  const int dbs = seg_grid64(B) > dw_grid(N, D) ? seg_grid64(B) : dw_grid(N, D);      // (first-layer form: one db slab per dW slab)
+  const size_t o3 = o2 + hcg_align_up((size_t)dbs * D * sizeof(float), 256);
   char* p = (char*)ws;
   t.inter = (float*)p;
   t.dw_slabs = p ? (float*)(p + o1) : nullptr;
@@ -1141,13 +1178,14 @@ extern "C" size_t hcg_tall_workspace_bytes(int64_t N, int64_t B, int64_t F, int6
 extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b, const int64_t* edge_index, int64_t E,
                                   const int32_t* graph_ptr, const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D,
                                   int64_t max_nodes, int64_t max_edges, float slope, int apply_act, float* out, float* emb,
-                                  uint8_t* poolbits, int32_t* status, void* workspace, size_t workspace_bytes,
-                                  hcg_stream_t stream_) {
+                                  uint8_t* poolbits, float* xagg, uint8_t* signbits, int32_t* status, void* workspace,
+                                  size_t workspace_bytes, hcg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!hcg_tall_supported(F, D, max_nodes, max_edges)) return HCG_ERR_UNSUPPORTED;
   if (D == 64)     // (64-wide layers: only the backward is cut this way)
     return hcg_mid_layer_fwd(x, W, b, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, max_nodes, max_edges, slope, apply_act, out, emb,
-                             poolbits, status, stream_);
+                             poolbits, xagg, signbits, status, stream_);
+  if (xagg || signbits) return HCG_ERR_UNSUPPORTED;   // (the first-layer form exists for 64-wide layers)
   if (poolbits && !emb) return HCG_ERR_INVALID_ARG;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
@@ -1190,7 +1228,7 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
 // apply_act: bit 0 = multiply the upstream gradient by leaky'(out); bit 1 = hand dx down already multiplied by leaky'(x).
 // Leaves dW / db slabs in `workspace`: describe them with hcg_tall_reduce_jobs (two jobs) and sum with hcg_step_tail.
 extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
-                                  const uint8_t* poolbits, const float* x,
+                                  const uint8_t* poolbits, const float* xagg, const uint8_t* signbits, const float* x,
                                   const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                   const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
                                   int64_t max_edges, float slope, int apply_act, float* dx, int32_t* status, void* workspace,
@@ -1203,6 +1241,28 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
   const bool poolg = (dout == nullptr);
   const bool bits = poolbits != nullptr;      // the forward's bit form stands in for `out` and `emb`
   if (bits && !poolg) return HCG_ERR_INVALID_ARG;
+  if ((xagg == nullptr) != (signbits == nullptr)) return HCG_ERR_INVALID_ARG;
+  if (xagg) {
+    // ---- first-layer form: dW = (dout (.) leaky'(out))^T (Ahat x) and db = its column sums, ONE dense launch (k_tall_dw<FIRST>)
+    if (D != 64 || dx || poolg || F > 64) return HCG_ERR_UNSUPPORTED;
+    if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
+    const TallWs ws = tall_carve(workspace, N, B, F, D);
+    const int fp = tall_fpad(F);
+    const dim3 grid(dw_grid(N, 64)), blk(DWT);
+    const float slope_eff = (apply_act & 1) ? slope : 1.f;
+#define LAUNCH_DW_FIRST(NBF)                                                                                         \
+  do {                                                                                                               \
+    const size_t lds = (size_t)3 * (64 + NBF * 32) * (DW_TILE + 8) * sizeof(short);                                  \
+    hipError_t e = allow_lds<k_tall_dw<2, NBF, true, true>>(lds);                                                    \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                      \
+    hipLaunchKernelGGL((k_tall_dw<2, NBF, true, true>), grid, blk, lds, stream, dout, xagg, fp, ws.dw_slabs, (int)N, \
+                       reinterpret_cast<const unsigned short*>(signbits), slope_eff, ws.db_slabs);                   \
+  } while (0)
+    if (fp == 32) LAUNCH_DW_FIRST(1); else LAUNCH_DW_FIRST(2);
+#undef LAUNCH_DW_FIRST
+    HCG_CHECK_LAUNCH();
+    return HCG_OK;
+  }
   if (poolg && (!demb || (!emb && !bits))) return HCG_ERR_INVALID_ARG;
   if ((apply_act & ~3) || ((apply_act & 2) && !dx)) return HCG_ERR_INVALID_ARG;
   if ((poolg || (apply_act & 1)) && !out && !bits) return HCG_ERR_INVALID_ARG;
@@ -1307,7 +1367,7 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
 
 // two jobs: job_host[0] = dW [D, F] from the k_tall_dw slabs, job_host[1] = db [D] from the k_seg_bwd slabs
 extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
-                                    float* dW, float* db, hcg_reduce_job* job_host) {
+                                    int first_layer_form, float* dW, float* db, hcg_reduce_job* job_host) {
   if ((D != 128 && D != 64) || F < 1 || F > 128 || N <= 0 || B <= 0 || !dW || !db || !job_host || !workspace) return HCG_ERR_INVALID_ARG;
   if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
   const TallWs ws = tall_carve(const_cast<void*>(workspace), N, B, F, D);
@@ -1322,7 +1382,7 @@ extern "C" int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_byte
   j->seg[0] = hcg_reduce_seg{0, (int32_t)(D * fp), fp, (int32_t)F, dW};
   j = job_host + 1;
   j->slabs = ws.db_slabs;
-  j->nslabs = seg_grid64(B);
+  j->nslabs = first_layer_form ? dw_grid(N, D) : seg_grid64(B);      // (first-layer form: k_tall_dw<FIRST> leaves the db slabs)
   j->slab_floats = (int32_t)D;
   j->nseg = 1;
   j->sse_part = nullptr;

@@ -258,7 +258,7 @@ class _MidLayerFn(torch.autograd.Function):
         emb = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev) if pool else None
         rc = lib.hcg_mid_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
                                    _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, plan.max_nodes,
-                                   plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), None, _lib.ptr(plan.status),
+                                   plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), None, None, None, _lib.ptr(plan.status),
                                    _lib.stream_ptr())
         _lib.check(rc, "hcg_mid_layer_fwd")
         ctx.plan, ctx.apply_act, ctx.slope, ctx.pool = plan, apply_act, slope, pool
@@ -335,7 +335,7 @@ class _TallLayerFn(torch.autograd.Function):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         rc = lib.hcg_tall_layer_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(plan.edge_index), plan.E,
                                     _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N, plan.B, F, D, plan.max_nodes,
-                                    plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), None, _lib.ptr(plan.status),
+                                    plan.max_edges, slope, int(apply_act), _lib.ptr(out), _lib.ptr(emb), None, None, None, _lib.ptr(plan.status),
                                     _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "hcg_tall_layer_fwd")
         ctx.plan, ctx.apply_act, ctx.slope, ctx.pool = plan, apply_act, slope, pool
@@ -365,14 +365,14 @@ class _TallLayerFn(torch.autograd.Function):
         wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         stream = _lib.stream_ptr()
-        rc = lib.hcg_tall_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), None, _lib.ptr(x), _lib.ptr(weight),
+        rc = lib.hcg_tall_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), None, None, None, _lib.ptr(x), _lib.ptr(weight),
                                     _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N,
                                     plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
                                     _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)
         _lib.check(rc, "hcg_tall_layer_bwd")
         jb = _lib.job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
-        _lib.check(lib.hcg_tall_reduce_jobs(_lib.ptr(ws), wsb, N, plan.B, F, D, _lib.ptr(dW), _lib.ptr(db),
+        _lib.check(lib.hcg_tall_reduce_jobs(_lib.ptr(ws), wsb, N, plan.B, F, D, 0, _lib.ptr(dW), _lib.ptr(db),
                                             ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
         _lib.reduce_jobs(ctypes.addressof(jobs), 2)
         return dx, dW, db, None, None, None, None

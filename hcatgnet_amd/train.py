@@ -36,7 +36,7 @@ class _Ctx:
     """Everything one step needs, resolved once: shapes, weights, buffers, the kernel family of every layer."""
     __slots__ = ("batch", "plan", "x", "y2", "convs", "l0", "l1", "N", "F", "B", "D", "C", "n_conv", "dev", "W", "bs",
                  "gpts", "tall", "bufs", "n_small", "head_fused", "forward_only", "flat", "gaddr", "step_word",
-                 "jobs", "jaddr", "jb", "njobs", "loss_mode", "sse_split", "poolbits")
+                 "jobs", "jaddr", "jb", "njobs", "loss_mode", "sse_split", "poolbits", "xagg")
 
 
 class FusedTrainStep:
@@ -66,6 +66,8 @@ class FusedTrainStep:
     # code): POOLBITS = False stores the pooled layer's activations as the plain forms do, PREMASK = False leaves every
     # activation derivative to the layer that owns it, HEAD_IN_FORWARD = False keeps the head a launch of its own
     POOLBITS = True
+    XAGG = True                    # first layer on the wide-layer route: Ahat x + sign pieces from the forward, one dense backward launch
+    TALL_PREMASK = False           # (measured: the dense dx kernel's strided mask loads cost what the layer below saves -- DESIGN 7)
     PREMASK = True
     HEAD_IN_FORWARD = True
     OVERLAP_GROUPS = True          # captured size-grouped steps: the two kernel families as two branches of the hipGraph
@@ -276,6 +278,7 @@ class FusedTrainStep:
         c.jaddr, c.njobs = ctypes.addressof(c.jobs), 0
         c.flat = c.gaddr = c.step_word = None
         c.poolbits = None
+        c.xagg = None
         # how the loss scale reaches the gradients (see the class docstring).  "sse" with a collective between backward and
         # update: the tail leaves the gradients unscaled and [SSE, count] behind the flat buffer; everything else: the tail
         # applies this rank's own scale ("sse" without any exchange IS sqrt(MSE) of the own batch)
@@ -387,13 +390,21 @@ class FusedTrainStep:
                     # the pooled layer's activations stay on chip: one byte per (row, 4 columns) -- sign, is-the-column-max --
                     # is all its backward (csrc/tall.hip: k_gseg_bwd) needs of them
                     bits = c.poolbits = self._ws(bufs, "poolbits_tall", N * (D // 4), c.dev)
+                xagg = signs = None
+                if (l == 0 and n_conv >= 2 and D == 64 and Fl <= 64 and self.XAGG and not c.forward_only and c.tall[1]):
+                    # training form of the FIRST layer: Ahat x [N, 32 | 64] and the sign pieces of its output leave too; its whole
+                    # backward is then ONE dense launch (csrc/tall.hip: k_tall_dw<FIRST>) -- no transpose sum, no dH round trip
+                    kp = 32 if Fl <= 32 else 64
+                    xagg = self._ws(bufs, "xagg", N * kp * 4, c.dev)
+                    signs = self._ws(bufs, "signs", N * 8, c.dev)
+                    c.xagg = (xagg, signs)
                 rc = lib.hcg_tall_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                             p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, None if bits is not None else p(acts[l]),
-                                            p(pe), p(bits), p(plan.status), p(ws), wsb, stream)
+                                            p(pe), p(bits), p(xagg), p(signs), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_tall_layer_fwd")
             else:
                 rc = lib.hcg_mid_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe), None,
+                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe), None, None, None,
                                            p(plan.status), stream)
                 _lib.check(rc, "hcg_mid_layer_fwd")
             h = acts[l]
@@ -414,9 +425,9 @@ class FusedTrainStep:
         fork()
         _lib.fused_forward(**self._tiles_args(c, Bs, gpt, poolbits=c.poolbits))
         _lib.check(lib.hcg_mid_layer_fwd(p(c.x), p(c.W[0]), p(c.bs[0]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.F, c.D,
-                                         mxn, mxe, slope, 1, p(acts[0]), None, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+                                         mxn, mxe, slope, 1, p(acts[0]), None, None, None, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
         _lib.check(lib.hcg_mid_layer_fwd(p(acts[0]), p(c.W[1]), p(c.bs[1]), p(plan.edge_index), plan.E, gp_b, ep_b, c.N, Bb, c.D,
-                                         c.D, mxn, mxe, slope, 1, p(acts[1]), emb_b, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
+                                         c.D, mxn, mxe, slope, 1, p(acts[1]), emb_b, None, None, None, p(plan.status), stream_b), "hcg_mid_layer_fwd")
         join()
         return gpt
 
@@ -490,17 +501,20 @@ class FusedTrainStep:
                 up = (None if last else p(dh), p(bufs["demb"]) if last else None, p(emb) if last else None)
                 act = 0 if premasked else 1
                 if c.tall[l]:
-                    # (never premasks: the layer below reads its own output row-contiguous instead -- the premask would be
-                    #  4-byte strided loads in the dense kernel's epilogue for the same bytes)
-                    premasked = False
+                    # (TALL_PREMASK: the dense dx kernel multiplies by leaky'(x) in its epilogue -- 4-byte strided loads of the
+                    #  rows it holds -- and the layer below reads ONE tensor instead of two)
+                    premasked = self.TALL_PREMASK and self.PREMASK and l > 0
                     tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
                     bits = c.poolbits if last else None          # (the forward's bit form stands in for the layer's output and emb)
                     if bits is not None:
                         up = (None, p(bufs["demb"]), None)
-                    rc = lib.hcg_tall_layer_bwd(*up, p(acts[l]) if ((act or last) and bits is None) else None, p(bits), p(inp),
-                                                p(c.W[l]), *geo, mxn, mxe, slope, act, p(dx), p(plan.status), p(tws), twsb, stream)
+                    first = c.xagg if (l == 0 and not last and dx is None) else None     # (Ahat x, sign pieces) of the forward
+                    a_out = p(acts[l]) if ((act or last) and bits is None and first is None) else None
+                    rc = lib.hcg_tall_layer_bwd(*up, a_out, p(bits), p(first[0]) if first else None, p(first[1]) if first else None,
+                                                p(inp), p(c.W[l]), *geo, mxn, mxe, slope, act | (2 if premasked else 0), p(dx),
+                                                p(plan.status), p(tws), twsb, stream)
                     _lib.check(rc, "hcg_tall_layer_bwd")
-                    _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, g(cv.lin.weight), g(cv.bias),
+                    _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, 1 if first else 0, g(cv.lin.weight), g(cv.bias),
                                                         self._job_slot(c)), "hcg_tall_reduce_jobs")
                     c.njobs += 1                          # (two jobs: dW, db)
                 else:

@@ -250,7 +250,8 @@ int hcg_mid_layer_fwd(const float* x, const float* W, const float* b,
                       const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                       int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
                       float slope, int apply_act, float* out, float* emb /*nullable*/,
-                      uint8_t* poolbits /*nullable: see hcg_tall_layer_fwd*/, int32_t* status,
+                      uint8_t* poolbits /*nullable: see hcg_tall_layer_fwd*/,
+                      float* xagg /*nullable*/, uint8_t* signbits /*nullable: both, see hcg_tall_layer_fwd*/, int32_t* status,
                       hcg_stream_t stream);
 int hcg_mid_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
                       const float* out, const float* x, const float* W,
@@ -273,15 +274,22 @@ int hcg_tall_layer_fwd(const float* x, const float* W, const float* b,
                        const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                        int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
                        float slope, int apply_act, float* out, float* emb /*nullable*/,
-                       uint8_t* poolbits /*nullable*/, int32_t* status,
-                       void* workspace, size_t workspace_bytes, hcg_stream_t stream);
+                       uint8_t* poolbits /*nullable*/, float* xagg /*nullable*/, uint8_t* signbits /*nullable*/,
+                       int32_t* status, void* workspace, size_t workspace_bytes, hcg_stream_t stream);
 /* `poolbits` [N, D / 4] bytes (training form of the POOLED layer, needs emb; F <= 64 for D = 64): the layer's output is
  * NOT written (`out` may be NULL) -- one byte per (row, 4 columns) leaves instead: bits 0-3 = the value is positive
  * (LeakyReLU'), bits 4-7 = it is its graph's column maximum (where global_max_pool's gradient goes, ties included).  Given
  * to hcg_tall_layer_bwd (pooled form: dout = NULL) they stand in for `out` AND `emb` (both may be NULL): a sixteenth of the
  * bytes on both sides of the step. */
+/* `xagg` [N, 32 | 64 (F <= 32 | F <= 64)] + `signbits` [N, 8] bytes (training form of a FIRST, not pooled, 64-wide layer; given
+ * together): besides `out` the forward leaves xagg = Ahat x (zero-padded columns) and, per row, four 16-bit pieces (piece j bit
+ * q = column 4 q + j of `out` is positive).  Given to hcg_tall_layer_bwd with dout and dx = NULL they select the first-layer
+ * form: dW = (dout (.) leaky'(out))^T xagg and db = the column sums of that product's left operand in ONE dense launch (the
+ * same sums as (Ahat^T G)^T x in another order) -- no transpose sum, no dH round trip; `out`, `x` are not read.
+ * hcg_tall_reduce_jobs(first_layer_form = 1) describes its slabs. */
 int hcg_tall_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
-                       const float* out, const uint8_t* poolbits /*nullable*/, const float* x, const float* W,
+                       const float* out, const uint8_t* poolbits /*nullable*/,
+                       const float* xagg /*nullable*/, const uint8_t* signbits /*nullable*/, const float* x, const float* W,
                        const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                        int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
                        float slope, int apply_act, float* dx /*nullable*/, int32_t* status,
@@ -375,7 +383,7 @@ int hcg_mid_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B,
                        int64_t max_nodes, int64_t max_edges, int half, float* dW, float* db, hcg_reduce_job* job_host);
 /* job_host[0] = dW [D, F], job_host[1] = db [D] of hcg_tall_layer_bwd */
 int hcg_tall_reduce_jobs(const void* workspace, size_t workspace_bytes, int64_t N, int64_t B, int64_t F, int64_t D,
-                         float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
+                         int first_layer_form, float* dW, float* db, hcg_reduce_job* job_host /*[2]*/);
 /* the head's slabs; job_host->sse_part = the workgroups' SSE partials.  dW0 == NULL (forward-only head): no segments,
  * the job then only carries the partials (hcg_loss_finalize) */
 int hcg_head_reduce_job(const void* workspace, size_t workspace_bytes, int64_t B, int64_t D, int64_t C,

@@ -121,12 +121,12 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
         dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
         dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
-        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), None, None, None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                           p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
                                           st), "hcg_tall_layer_bwd")
         jb = _lib.job_bytes()
         jobs = ctypes.create_string_buffer(jb * 2)
-        _lib.check(lib.hcg_tall_reduce_jobs(p(ws), wsb, N, B, F_, D, p(dW), p(db), ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
+        _lib.check(lib.hcg_tall_reduce_jobs(p(ws), wsb, N, B, F_, D, 0, p(dW), p(db), ctypes.addressof(jobs)), "hcg_tall_reduce_jobs")
         _lib.reduce_jobs(ctypes.addressof(jobs), 2)
         return dx, dW, db
 
@@ -172,3 +172,45 @@ def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, D, F, nodes, jitter,
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(res[0][1]).all()) and float(res[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("F,nodes,jitter,B", [(25, 100, 17, 400), (64, 160, 30, 260), (32, 90, 20, 420)])
+def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, F, nodes, jitter, B):
+    """Training form of the FIRST layer on the wide-layer route (`xagg` + `signbits` of hcg_tall_layer_fwd / _bwd): the forward
+    also leaves Ahat x and the sign pieces of its output, the backward is ONE dense launch dW = (dA (.) leaky'(A))^T (Ahat x).
+    The same sums as the transpose-sum form in another order: every gradient within 1e-5 of that form's (layer-1 weight
+    within 1e-4 of the fp64 oracle like every conv weight), everything that does not depend on the order -- loss, outputs, the
+    second layer's and the head's gradients -- bitwise; exact zeros in the first layer's output (an all-zero graph with zero
+    bias: LeakyReLU'(0) = slope) included."""
+    from hcatgnet_amd import synth
+    from hcatgnet_amd.train import FusedTrainStep
+    sb = synth.make_batch(num_graphs=B, nodes=nodes, nodes_jitter=jitter, feat=F, extra_bonds=4, max_degree=4, seed=91)
+    gp = torch.zeros(B + 1, dtype=torch.int64)
+    gp[1:] = torch.bincount(sb.batch, minlength=B).cumsum(0)
+    sb.x[gp[1]:gp[2]] = 0.0                                   # graph 1: zero features
+    params = _rand_params(F, 64, seed=6)
+    params["conv1.bias"].zero_()                               # ... and zero bias: its layer-1 outputs are EXACTLY zero
+    res = []
+    for xagg in (True, False):
+        m = _model_from_params(H, params)
+        step = FusedTrainStep(m, optimizer_step=False)
+        step.XAGG = xagg
+        batch = sb.as_batch("cuda")
+        assert step.reason(batch) is None
+        loss = step(batch)
+        assert batch._hcg_plan.check_status() == 0
+        cap = step._bufs["cap"]
+        assert ("xagg" in cap["ws"]) == xagg, "the wide-layer route / its first-layer form did not run"
+        res.append((loss.clone(), step.last_out.clone(), {k: v.grad.detach().clone() for k, v in m.named_parameters()},
+                    cap["acts"][0][:sb.x.shape[0]].clone()))
+    (la, oa, ga, a1a), (lb, ob, gb, a1b) = res
+    assert torch.equal(la, lb) and torch.equal(oa, ob) and torch.equal(a1a, a1b)
+    assert bool((a1a[gp[1]:gp[2]] == 0).all())
+    for k in ga:
+        if k.startswith("conv1."):
+            assert rel_inf(ga[k], gb[k]) <= TOL, k
+        else:
+            assert torch.equal(ga[k], gb[k]), k
+    _, _, _, g64 = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, B, dtype=torch.float64)
+    assert rel_inf(ga["conv1.lin.weight"], g64["conv1.lin.weight"]) <= TOL_DW
+    assert rel_inf(ga["conv1.bias"], g64["conv1.bias"]) <= TOL

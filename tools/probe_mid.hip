@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 25; ++it) {
     if (it == 5) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
     int rc;
-    if (!bwd) rc = hcg_mid_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 1, dout, F == 64 ? demb : nullptr, nullptr, dstatus, 0);
+    if (!bwd) rc = hcg_mid_layer_fwd(dx, dW, db, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 1, dout, F == 64 ? demb : nullptr, nullptr, nullptr, nullptr, dstatus, 0);
     else if (F == 64) rc = hcg_mid_layer_bwd(nullptr, ddemb, demb, da, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 3, ddx, dstatus, dws, wsb, 0);
     else rc = hcg_mid_layer_bwd(dout, nullptr, nullptr, nullptr, dx, dW, (const int64_t*)dei, E, dgp, dep, N, B, F, D, 117, 300, 0.01f, 0, nullptr, dstatus, dws, wsb, 0);
     if (rc) { printf("rc %d\n", rc); return 1; }
