@@ -510,9 +510,9 @@ __device__ __forceinline__ Quad ldq(const char* p) {
 
 // Z = Ahat x of a unit of 16 rows, from the x tile BEFORE the GEMM overwrites it (training form of the FIRST layer: with Z
 // its weight gradient is the dense product G^T Z, G = dA (.) leaky'(A) -- no transpose sum, no dH round trip: csrc/tall.hip).
-// KPAD / 4 lanes per row.  The slots may not be sorted yet (the row's dinv lane sorts them concurrently: an 8-byte LDS read
-// sees one order or the other) and dinv may not be written yet: the lane sorts its copy and derives every dinv from the
-// in-degree counters with the expression the dinv lanes use (bitwise the same values); the CSR route reads both finished.
+// KPAD / 4 lanes per row; a barrier in front makes every dinv and the sorted slots readable (first form: no barrier, every
+// lane sorted its own copy of the slots and re-derived five dinv per row from the counters -- 1 / sqrtf is ~25 VALU
+// instructions without fast-math: the extra aggregation cost 18 us of a 45 us launch, tools/ab_kernels.sh).
 template <int KPAD, bool CSR>
 __device__ __forceinline__ void mid_zagg_unit(const MidLds& L, int u, int n, int npad, unsigned empty_id, float* __restrict__ z_graph) {
   constexpr int LPRQ = KPAD / 4, RPP = 64 / LPRQ, NP = 16 / RPP;
@@ -525,15 +525,9 @@ __device__ __forceinline__ void mid_zagg_unit(const MidLds& L, int u, int n, int
     int kb = 0, ke = 0;
     float di;
     if constexpr (!CSR) {
-      const uint2 nb = *reinterpret_cast<const uint2*>(L.nbr + row * NSLOT);
-      unsigned t;
+      const uint2 nb = *reinterpret_cast<const uint2*>(L.nbr + row * NSLOT);       // (sorted by the row's dinv lane)
       a0 = nb.x & 0xffffu; a1 = nb.x >> 16; a2 = nb.y & 0xffffu; a3 = nb.y >> 16;
-      t = min(a0, a1); a1 = max(a0, a1); a0 = t;
-      t = min(a2, a3); a3 = max(a2, a3); a2 = t;
-      t = min(a0, a2); a2 = max(a0, a2); a0 = t;
-      t = min(a1, a3); a3 = max(a1, a3); a1 = t;
-      t = min(a1, a2); a2 = max(a1, a2); a1 = t;
-      di = 1.0f / sqrtf(1.0f + (float)L.cursor[row]);
+      di = L.dinv[row];
     } else {
       kb = L.rowptr[row];
       ke = L.rowptr[row + 1];
@@ -545,11 +539,7 @@ __device__ __forceinline__ void mid_zagg_unit(const MidLds& L, int u, int n, int
     }
     // an empty slot names the all-zero row; its factor only has to be finite: the last real row's
     const unsigned last = (unsigned)npad - 1u;
-    auto dof = [&](unsigned a) -> float {
-      const unsigned i = a < last ? a : last;
-      if constexpr (!CSR) return 1.0f / sqrtf(1.0f + (float)L.cursor[i]);
-      else return L.dinv[i];
-    };
+    auto dof = [&](unsigned a) -> float { return L.dinv[a < last ? a : last]; };
     const float d0 = dof(a0), d1 = dof(a1), d2 = dof(a2), d3 = dof(a3);
     Quad acc = ldq(tq + __umul24((unsigned)row, HS * 4u));
     const Quad n0 = ldq(tq + __umul24(a0, HS * 4u)), n1 = ldq(tq + __umul24(a1, HS * 4u));
@@ -844,7 +834,7 @@ __global__ __launch_bounds__(MT, MULTIK ? 2 : 4) void k_mid_layer_fwd(const floa
     }
     MSTAMP(3);
     if constexpr (ZS) {
-      if (csr_route) __syncthreads();                    // the sorted CSR and every dinv are complete
+      __syncthreads();                                   // every dinv and the sorted slots (the sorted CSR) are complete
       float* z_graph = zagg + (size_t)gcur.nbase * KPAD;
       for (int u = wave; u < gcur.nblk * 2; u += MW) {
         if (!csr_route) mid_zagg_unit<KPAD, false>(L, u, gcur.n, npad, empty_id, z_graph);
