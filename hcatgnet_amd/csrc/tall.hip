@@ -21,6 +21,8 @@
 // traffic in the backward: dH makes a round trip (written once, read by both dense kernels).  What bounds each kernel and
 // what was tried: DESIGN.md 4.2c.
 // Reference: the same PyG GCNConv call sites as mid.hip (model/gcn.py:58-63), `loss.backward()` utils/utils_model.py:65.
+#include <type_traits>
+
 #include "common.h"
 #include "split_mfma.h"
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
                                                                  float* __restrict__ slabs, int N,
                                                                  const unsigned short* __restrict__ signs = nullptr,
                                                                  float slope = 1.f, float* __restrict__ db_slabs = nullptr) {
-  static_assert(!FIRST || (DB == 2 && XVEC), "first-layer form: 64 output columns, padded Ahat x rows");
+  static_assert(!FIRST || ((DB == 2 || DB == 4) && XVEC), "first-layer form: padded Ahat x rows");
   constexpr int D = DB * 32, FP = NBF * 32, TR = 64, LDT = TR + 8;
   constexpr int NTILE = DB * NBF, TPW = NTILE >= DWW ? NTILE / DWW : 1, KPARTS = NTILE >= DWW ? 1 : DWW / NTILE;
   static_assert(NTILE * KPARTS == DWW * TPW, "block -> wave map");
@@ -203,7 +205,9 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
   static_assert(XVEC || FP * 8 <= DWT, "one X item per thread");
   float4 sv[8];
   float xs[XVEC ? 1 : 8];
-  uint2 sg[FIRST ? 8 : 1];                             // FIRST: the sign pieces of this thread's eight nodes
+  // FIRST: the sign pieces of this thread's eight nodes (D = 64: four 16-bit pieces per row, D = 128: four 32-bit pieces)
+  typedef typename std::conditional<DB == 2, uint2, uint4>::type SignRow;
+  SignRow sg[FIRST ? 8 : 1];
   float dbacc[FIRST ? 4 : 1] = {};                     // FIRST: column sums of G over this thread's nodes
   auto load_tile = [&](int t) {
     if (live) {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
         if (node > N - 1) node = N - 1;
         sv[u] = *reinterpret_cast<const float4*>(src + (size_t)node * ldm + c);
         if constexpr (FIRST) {
-          if (!is_x) sg[u] = *reinterpret_cast<const uint2*>(signs + (size_t)node * 4);
+          if (!is_x) sg[u] = *reinterpret_cast<const SignRow*>(reinterpret_cast<const char*>(signs) + (size_t)node * sizeof(SignRow));
         }
       }
     }
@@ -246,8 +250,16 @@ __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* _
           float e = i == 0 ? sv[u].x : (i == 1 ? sv[u].y : (i == 2 ? sv[u].z : sv[u].w));
           if constexpr (FIRST) {
             if (!is_x) {                               // G = dA (.) leaky'(A): piece i of the node, bit cq
-              const unsigned w = i < 2 ? sg[u].x : sg[u].y;
-              e *= ((w >> (16 * (i & 1) + cq)) & 1u) ? 1.f : slope;
+              unsigned bit;
+              if constexpr (DB == 2) {
+                const unsigned w = i < 2 ? sg[u].x : sg[u].y;
+                bit = (w >> (16 * (i & 1) + cq)) & 1u;
+              } else {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(&sg[u]);
+                const unsigned w = i == 0 ? w4.x : (i == 1 ? w4.y : (i == 2 ? w4.z : w4.w));
+                bit = (w >> cq) & 1u;
+              }
+              e *= bit ? 1.f : slope;
             }
           }
           v[u] = (row0 + u < N && c < lim) ? e : 0.f;
@@ -589,14 +601,21 @@ constexpr int WCH = 3 * 128 * 16;     // shorts of one 16-column weight chunk (t
 // BITS (needs POOL; the pooled layer of a training step): `out` is not written -- one byte per (row, 4 columns) leaves
 // instead (low nibble: the value is positive, high nibble: it is its graph's column maximum; mid.hip: mid_agg_unit has the
 // scheme), all the pooled backward (k_gseg_bwd<.., BITS>) needs of the layer's output.
-template <bool POOL, bool BITS = false>
+// ZS (training form of the FIRST layer, not POOL): two more outputs for the dense first-layer backward (k_tall_dw<FIRST>):
+// `zagg` [N][zld] = Ahat x and four 32-bit sign pieces per output row (piece j bit q = column 4 q + j is positive).  The x
+// rows go into the tile ALREADY scaled by their dinv (the CSR build has finished): Ahat x is then the plain row sum of the
+// sums phase over the x tile, and the GEMM yields H' = (dinv x) W^T directly.
+template <bool POOL, bool BITS = false, bool ZS = false>
 __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src, int F, int KP, const short* __restrict__ gW,
                                                    const float* __restrict__ bias,
                                                    const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ graph_ptr,
                                                    const int32_t* __restrict__ edge_ptr, int B, int npad, float slope, int apply_act,
                                                    float* __restrict__ out, float* __restrict__ emb, int32_t* __restrict__ status,
-                                                   unsigned char* __restrict__ poolbits = nullptr) {
+                                                   unsigned char* __restrict__ poolbits = nullptr,
+                                                   float* __restrict__ zagg = nullptr, int zld = 0,
+                                                   uint32_t* __restrict__ signs = nullptr) {
   static_assert(!BITS || POOL, "the bit form belongs to the pooled layer");
+  static_assert(!ZS || !POOL, "Ahat x / sign pieces: the first (not pooled) layer");
   constexpr int D = SEG_D;
   __shared__ SegLdsT<false> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -637,8 +656,11 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
 #pragma unroll
       for (int j = 0; j < SEG_RPT; ++j) {
         const int row = rg + 32 * j;
-        if (j * 32 < gi.n && row < gi.n)
-          *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = 4 * c4 < F ? xrows.v[j] : f4_zero();
+        if (j * 32 < gi.n && row < gi.n) {
+          float4 xv = 4 * c4 < F ? xrows.v[j] : f4_zero();
+          if constexpr (ZS) xv = f4_scale(L.dinv[row], xv);
+          *reinterpret_cast<float4*>(tile + row * SEG_TS + 4 * c4) = xv;
+        }
       }
       f32x16 acc[2];
 #pragma unroll
@@ -657,6 +679,22 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
       if (wcopy) *reinterpret_cast<u32x4*>(wdst) = wreg;           // chunk 0 -> buffer 0 (free since the previous graph's last barrier)
       wreg = wreg2;
       __syncthreads();                                             // x tile + chunk 0 visible
+      if constexpr (ZS) {
+        // Ahat x = dinv_i (x'_i + sum of the neighbours' x'_j): the tile is only READ until the k-loop's last barrier
+        if (4 * c4 < zld) {
+#pragma unroll
+          for (int j = 0; j < SEG_RPT; ++j) {
+            if (j * 32 < gi.n) {
+              const int row = rg + 32 * j;
+              const bool valid = row < gi.n;
+              const int rr = valid ? row : gi.n - 1;
+              const int kb = valid ? L.rowptr[rr] : 0, ke = valid ? L.rowptr[rr + 1] : 0;
+              const float4 zs = seg_row_sum(tile, L.col, rr, kb, ke, c4);
+              if (valid) *reinterpret_cast<float4*>(zagg + (size_t)(gi.nbase + row) * zld + 4 * c4) = f4_scale(L.dinv[rr], zs);
+            }
+          }
+        }
+      }
       const float* arow = tile + (rbw * 32 + r) * SEG_TS + 8 * h;   // (rows past the graph: stale LDS, they only feed unused output rows)
       auto split_a = [&](int ks) {
         const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
@@ -697,7 +735,7 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = rbw * 32 + krow(i, h);
-            if (row < gi.n) tile[row * SEG_TS + (ch * 2 + nb) * 32 + r] = acc[nb][i] * L.dinv[row];
+            if (row < gi.n) tile[row * SEG_TS + (ch * 2 + nb) * 32 + r] = ZS ? acc[nb][i] : acc[nb][i] * L.dinv[row];
           }
       }
     }
@@ -735,6 +773,14 @@ __global__ __launch_bounds__(SN, 4) void k_seg_fwd(const float* __restrict__ src
             sgn |= sn << (4 * j);
           } else {
             *reinterpret_cast<float4*>(out + (size_t)(gi.nbase + row) * D + 4 * c4) = y;
+          }
+          if constexpr (ZS) {
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(y.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(y.y > 0.f);
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(y.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(y.w > 0.f);
+            if (c4 < 4) {
+              const unsigned long long bsel = c4 == 0 ? b0 : (c4 == 1 ? b1 : (c4 == 2 ? b2 : b3));
+              signs[(size_t)(gi.nbase + row) * 4 + c4] = (uint32_t)(bsel >> (32 * (lane >> 5)));
+            }
           }
           if (POOL) {
             pmax = make_float4(fmaxf(pmax.x, y.x), fmaxf(pmax.y, y.y), fmaxf(pmax.z, y.z), fmaxf(pmax.w, y.w));
@@ -1185,7 +1231,8 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
   if (D == 64)     // (64-wide layers: only the backward is cut this way)
     return hcg_mid_layer_fwd(x, W, b, edge_index, E, graph_ptr, edge_ptr, N, B, F, D, max_nodes, max_edges, slope, apply_act, out, emb,
                              poolbits, xagg, signbits, status, stream_);
-  if (xagg || signbits) return HCG_ERR_UNSUPPORTED;   // (the first-layer form exists for 64-wide layers)
+  if ((xagg == nullptr) != (signbits == nullptr)) return HCG_ERR_INVALID_ARG;
+  if (xagg && (emb || poolbits || !out)) return HCG_ERR_UNSUPPORTED;     // (first-layer form: a layer that is not pooled)
   if (poolbits && !emb) return HCG_ERR_INVALID_ARG;
   if (apply_act && !(slope >= 0.f && slope <= 1.f)) return HCG_ERR_UNSUPPORTED;   // LeakyReLU is evaluated as max(v, slope*v)
   if (N < 0 || B < 0 || E < 0) return HCG_ERR_INVALID_ARG;
@@ -1207,10 +1254,15 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
     HCG_CHECK_LAUNCH();
     const size_t lds = slds + wbuf, lds_max = 160 * 1024 - 512 - sizeof(SegLdsT<false>);
     if (lds > lds_max) return HCG_ERR_UNSUPPORTED;
-    hipError_t e = poolbits ? allow_lds<k_seg_fwd<true, true>>(lds_max)
-                            : (emb ? allow_lds<k_seg_fwd<true>>(lds_max) : allow_lds<k_seg_fwd<false>>(lds_max));
+    hipError_t e = xagg ? allow_lds<k_seg_fwd<false, false, true>>(lds_max)
+                        : (poolbits ? allow_lds<k_seg_fwd<true, true>>(lds_max)
+                                    : (emb ? allow_lds<k_seg_fwd<true>>(lds_max) : allow_lds<k_seg_fwd<false>>(lds_max)));
     if (e != hipSuccess) return hcg_hip_err(e);
-    if (poolbits)
+    if (xagg)
+      hipLaunchKernelGGL((k_seg_fwd<false, false, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index,
+                         E, graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status, (unsigned char*)nullptr, xagg,
+                         tall_fpad(F), reinterpret_cast<uint32_t*>(signbits));
+    else if (poolbits)
       hipLaunchKernelGGL((k_seg_fwd<true, true>), sgrid, sblk, lds, stream, x, (int)F, KP, (const short*)img, b, edge_index, E,
                          graph_ptr, edge_ptr, (int)B, npad, slope, apply_act, out, emb, status, poolbits);
     else if (emb)
@@ -1244,21 +1296,22 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
   if ((xagg == nullptr) != (signbits == nullptr)) return HCG_ERR_INVALID_ARG;
   if (xagg) {
     // ---- first-layer form: dW = (dout (.) leaky'(out))^T (Ahat x) and db = its column sums, ONE dense launch (k_tall_dw<FIRST>)
-    if (D != 64 || dx || poolg || F > 64) return HCG_ERR_UNSUPPORTED;
+    if (dx || poolg || (D == 64 && F > 64)) return HCG_ERR_UNSUPPORTED;
     if (workspace_bytes < hcg_tall_workspace_bytes(N, B, F, D)) return HCG_ERR_WORKSPACE;
     const TallWs ws = tall_carve(workspace, N, B, F, D);
     const int fp = tall_fpad(F);
-    const dim3 grid(dw_grid(N, 64)), blk(DWT);
+    const dim3 grid(dw_grid(N, D)), blk(DWT);
     const float slope_eff = (apply_act & 1) ? slope : 1.f;
-#define LAUNCH_DW_FIRST(NBF)                                                                                         \
-  do {                                                                                                               \
-    const size_t lds = (size_t)3 * (64 + NBF * 32) * (DW_TILE + 8) * sizeof(short);                                  \
-    hipError_t e = allow_lds<k_tall_dw<2, NBF, true, true>>(lds);                                                    \
-    if (e != hipSuccess) return hcg_hip_err(e);                                                                      \
-    hipLaunchKernelGGL((k_tall_dw<2, NBF, true, true>), grid, blk, lds, stream, dout, xagg, fp, ws.dw_slabs, (int)N, \
-                       reinterpret_cast<const unsigned short*>(signbits), slope_eff, ws.db_slabs);                   \
+#define LAUNCH_DW_FIRST(DBV, NBF)                                                                                        \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)3 * (DBV * 32 + NBF * 32) * (DW_TILE + 8) * sizeof(short);                                \
+    hipError_t e = allow_lds<k_tall_dw<DBV, NBF, true, true>>(lds);                                                      \
+    if (e != hipSuccess) return hcg_hip_err(e);                                                                          \
+    hipLaunchKernelGGL((k_tall_dw<DBV, NBF, true, true>), grid, blk, lds, stream, dout, xagg, fp, ws.dw_slabs, (int)N,   \
+                       reinterpret_cast<const unsigned short*>(signbits), slope_eff, ws.db_slabs);                       \
   } while (0)
-    if (fp == 32) LAUNCH_DW_FIRST(1); else LAUNCH_DW_FIRST(2);
+    if (D == 64) { if (fp == 32) LAUNCH_DW_FIRST(2, 1); else LAUNCH_DW_FIRST(2, 2); }
+    else         { if (fp == 32) LAUNCH_DW_FIRST(4, 1); else if (fp == 64) LAUNCH_DW_FIRST(4, 2); else LAUNCH_DW_FIRST(4, 4); }
 #undef LAUNCH_DW_FIRST
     HCG_CHECK_LAUNCH();
     return HCG_OK;

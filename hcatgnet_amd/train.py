@@ -391,12 +391,12 @@ class FusedTrainStep:
                     # is all its backward (csrc/tall.hip: k_gseg_bwd) needs of them
                     bits = c.poolbits = self._ws(bufs, "poolbits_tall", N * (D // 4), c.dev)
                 xagg = signs = None
-                if (l == 0 and n_conv >= 2 and D == 64 and Fl <= 64 and self.XAGG and not c.forward_only and c.tall[1]):
-                    # training form of the FIRST layer: Ahat x [N, 32 | 64] and the sign pieces of its output leave too; its whole
-                    # backward is then ONE dense launch (csrc/tall.hip: k_tall_dw<FIRST>) -- no transpose sum, no dH round trip
-                    kp = 32 if Fl <= 32 else 64
+                if (l == 0 and n_conv >= 2 and (Fl <= 64 or D == 128) and self.XAGG and not c.forward_only and c.tall[1]):
+                    # training form of the FIRST layer: Ahat x [N, 32 | 64 | 128] and the sign pieces of its output leave too; its
+                    # whole backward is then ONE dense launch (csrc/tall.hip: k_tall_dw<FIRST>) -- no transpose sum, no dH round trip
+                    kp = 32 if Fl <= 32 else (64 if Fl <= 64 else 128)
                     xagg = self._ws(bufs, "xagg", N * kp * 4, c.dev)
-                    signs = self._ws(bufs, "signs", N * 8, c.dev)
+                    signs = self._ws(bufs, "signs", N * (D // 8), c.dev)
                     c.xagg = (xagg, signs)
                 rc = lib.hcg_tall_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                             p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, None if bits is not None else p(acts[l]),

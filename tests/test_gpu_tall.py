@@ -174,21 +174,23 @@ def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, D, F, nodes, jitter,
     assert bool(torch.isfinite(res[0][1]).all()) and float(res[0][1].abs().max()) > 0
 
 
-@pytest.mark.parametrize("F,nodes,jitter,B", [(25, 100, 17, 400), (64, 160, 30, 260), (32, 90, 20, 420)])
-def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, F, nodes, jitter, B):
+@pytest.mark.parametrize("D,F,nodes,jitter,B", [(64, 25, 100, 17, 400), (64, 64, 160, 30, 260), (64, 32, 90, 20, 420),
+                                                (128, 128, 200, 24, 12), (128, 28, 150, 40, 24), (128, 64, 90, 30, 20)])
+def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, D, F, nodes, jitter, B):
     """Training form of the FIRST layer on the wide-layer route (`xagg` + `signbits` of hcg_tall_layer_fwd / _bwd): the forward
     also leaves Ahat x and the sign pieces of its output, the backward is ONE dense launch dW = (dA (.) leaky'(A))^T (Ahat x).
     The same sums as the transpose-sum form in another order: every gradient within 1e-5 of that form's (layer-1 weight
     within 1e-4 of the fp64 oracle like every conv weight), everything that does not depend on the order -- loss, outputs, the
-    second layer's and the head's gradients -- bitwise; exact zeros in the first layer's output (an all-zero graph with zero
-    bias: LeakyReLU'(0) = slope) included."""
+    second layer's and the head's gradients -- bitwise for 64-wide layers (128-wide: the training form's forward scales the x
+    rows by dinv BEFORE the GEMM instead of behind it, so everything is within 1e-5); exact zeros in the first layer's output
+    (an all-zero graph with zero bias: LeakyReLU'(0) = slope) included."""
     from hcatgnet_amd import synth
     from hcatgnet_amd.train import FusedTrainStep
     sb = synth.make_batch(num_graphs=B, nodes=nodes, nodes_jitter=jitter, feat=F, extra_bonds=4, max_degree=4, seed=91)
     gp = torch.zeros(B + 1, dtype=torch.int64)
     gp[1:] = torch.bincount(sb.batch, minlength=B).cumsum(0)
     sb.x[gp[1]:gp[2]] = 0.0                                   # graph 1: zero features
-    params = _rand_params(F, 64, seed=6)
+    params = _rand_params(F, D, seed=6)
     params["conv1.bias"].zero_()                               # ... and zero bias: its layer-1 outputs are EXACTLY zero
     res = []
     for xagg in (True, False):
@@ -204,11 +206,14 @@ def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, F, 
         res.append((loss.clone(), step.last_out.clone(), {k: v.grad.detach().clone() for k, v in m.named_parameters()},
                     cap["acts"][0][:sb.x.shape[0]].clone()))
     (la, oa, ga, a1a), (lb, ob, gb, a1b) = res
-    assert torch.equal(la, lb) and torch.equal(oa, ob) and torch.equal(a1a, a1b)
+    if D == 64:
+        assert torch.equal(la, lb) and torch.equal(oa, ob) and torch.equal(a1a, a1b)
+    else:
+        assert abs(float(la) - float(lb)) <= TOL * abs(float(lb)) and rel_inf(oa, ob, floor=1.0) <= TOL and rel_inf(a1a, a1b) <= TOL
     assert bool((a1a[gp[1]:gp[2]] == 0).all())
     for k in ga:
-        if k.startswith("conv1."):
-            assert rel_inf(ga[k], gb[k]) <= TOL, k
+        if k.startswith("conv1.") or D != 64:
+            assert rel_inf(ga[k], gb[k]) <= (TOL_DW if k.endswith("lin.weight") and D != 64 else TOL), k
         else:
             assert torch.equal(ga[k], gb[k]), k
     _, _, _, g64 = oracle.train_step_grads(params, sb.x, sb.edge_index, sb.batch, sb.y, B, dtype=torch.float64)
