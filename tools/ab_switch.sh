@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: per-kernel averages + ms/step of REAL and C5 with one FusedTrainStep switch on / off, interleaved twice.
-# usage: tools/ab_bits.sh [ENV_SWITCH=HCG_NO_POOLBITS] [CONFIGS="REAL C5"]
+# usage: tools/ab_switch.sh [ENV_SWITCH=HCG_NO_POOLBITS] [CONFIGS="REAL C5"]
 SW=${1:-HCG_NO_POOLBITS}
 CFGS=${2:-"REAL C5"}
 R=${GRAFT_REPO_ROOT:-/root/repo}
