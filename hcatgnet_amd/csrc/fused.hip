@@ -123,6 +123,36 @@ __device__ __forceinline__ TileRaw tile_raw(int t, int num_tiles, int gpt, int B
   return w;
 }
 
+// The tiles of one wave, round by round.  Full rounds: tile k * stride + 8 b + w (a workgroup's tiles of a round are
+// consecutive).  The LAST, partial round is dealt round-robin over the workgroups instead (position p = w * G + b): with the
+// plain formula its tiles went to the first workgroups' eight waves each while the other CUs idled -- 2 826 tiles on 2 048
+// waves (the ragged batch's small graphs) took two full rounds; dealt evenly every CU runs three of its waves a second time,
+// alone on their SIMDs.  `num_tiles` = no tile.
+// The host picks DEAL only when the last round IS partial (4096 tiles on 2048 waves: the plain form, whose code is the
+// one the headline configuration was tuned with -- the dealt form's extra scalars cost its kernels 1-1.7 us).
+template <bool DEAL>
+struct TileSeq {
+  int kf, rem, stride, first, last_p;
+  __device__ __forceinline__ TileSeq(int num_tiles, int wave) {
+    const int G = (int)gridDim.x;
+    stride = G * WAVES;
+    first = (int)blockIdx.x * WAVES + wave;
+    if constexpr (DEAL) {
+      kf = num_tiles / stride;
+      rem = num_tiles - kf * stride;
+      last_p = wave * G + (int)blockIdx.x;
+    } else {
+      kf = rem = last_p = 0;
+    }
+  }
+  // tile of round k; `prev` = the tile of round k - 1 (the plain form only adds the stride, as it always did)
+  __device__ __forceinline__ int at(int k, int prev, int num_tiles) const {
+    if constexpr (!DEAL) return prev + stride;
+    if (k < kf) return k * stride + first;
+    return (k == kf && last_p < rem) ? kf * stride + last_p : num_tiles;
+  }
+};
+
 __device__ __forceinline__ TileInfo tile_finish(const TileRaw& w, int gpt, int lane, int32_t* status) {
   TileInfo ti;
   ti.g0 = w.g0;
@@ -302,7 +332,8 @@ struct Stager {
 // them leaves as two bits per element, in the accumulator layout: poolbits[tile][0][lane] bit 16 b + i <-> value at
 // (row krow(i, h), column 32 b + r) is > 0, poolbits[tile][1][lane] the same positions: value == its graph's column max.
 // HEAD (needs POOL): the regression head rides in the TAIL of this launch (head_tile.h).  A workgroup's tiles are
-// {8 b + w + k * 8 grid}: runs of 8 gpt consecutive graphs per round k; once its waves have left the tile loop their LDS is
+// TileSeq's: {8 b + w + k * 8 grid} in the full rounds -- runs of 8 gpt consecutive graphs per round k -- and the dealt ones
+// of the last round; once its waves have left the tile loop their LDS is
 // free, the pooled rows they wrote are visible to the whole workgroup (workgroup-scope barrier), and the workgroup runs
 // readout forward, squared error and -- HEAD == 2 -- the UNSCALED readout backward over its own graphs (head_tile.h:
 // hcg_head16, 16-row tiles on all 8 waves): z, out, demb and one gradient slab + SSE partial per workgroup.  Round 2 spent a launch of its own (15 us at C3: a grid-wide exchange of
@@ -323,7 +354,7 @@ struct FwdHead {
 
 constexpr int SEMB_ROWS = 32;    // pooled rows a workgroup keeps in LDS for its head tail (C3: 16 graphs per workgroup)
 
-template <int RC, bool BACKWARD>
+template <int RC, bool BACKWARD, bool DEAL>
 __device__ __forceinline__ void fwd_head_tail(void* lds_base, const float* semb, const FwdHead& H, const float* __restrict__ emb,
                                               int gpt, int B, int num_tiles, float slope) {
   using namespace hcg_head16;
@@ -335,25 +366,47 @@ __device__ __forceinline__ void fwd_head_tail(void* lds_base, const float* semb,
   __syncthreads();             // every wave has left its tiles: LDS free, this workgroup's pooled rows visible to all of it
   H16STAMP(1);
   Lds& HL = *reinterpret_cast<Lds*>(lds_base);
-  const int R = WAVES * gpt;                               // graphs of this workgroup per round of its waves
-  const int stride = gridDim.x * WAVES;                    // tiles between two rounds
+  const int R = WAVES * gpt;                               // graphs of this workgroup per FULL round of its waves
+  const int G = (int)gridDim.x, stride = G * WAVES;        // tiles between two rounds
+  // TileSeq: full rounds, tiles of the dealt last round (not DEAL: every round, the last one included, is a "full" one whose
+  // run of tiles may end early)
+  const int kf = DEAL ? num_tiles / stride : 0;
+  const int rem = DEAL ? num_tiles - kf * stride : 0;
   int rows_total = 0;
-  for (int tb = blockIdx.x * WAVES; tb < num_tiles; tb += stride) {
-    const int left = B - tb * gpt;
-    rows_total += left < R ? left : R;
+  if constexpr (DEAL) {
+    for (int k = 0; k < kf; ++k) {
+      const int left = B - (k * stride + (int)blockIdx.x * WAVES) * gpt;
+      rows_total += left < R ? left : R;
+    }
+  } else {
+    for (int tb = blockIdx.x * WAVES; tb < num_tiles; tb += stride) {
+      const int left = B - tb * gpt;
+      rows_total += left < R ? left : R;
+    }
   }
-  const int base = blockIdx.x * WAVES * gpt, step_g = stride * gpt;
+  const int rows_full = rows_total;
+  for (int p = (int)blockIdx.x; p < rem; p += G) {         // the last round's tiles of this workgroup: waves 0, 1, ...
+    const int left = B - (kf * stride + p) * gpt;
+    rows_total += left < gpt ? left : gpt;
+  }
+  const int base = blockIdx.x * WAVES * gpt, step_g = stride * gpt, base_last = (kf * stride + (int)blockIdx.x) * gpt;
   const bool in_lds = rows_total <= SEMB_ROWS;             // block-uniform
   H16STAMP(2);
   for (int j0 = 0; j0 < rows_total; j0 += RT) {
     const int n = rows_total - j0 < RT ? rows_total - j0 : RT;
-    tile<RC, BACKWARD>(HL, S, P, [=](int row) { const int j = j0 + row, k = j / R; return base + k * step_g + (j - k * R); },
+    tile<RC, BACKWARD>(HL, S, P,
+                       [=](int row) {
+                         const int j = j0 + row;
+                         if (j < rows_full) { const int k = j / R; return base + k * step_g + (j - k * R); }
+                         const int jj = j - rows_full, w = jj / gpt;        // (only the batch's very last tile can be short: it is
+                         return base_last + w * G * gpt + (jj - w * gpt);   //  the last slot of its workgroup)
+                       },
                        n, H.C, slope, in_lds ? semb + j0 * ES : nullptr, emb, H.y, H.z, H.out, H.demb, j0 == 0);
   }
   end<RC, BACKWARD>(HL, S, H.C, H.slabs + (size_t)blockIdx.x * SLAB, H.slabs + (size_t)gridDim.x * SLAB + blockIdx.x);
 }
 
-template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false, int HEAD = 0>
+template <int KPAD, bool VEC, bool POOL, bool STACK2, bool BITS = false, int HEAD = 0, bool DEAL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ W2, const float* __restrict__ bias2,
@@ -375,8 +428,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   WaveLdsF& L = lds[wave];
   int* cnt = reinterpret_cast<int*>(L.buf);
   const int r = lane & 31, h = lane >> 5;
-  const int stride = gridDim.x * WAVES;
-  int t = blockIdx.x * WAVES + wave;
+  const TileSeq<DEAL> seq(num_tiles, wave);
+  int t = DEAL ? seq.at(0, 0, num_tiles) : seq.first;
   bool have = t < num_tiles;
 
   // first tile's loads go out before anything else
@@ -386,7 +439,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   TileRaw raw_next;   // scalars of the tile after the current one, always one tile ahead
   if (have) {
     const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
-    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    raw_next = tile_raw(seq.at(1, t, num_tiles), num_tiles, gpt, B, graph_ptr, edge_ptr);
     ti = tile_finish(raw0, gpt, lane, status);
     sx.load(x, F, N, ti.nbase, ti.n, lane);
     te.load(ti, graph_ptr, ei, E, lane);
@@ -417,17 +470,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
     for (int i = 0; i < 16; ++i) dvr[i] = L.ldinv[krow(i, h)];
     sx.write(L.buf, F, ti.n, lane);
   }
-  int round_it = 0;      // rounds of this wave so far (tile t = first + round_it * stride)
+  int round_it = 0;      // rounds of this wave so far (tile t = seq.at(round_it))
   while (have) {
     STAMP(1 + 8 * stamp_it);
     // prefetch the next tile of this wave (registers only) while this one computes
-    const int tn = t + stride;
+    const int tn = seq.at(round_it + 1, t, num_tiles);
     const bool have_next = tn < num_tiles;
     TileInfo tin;
     TileEdges ten;
     Stager<KPAD, VEC> sxn;
     const TileRaw raw_cur = raw_next;                                    // loaded one tile ago
-    raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);   // consumed one tile from now
+    raw_next = tile_raw(seq.at(round_it + 2, tn, num_tiles), num_tiles, gpt, B, graph_ptr, edge_ptr);   // consumed one tile from now
     if (VEC && have_next) {   // (the scalar-staging variants are short of registers: they load after the compute)
       tin = tile_finish(raw_cur, gpt, lane, status);
       sxn.load(x, F, N, tin.nbase, tin.n, lane);
@@ -594,8 +647,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
   STAMP(63);
   STAMP_FLUSH();
   if constexpr (HEAD != 0) {
-    if (HA.C == 1) fwd_head_tail<1, HEAD == 2>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
-    else fwd_head_tail<hcg_head::RCMAX, HEAD == 2>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
+    if (HA.C == 1) fwd_head_tail<1, HEAD == 2, DEAL>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
+    else fwd_head_tail<hcg_head::RCMAX, HEAD == 2, DEAL>(&lds[0], semb, HA, emb, gpt, B, num_tiles, slope);
   }
 }
 
@@ -607,7 +660,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_fwd(
 // =====================================================================================================
 // BITS (needs POOLG): the layer's output was never stored; its sign / is-the-column-max bits (`poolbits`, written by the
 // BITS forward over the same tiles) stand in for a_out and emb.
-template <int KPAD, bool VEC, bool NEEDS_DX, bool POOLG, bool BITS = false>
+template <int KPAD, bool VEC, bool NEEDS_DX, bool POOLG, bool BITS = false, bool DEAL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     const float* __restrict__ dout, const float* __restrict__ demb, const float* __restrict__ emb,
     const float* __restrict__ a_out, const uint32_t* __restrict__ poolbits, const float* __restrict__ x, int F,
@@ -631,10 +684,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   static_assert(!BITS || POOLG, "the bit form is the pooled backward");
   const bool premask = NEEDS_DX && (apply_act & 2);
   const bool use_out = !BITS && a_out != nullptr;
-  const int stride = gridDim.x * WAVES;
+  const TileSeq<DEAL> seq(num_tiles, wave);
+  int round_it = 0;      // rounds of this wave so far (tile t = seq.at(round_it))
 
   // first tile's loads go out before anything else
-  int t = blockIdx.x * WAVES + wave;
+  int t = DEAL ? seq.at(0, 0, num_tiles) : seq.first;
   bool have = t < num_tiles;
   TileInfo ti;
   TileRaw raw_next;
@@ -643,7 +697,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
   TileEdges te;
   if (have) {
     const TileRaw raw0 = tile_raw(t, num_tiles, gpt, B, graph_ptr, edge_ptr);
-    raw_next = tile_raw(t + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    raw_next = tile_raw(seq.at(1, t, num_tiles), num_tiles, gpt, B, graph_ptr, edge_ptr);
     ti = tile_finish(raw0, gpt, lane, status);
     if (BITS) {
       pos = poolbits[(size_t)t * 128 + lane];
@@ -774,10 +828,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
     BSTAMP(2 + 8 * bstamp_it);
     // next tile of this wave: scalars one tile further ahead (the row loads wait until the accumulators leave room:
     // measured with the loads here, the dx / pooled variants spill 24-89 VGPRs and run 20-30 % SLOWER)
-    const int tn = t + stride;
+    const int tn = seq.at(round_it + 1, t, num_tiles);
     const bool have_next = tn < num_tiles;
     const TileRaw raw_cur = raw_next;
-    raw_next = tile_raw(tn + stride, num_tiles, gpt, B, graph_ptr, edge_ptr);
+    raw_next = tile_raw(seq.at(round_it + 2, tn, num_tiles), num_tiles, gpt, B, graph_ptr, edge_ptr);
     TileInfo tin;
     Stager<DD, true> san{}, sdn;
     TileEdges ten;
@@ -940,6 +994,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_fused_layer_bwd(
 
     BSTAMP(7 + 8 * bstamp_it);
     have = have_next;
+    ++round_it;
     if (have_next) {
       tin = tile_finish(raw_cur, gpt, lane, status);
       if (BITS) {
@@ -1100,10 +1155,14 @@ extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t strea
   const bool vec = (F == 64 || F == 32) && ((uintptr_t)x % 16 == 0);
   const dim3 g(grid), blk(WAVES * 64);
   if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(a->graph_ptr); E = 1; }  // readable dummy; no tile has edges
-#define LAUNCH_FWD(KP, VC, PL, ST, BT, HD)                                                                               \
-  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST, BT, HD>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, \
+  // a partial last round is dealt evenly over the workgroups (TileSeq); whole rounds keep the plain form
+  const bool deal = tiles % (grid * WAVES) != 0 && tiles > grid * WAVES;
+#define LAUNCH_FWD_D(KP, VC, PL, ST, BT, HD, DL)                                                                           \
+  hipLaunchKernelGGL((k_fused_layer_fwd<KP, VC, PL, ST, BT, HD, DL>), g, blk, 0, stream, x, (int)F, W, b, W2, b2, edge_index, \
                      E, a->graph_ptr, a->edge_ptr, N, graphs_per_tile, (int)B, tiles, a->slope, a->apply_act, out, out2, \
                      emb, poolbits, a->status, H)
+#define LAUNCH_FWD(KP, VC, PL, ST, BT, HD)                                                                               \
+  do { if (deal) LAUNCH_FWD_D(KP, VC, PL, ST, BT, HD, true); else LAUNCH_FWD_D(KP, VC, PL, ST, BT, HD, false); } while (0)
 #define DISPATCH_FWD(KP, VC)                                                                                     \
   do {                                                                                                           \
     if (head)        { if (head_bwd) LAUNCH_FWD(KP, VC, true, true, true, 2); else LAUNCH_FWD(KP, VC, true, true, true, 1); } \
@@ -1115,6 +1174,7 @@ extern "C" int hcg_fused_forward(const hcg_fused_fwd_args* a, hcg_stream_t strea
   else         { if (vec) DISPATCH_FWD(64, true); else DISPATCH_FWD(64, false); }
 #undef DISPATCH_FWD
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD_D
   HCG_CHECK_LAUNCH();
   return HCG_OK;
 }
@@ -1160,10 +1220,13 @@ static int launch_fused_bwd(const float* dout, const float* demb, const float* e
     const bool ndx = dx != nullptr;
     const dim3 g(grid), blk(WAVES * 64);
     if (E == 0) { edge_index = reinterpret_cast<const int64_t*>(graph_ptr); E = 1; }  // readable dummy
-#define LAUNCH_BWD(KP, VC, DX, PG, BT)                                                                                \
-  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG, BT>), g, blk, 0, stream, dout, demb, emb, out, poolbits, x,    \
+    const bool deal = tiles % (grid * WAVES) != 0 && tiles > grid * WAVES;     // (as the forward: TileSeq)
+#define LAUNCH_BWD_D(KP, VC, DX, PG, BT, DL)                                                                          \
+  hipLaunchKernelGGL((k_fused_layer_bwd<KP, VC, DX, PG, BT, DL>), g, blk, 0, stream, dout, demb, emb, out, poolbits, x, \
                      (int)F, W, edge_index, E, graph_ptr, edge_ptr, N, graphs_per_tile, (int)B, tiles, slope, apply_act, \
                      dx, partials, status)
+#define LAUNCH_BWD(KP, VC, DX, PG, BT)                                                                                \
+  do { if (deal) LAUNCH_BWD_D(KP, VC, DX, PG, BT, true); else LAUNCH_BWD_D(KP, VC, DX, PG, BT, false); } while (0)
 #define DISPATCH_BWD(KP, VC)                                                                                   \
   do {                                                                                                         \
     if (bits)     { if (ndx) LAUNCH_BWD(KP, VC, true, true, true); else LAUNCH_BWD(KP, VC, false, true, true); }   \
@@ -1174,6 +1237,7 @@ static int launch_fused_bwd(const float* dout, const float* demb, const float* e
     else            { if (vec) DISPATCH_BWD(64, true); else DISPATCH_BWD(64, false); }
 #undef DISPATCH_BWD
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD_D
     HCG_CHECK_LAUNCH();
   }
   return HCG_OK;
