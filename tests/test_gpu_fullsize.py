@@ -29,6 +29,12 @@ CASES = {
     "REAL":   ("REAL", dict(),                                           25,  64,  29),
     "BIARYL": ("REAL", dict(num_graphs=2048, feat=32),                   32,  64,  31),
     "RAGGED": ("C2", dict(nodes_jitter=6, group_by_size=True),           64,  64,  37),
+    # a partial last round of tiles, dealt evenly over the workgroups (fused.hip: TileSeq<DEAL>) with the head in the forward's
+    # tail: 2500 tiles on 2048 waves; 7001 graphs of ~10 atoms = 2334 tiles of three graphs, the last one holding ONE graph
+    "C3_2500": ("C2", dict(num_graphs=2500),                             64,  64,  41),
+    # (trees: a triangle makes structural twins -- two nodes with the same closed neighbourhood have EQUAL outputs in exact
+    #  arithmetic, so which of them is "the" maximum is rounding's call and no re-draw of the features makes it decidable)
+    "TINY_7001": ("C2", dict(num_graphs=7001, nodes=10, nodes_jitter=0, extra_bonds=0), 64, 64, 43),
 }
 
 
@@ -56,6 +62,10 @@ def test_full_size_step_every_gradient_vs_oracle(H, oracle, case):
     N, B = sb.x.shape[0], sb.num_graphs
     if case == "RAGGED":
         assert 0 < sb.n_small < B and sb.max_nodes > 32          # both families ran
+    if case in ("C3_2500", "TINY_7001"):
+        gpt = 32 // sb.max_nodes
+        tiles = -(-B // gpt)
+        assert tiles > 2048 and tiles % 2048 != 0 and step._head_in_forward(step._prepare(batch, False))
     cap = step._bufs["cap"]
     got = {k: v.grad.detach().clone() for k, v in m.named_parameters()}
     p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
