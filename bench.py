@@ -442,6 +442,9 @@ def main():
     F, D = cfg["feat"], cfg["hidden"]
     opt = H.default_options(embedding_dim=D)
     model = H.make_network("GCN", opt, F).to(dev)
+    if os.environ.get("HCG_TALL_MIN_NODES"):          # development A/B: where the 64-wide backward moves to the wide-layer route
+        from hcatgnet_amd import functional as _HF
+        _HF.TALL_MIN_NODES_D64 = int(os.environ["HCG_TALL_MIN_NODES"])
     if os.environ.get("HCG_FAMILY_MID") == "1":       # development A/B: keep every layer on the one-graph-per-workgroup kernels
         for cv in [model.conv1] + list(model.conv_layers):
             cv.family = "mid"

@@ -378,10 +378,11 @@ class _TallLayerFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None
 
 
-# 64-wide layers: the three-launch backward of csrc/tall.hip pays off once a batch fills the chip; the reference's own
-# batch of 40 graphs (3.5 k nodes: launch-bound) is 11 % faster on the one-launch kernel of csrc/mid.hip (measured: 0.072
-# vs 0.080 ms/step, profiles/r02_c vs r02_e REAL40)
-TALL_MIN_NODES_D64 = 32768
+# 64-wide layers: the dense-parts backward of csrc/tall.hip pays off once a batch fills the chip several times over; below
+# ~70 k nodes the one-launch-per-layer kernels of csrc/mid.hip are faster (tools/sweep_tall_threshold.sh on the reference's
+# graph sizes, end of round 3, ms/step mid vs wide-layer route: 34 k nodes 0.0727 / 0.0766, 45 k 0.0752 / 0.0791, 67 k 0.0968 /
+# 0.0971, 89 k 0.1176 / 0.1131, 133 k 0.1587 / 0.1464; the reference's own batch of 40 graphs = 3.5 k nodes: 11 % in round 2)
+TALL_MIN_NODES_D64 = 72000
 
 
 def tall_supported(plan: BatchPlan, F: int, D: int) -> bool:

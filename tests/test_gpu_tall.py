@@ -144,14 +144,15 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
 
 
 @pytest.mark.parametrize("D,F,nodes,jitter,B", [(64, 25, 100, 17, 400), (64, 64, 160, 30, 260), (128, 64, 150, 20, 24), (128, 128, 200, 24, 12)])
-def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, D, F, nodes, jitter, B):
+def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, monkeypatch, D, F, nodes, jitter, B):
     """Training form of the pooled layer on the wide-layer route (`poolbits` of hcg_tall_layer_fwd / hcg_tall_layer_bwd): its
     activations never leave the chip -- one byte per (row, 4 columns) does (sign, is-the-column-max).  Loss, outputs, pooled
     embedding and EVERY gradient are BITWISE those of the plain form (output + emb read back), with exact max-pool ties in the
     batch (a graph of identical rows: its equal-degree nodes tie).  (Against the oracle: the full-size and fuzz tests run this
     form, it is the default.)"""
-    from hcatgnet_amd import synth
+    from hcatgnet_amd import synth, functional as HF
     from hcatgnet_amd.train import FusedTrainStep
+    monkeypatch.setattr(HF, "TALL_MIN_NODES_D64", 0)      # (these batches are small: the host would keep 64-wide layers on mid.hip)
     sb = synth.make_batch(num_graphs=B, nodes=nodes, nodes_jitter=jitter, feat=F, extra_bonds=4, max_degree=4, seed=77)
     gp = torch.zeros(B + 1, dtype=torch.int64)
     gp[1:] = torch.bincount(sb.batch, minlength=B).cumsum(0)
@@ -176,7 +177,7 @@ def test_pooled_layer_bit_form_is_bitwise_the_plain_form(H, D, F, nodes, jitter,
 
 @pytest.mark.parametrize("D,F,nodes,jitter,B", [(64, 25, 100, 17, 400), (64, 64, 160, 30, 260), (64, 32, 90, 20, 420),
                                                 (128, 128, 200, 24, 12), (128, 28, 150, 40, 24), (128, 64, 90, 30, 20)])
-def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, D, F, nodes, jitter, B):
+def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, monkeypatch, D, F, nodes, jitter, B):
     """Training form of the FIRST layer on the wide-layer route (`xagg` + `signbits` of hcg_tall_layer_fwd / _bwd): the forward
     also leaves Ahat x and the sign pieces of its output, the backward is ONE dense launch dW = (dA (.) leaky'(A))^T (Ahat x).
     The same sums as the transpose-sum form in another order: every gradient within 1e-5 of that form's (layer-1 weight
@@ -184,8 +185,9 @@ def test_first_layer_dense_backward_equals_the_transpose_sum_form(H, oracle, D, 
     second layer's and the head's gradients -- bitwise for 64-wide layers (128-wide: the training form's forward scales the x
     rows by dinv BEFORE the GEMM instead of behind it, so everything is within 1e-5); exact zeros in the first layer's output
     (an all-zero graph with zero bias: LeakyReLU'(0) = slope) included."""
-    from hcatgnet_amd import synth
+    from hcatgnet_amd import synth, functional as HF
     from hcatgnet_amd.train import FusedTrainStep
+    monkeypatch.setattr(HF, "TALL_MIN_NODES_D64", 0)
     sb = synth.make_batch(num_graphs=B, nodes=nodes, nodes_jitter=jitter, feat=F, extra_bonds=4, max_degree=4, seed=91)
     gp = torch.zeros(B + 1, dtype=torch.int64)
     gp[1:] = torch.bincount(sb.batch, minlength=B).cumsum(0)
