@@ -426,7 +426,7 @@ def main():
     lib = _lib.load()
     # development A/B switches (tools/ab_env.sh): measurement tooling only, the product has no environment switches
     for env, attr in (("HCG_NO_POOLBITS", "POOLBITS"), ("HCG_NO_PREMASK", "PREMASK"), ("HCG_NO_OVERLAP", "OVERLAP_GROUPS"),
-                      ("HCG_NO_HEAD_IN_FORWARD", "HEAD_IN_FORWARD"), ("HCG_NO_TALL_PREMASK", "TALL_PREMASK"), ("HCG_NO_XAGG", "XAGG")):
+                      ("HCG_NO_HEAD_IN_FORWARD", "HEAD_IN_FORWARD"), ("HCG_NO_TALL_PREMASK", "TALL_PREMASK"), ("HCG_NO_XAGG", "XAGG"), ("HCG_NO_XAGG_MID", "XAGG_MID")):
         if os.environ.get(env) == "1":
             setattr(FusedTrainStep, attr, False)
     log(f"rank {rank}/{world}: library loaded")

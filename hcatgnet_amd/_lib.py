@@ -101,7 +101,7 @@ SIGNATURES = {
     "hcg_tall_supported": (INT, [I64, I64, I64, I64]),
     "hcg_tall_workspace_bytes": (SZ, [I64, I64, I64, I64]),
     "hcg_tall_layer_fwd": (INT, [P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, P, P, P, P, SZ, P]),
-    "hcg_tall_layer_bwd": (INT, [P, P, P, P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, SZ, P]),
+    "hcg_tall_layer_bwd": (INT, [P, P, P, P, P, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, F32, INT, P, P, P, SZ, P]),
     "hcg_tall_reduce_jobs": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
     "hcg_fused_reduce_job": (INT, [P, SZ, I64, I64, I64, I64, INT, P, P, P]),
     "hcg_readout2_bwd_partial": (INT, [P, P, P, P, P, I64, I64, I64, F32, P, P, SZ, P]),

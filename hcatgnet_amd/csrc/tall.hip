@@ -165,10 +165,20 @@ __device__ __forceinline__ constexpr int dw_oct(int c, int o) { return o ^ ((c >
 // column sums of G -- leaves in `db_slabs` [grid][D].
 template <int DB, int NBF, bool XVEC = true, bool FIRST = false>
 __global__ __launch_bounds__(DWT, DB == 2 ? 4 : 2) void k_tall_dw(const float* __restrict__ Z, const float* __restrict__ X, int F,
-                                                                 float* __restrict__ slabs, int N,
+                                                                 float* __restrict__ slabs, int N_arg,
                                                                  const unsigned short* __restrict__ signs = nullptr,
-                                                                 float slope = 1.f, float* __restrict__ db_slabs = nullptr) {
+                                                                 float slope = 1.f, float* __restrict__ db_slabs = nullptr,
+                                                                 const int32_t* __restrict__ n_dev = nullptr) {
   static_assert(!FIRST || ((DB == 2 || DB == 4) && XVEC), "first-layer form: padded Ahat x rows");
+  // `n_dev` (FIRST): the batch's node count in device memory (graph_ptr[B]) -- a captured epoch's batch slots have a fixed
+  // CAPACITY of rows (train.EpochWindow), the launch is sized for it and the rows past the batch's own stay out of the sums
+  int N = N_arg;
+  if constexpr (FIRST) {
+    if (n_dev) {
+      const int nd = __builtin_amdgcn_readfirstlane(n_dev[0]);
+      N = nd < N_arg ? (nd > 0 ? nd : 1) : N_arg;
+    }
+  }
   constexpr int D = DB * 32, FP = NBF * 32, TR = 64, LDT = TR + 8;
   constexpr int NTILE = DB * NBF, TPW = NTILE >= DWW ? NTILE / DWW : 1, KPARTS = NTILE >= DWW ? 1 : DWW / NTILE;
   static_assert(NTILE * KPARTS == DWW * TPW, "block -> wave map");
@@ -1280,7 +1290,8 @@ extern "C" int hcg_tall_layer_fwd(const float* x, const float* W, const float* b
 // apply_act: bit 0 = multiply the upstream gradient by leaky'(out); bit 1 = hand dx down already multiplied by leaky'(x).
 // Leaves dW / db slabs in `workspace`: describe them with hcg_tall_reduce_jobs (two jobs) and sum with hcg_step_tail.
 extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const float* emb, const float* out,
-                                  const uint8_t* poolbits, const float* xagg, const uint8_t* signbits, const float* x,
+                                  const uint8_t* poolbits, const float* xagg, const uint8_t* signbits, const int32_t* n_dev,
+                                  const float* x,
                                   const float* W, const int64_t* edge_index, int64_t E, const int32_t* graph_ptr,
                                   const int32_t* edge_ptr, int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes,
                                   int64_t max_edges, float slope, int apply_act, float* dx, int32_t* status, void* workspace,
@@ -1308,7 +1319,7 @@ extern "C" int hcg_tall_layer_bwd(const float* dout, const float* demb, const fl
     hipError_t e = allow_lds<k_tall_dw<DBV, NBF, true, true>>(lds);                                                      \
     if (e != hipSuccess) return hcg_hip_err(e);                                                                          \
     hipLaunchKernelGGL((k_tall_dw<DBV, NBF, true, true>), grid, blk, lds, stream, dout, xagg, fp, ws.dw_slabs, (int)N,   \
-                       reinterpret_cast<const unsigned short*>(signbits), slope_eff, ws.db_slabs);                       \
+                       reinterpret_cast<const unsigned short*>(signbits), slope_eff, ws.db_slabs, n_dev);                \
   } while (0)
     if (D == 64) { if (fp == 32) LAUNCH_DW_FIRST(2, 1); else LAUNCH_DW_FIRST(2, 2); }
     else         { if (fp == 32) LAUNCH_DW_FIRST(4, 1); else if (fp == 64) LAUNCH_DW_FIRST(4, 2); else LAUNCH_DW_FIRST(4, 4); }

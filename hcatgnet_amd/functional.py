@@ -365,7 +365,7 @@ class _TallLayerFn(torch.autograd.Function):
         wsb = lib.hcg_tall_workspace_bytes(N, plan.B, F, D)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         stream = _lib.stream_ptr()
-        rc = lib.hcg_tall_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), None, None, None, _lib.ptr(x), _lib.ptr(weight),
+        rc = lib.hcg_tall_layer_bwd(_lib.ptr(dout), _lib.ptr(demb), _lib.ptr(emb), _lib.ptr(out), None, None, None, None, _lib.ptr(x), _lib.ptr(weight),
                                     _lib.ptr(plan.edge_index), plan.E, _lib.ptr(plan.graph_ptr), _lib.ptr(plan.edge_ptr), N,
                                     plan.B, F, D, plan.max_nodes, plan.max_edges, ctx.slope, int(ctx.apply_act), _lib.ptr(dx),
                                     _lib.ptr(plan.status), _lib.ptr(ws), wsb, stream)

@@ -66,6 +66,7 @@ class FusedTrainStep:
     # code): POOLBITS = False stores the pooled layer's activations as the plain forms do, PREMASK = False leaves every
     # activation derivative to the layer that owns it, HEAD_IN_FORWARD = False keeps the head a launch of its own
     POOLBITS = True
+    XAGG_MID = True                # ... and behind the one-graph-per-workgroup kernels (batches under functional.TALL_MIN_NODES_D64)
     XAGG = True                    # first layer on the wide-layer route: Ahat x + sign pieces from the forward, one dense backward launch
     TALL_PREMASK = False           # (measured: the dense dx kernel's strided mask loads cost what the layer below saves -- DESIGN 7)
     PREMASK = True
@@ -403,8 +404,15 @@ class FusedTrainStep:
                                             p(pe), p(bits), p(xagg), p(signs), p(plan.status), p(ws), wsb, stream)
                 _lib.check(rc, "hcg_tall_layer_fwd")
             else:
+                xagg = signs = None
+                if (l == 0 and n_conv >= 2 and D == 64 and Fl <= 64 and self.XAGG and self.XAGG_MID and not c.forward_only
+                        and gpts[1] <= 0 and lib.hcg_tall_supported(Fl, D, mxn, mxe)):
+                    kp = 32 if Fl <= 32 else 64            # (as on the wide-layer route: Ahat x + sign pieces for the dense backward)
+                    xagg = self._ws(bufs, "xagg", N * kp * 4, c.dev)
+                    signs = self._ws(bufs, "signs", N * (D // 8), c.dev)
+                    c.xagg = (xagg, signs)
                 rc = lib.hcg_mid_layer_fwd(p(h), p(c.W[l]), p(c.bs[l]), p(plan.edge_index), plan.E, p(plan.graph_ptr),
-                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe), None, None, None,
+                                           p(plan.edge_ptr), N, B, Fl, D, mxn, mxe, slope, 1, p(acts[l]), p(pe), None, p(xagg), p(signs),
                                            p(plan.status), stream)
                 _lib.check(rc, "hcg_mid_layer_fwd")
             h = acts[l]
@@ -511,10 +519,23 @@ class FusedTrainStep:
                     first = c.xagg if (l == 0 and not last and dx is None) else None     # (Ahat x, sign pieces) of the forward
                     a_out = p(acts[l]) if ((act or last) and bits is None and first is None) else None
                     rc = lib.hcg_tall_layer_bwd(*up, a_out, p(bits), p(first[0]) if first else None, p(first[1]) if first else None,
-                                                p(inp), p(c.W[l]), *geo, mxn, mxe, slope, act | (2 if premasked else 0), p(dx),
+                                                None, p(inp), p(c.W[l]), *geo, mxn, mxe, slope, act | (2 if premasked else 0), p(dx),
                                                 p(plan.status), p(tws), twsb, stream)
                     _lib.check(rc, "hcg_tall_layer_bwd")
                     _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, 1 if first else 0, g(cv.lin.weight), g(cv.bias),
+                                                        self._job_slot(c)), "hcg_tall_reduce_jobs")
+                    c.njobs += 1                          # (two jobs: dW, db)
+                elif l == 0 and not last and c.xagg is not None:
+                    # the first layer's backward as ONE dense launch over the forward's Ahat x (csrc/tall.hip: k_tall_dw<FIRST>) also
+                    # behind the one-graph-per-workgroup kernels; the batch's node count is read on the device (graph_ptr[B]): a
+                    # captured epoch's slot has a CAPACITY of rows
+                    premasked = False
+                    tws, twsb = self._tall_ws(bufs, l, N, B, Fl, D, c.dev)
+                    rc = lib.hcg_tall_layer_bwd(p(dh), None, None, None, None, p(c.xagg[0]), p(c.xagg[1]),
+                                                plan.graph_ptr.data_ptr() + 4 * B, p(inp), p(c.W[l]), *geo, mxn, mxe, slope, act, None,
+                                                p(plan.status), p(tws), twsb, stream)
+                    _lib.check(rc, "hcg_tall_layer_bwd")
+                    _lib.check(lib.hcg_tall_reduce_jobs(p(tws), twsb, N, B, Fl, D, 1, g(cv.lin.weight), g(cv.bias),
                                                         self._job_slot(c)), "hcg_tall_reduce_jobs")
                     c.njobs += 1                          # (two jobs: dW, db)
                 else:

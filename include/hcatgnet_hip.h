@@ -289,7 +289,10 @@ int hcg_tall_layer_fwd(const float* x, const float* W, const float* b,
  * hcg_tall_reduce_jobs(first_layer_form = 1) describes its slabs. */
 int hcg_tall_layer_bwd(const float* dout /*nullable*/, const float* demb, const float* emb,
                        const float* out, const uint8_t* poolbits /*nullable*/,
-                       const float* xagg /*nullable*/, const uint8_t* signbits /*nullable*/, const float* x, const float* W,
+                       const float* xagg /*nullable*/, const uint8_t* signbits /*nullable*/,
+                       const int32_t* n_dev /*nullable; first-layer form: the batch's node count on the device (graph_ptr + B) when
+                                              N is a CAPACITY (a captured epoch's batch slot): rows past it stay out of the sums*/,
+                       const float* x, const float* W,
                        const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, const int32_t* edge_ptr,
                        int64_t N, int64_t B, int64_t F, int64_t D, int64_t max_nodes, int64_t max_edges,
                        float slope, int apply_act, float* dx /*nullable*/, int32_t* status,

@@ -121,7 +121,7 @@ def test_tall_backward_hands_down_a_premasked_dx(H, D, feat):
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
         dx = torch.full((N, F_), float("nan"), device="cuda") if want_dx else None
         dW, db = torch.empty(D, F_, device="cuda"), torch.empty(D, device="cuda")
-        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), None, None, None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
+        _lib.check(lib.hcg_tall_layer_bwd(p(dout_), None, None, p(out_), None, None, None, None, p(x_), p(W_), p(plan.edge_index), plan.E, p(plan.graph_ptr),
                                           p(plan.edge_ptr), N, B, F_, D, mxn, mxe, slope, flags, p(dx), p(plan.status), p(ws), wsb,
                                           st), "hcg_tall_layer_bwd")
         jb = _lib.job_bytes()

@@ -43,9 +43,9 @@ cases = {
   "mid  fwd L1": lambda: chk(lib.hcg_mid_layer_fwd(p(x), p(W1), p(b1), ei, E, gp, ep, N, B, F, D, mxn, mxe, slope, 1, p(a1), None, None, None, None, stt, st), "f"),
   "tall fwd L2+pool": lambda: chk(lib.hcg_tall_layer_fwd(p(a1), p(W2), p(b2), ei, E, gp, ep, N, B, D, D, mxn, mxe, slope, 1, p(a2), p(emb), None, None, None, stt, p(wst), wst.numel(), st), "f"),
   "mid  fwd L2+pool": lambda: chk(lib.hcg_mid_layer_fwd(p(a1), p(W2), p(b2), ei, E, gp, ep, N, B, D, D, mxn, mxe, slope, 1, p(a2), p(emb), None, None, None, stt, st), "f"),
-  "tall bwd L2 (pooled, dx premasked)": lambda: chk(lib.hcg_tall_layer_bwd(None, p(demb), p(emb), p(a2), None, None, None, p(a1), p(W2), ei, E, gp, ep, N, B, D, D, mxn, mxe, slope, 3, p(dx), stt, p(wst), wst.numel(), st), "b"),
+  "tall bwd L2 (pooled, dx premasked)": lambda: chk(lib.hcg_tall_layer_bwd(None, p(demb), p(emb), p(a2), None, None, None, None, p(a1), p(W2), ei, E, gp, ep, N, B, D, D, mxn, mxe, slope, 3, p(dx), stt, p(wst), wst.numel(), st), "b"),
   "mid  bwd L2 (pooled, dx premasked)": lambda: chk(lib.hcg_mid_layer_bwd(None, p(demb), p(emb), p(a2), p(a1), p(W2), ei, E, gp, ep, N, B, D, D, mxn, mxe, slope, 3, p(dx), stt, p(wsm), wsm.numel(), st), "b"),
-  "tall bwd L1 (no dx)": lambda: chk(lib.hcg_tall_layer_bwd(p(dx), None, None, None, None, None, None, p(x), p(W1), ei, E, gp, ep, N, B, F, D, mxn, mxe, slope, 0, None, stt, p(wst), wst.numel(), st), "b"),
+  "tall bwd L1 (no dx)": lambda: chk(lib.hcg_tall_layer_bwd(p(dx), None, None, None, None, None, None, None, p(x), p(W1), ei, E, gp, ep, N, B, F, D, mxn, mxe, slope, 0, None, stt, p(wst), wst.numel(), st), "b"),
   "mid  bwd L1 (no dx)": lambda: chk(lib.hcg_mid_layer_bwd(p(dx), None, None, None, p(x), p(W1), ei, E, gp, ep, N, B, F, D, mxn, mxe, slope, 0, None, stt, p(wsm), wsm.numel(), st), "b"),
 }
 for k, fn in cases.items():
