@@ -382,7 +382,9 @@ class _TallLayerFn(torch.autograd.Function):
 # ~70 k nodes the one-launch-per-layer kernels of csrc/mid.hip are faster (tools/sweep_tall_threshold.sh on the reference's
 # graph sizes, end of round 3, ms/step mid vs wide-layer route: 34 k nodes 0.0727 / 0.0766, 45 k 0.0752 / 0.0791, 67 k 0.0968 /
 # 0.0971, 89 k 0.1176 / 0.1131, 133 k 0.1587 / 0.1464; the reference's own batch of 40 graphs = 3.5 k nodes: 11 % in round 2)
-TALL_MIN_NODES_D64 = 72000
+# (with the first layer's dense backward behind BOTH routes the crossover moved again: 67 k 0.0920 / 0.0959, 89 k 0.1100 / 0.1107,
+#  133 k 0.1465 / 0.1458, 177 k 0.1799 / 0.1689 -- profiles/r03_v_sweep_tall_threshold.txt)
+TALL_MIN_NODES_D64 = 140000
 
 
 def tall_supported(plan: BatchPlan, F: int, D: int) -> bool:
